@@ -1,0 +1,23 @@
+"""pytest configuration: registers the `gpu` marker and puts the repo root on sys.path.
+
+`-m "not gpu"`  : oracle vs. golden fixtures, host logic, C-ABI symbol checks (no GPU needed)
+`-m gpu`        : parity tests proper -- HIP path (through the C-ABI) vs. the oracle, on a MI355X
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

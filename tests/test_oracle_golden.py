@@ -1,0 +1,177 @@
+"""The oracle (oracle/) against the golden vectors produced by the reference's own code
+(tests/golden/make_fixtures.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as omodel
+from oracle import postproc as opost
+
+torch.set_num_threads(1)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# --------------------------------------------------------------------------- neck + head + layout
+def _cases(golden_dir):
+    with open(os.path.join(golden_dir, "neck_head_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_neck_head_matches_reference(golden_dir, idx):
+    z = _load(golden_dir, "neck_head.npz")
+    c = _cases(golden_dir)[idx]
+    tag = c["tag"]
+    arch = c["cls"]
+    m = omodel.DetectorOracle(arch=arch, backbone="oracle_tiny", **c["kw"]).eval()
+    sd = {k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "/sd/")}
+    m.load_state_dict(sd, strict=True)            # identical key set to the reference class
+    x = torch.from_numpy(z[f"{tag}/x"])
+    with torch.no_grad():
+        outs = m(x)
+        m.export_concat = True
+        cat = m(x)
+    assert list(z[f"{tag}/strides"]) == m.get_strides()
+    assert tuple(z[f"{tag}/anchors"]) == m.get_num_anchors_per_level()
+    for j, o in enumerate(outs):
+        ref = z[f"{tag}/out{j}"]
+        assert o.shape == ref.shape
+        assert o.is_contiguous()
+        np.testing.assert_allclose(o.numpy(), ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(cat.numpy(), z[f"{tag}/concat"], rtol=0, atol=1e-6)
+
+
+# --------------------------------------------------------------------------- decode
+def test_decode_zero_logits_known_answer(golden_dir):
+    z = _load(golden_dir, "decode.npz")
+    d = opost.decode_levels([torch.zeros(1, 1, s, s, 8) for s in (80, 40, 20)], 640)
+    assert d["box"].shape == (1, 8400, 4)
+    np.testing.assert_array_equal(d["box"][0, :3].numpy(), z["zero/box_first"])
+    np.testing.assert_array_equal(d["box"][0, -3:].numpy(), z["zero/box_last"])
+    # SURVEY 8(a) a8 known answer: P3 cell (0,0)
+    np.testing.assert_allclose(d["box"][0, 0].numpy(), [1.2274113, 1.2274113, 6.7725887, 6.7725887], atol=1e-6)
+
+
+@pytest.mark.parametrize("cm", ["v8", "simple"])
+@pytest.mark.parametrize("wm", ["softplus", "v8", "exp"])
+def test_decode_random_bit_exact(golden_dir, cm, wm):
+    z = _load(golden_dir, "decode.npz")
+    lv = [torch.from_numpy(z[f"rand/level{j}"]) for j in range(3)]
+    d = opost.decode_levels(lv, 128, center_mode=cm, wh_mode=wm)
+    for k in ("box", "obj", "cls"):
+        np.testing.assert_array_equal(d[k].numpy(), z[f"rand/{cm}_{wm}/{k}"])
+
+
+def test_decode_multi_anchor_c1(golden_dir):
+    z = _load(golden_dir, "decode.npz")
+    d = opost.decode_levels([torch.from_numpy(z[f"a2/level{j}"]) for j in range(2)], 96)
+    for k in ("box", "obj", "cls"):
+        np.testing.assert_array_equal(d[k].numpy(), z[f"a2/{k}"])
+
+
+# --------------------------------------------------------------------------- pipelines
+def _pipe_cases(golden_dir):
+    with open(os.path.join(golden_dir, "pipelines_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_eval_pipeline_matches_reference(golden_dir, idx):
+    z = _load(golden_dir, "pipelines.npz")
+    c = _pipe_cases(golden_dir)[idx]
+    lv = [torch.from_numpy(z[f"{c['tag']}/level{j}"]) for j in range(3)]
+    dets, _ = opost.pipeline_eval(lv, c["img"], conf_th=c["conf"], iou_th=c["iou"], add_one=True)
+    for b, dl in enumerate(dets):
+        bbox = np.asarray([d["bbox"] for d in dl], np.float64).reshape(-1, 4)
+        np.testing.assert_array_equal(bbox, z[f"{c['tag']}/eval/{b}/bbox"])
+        np.testing.assert_array_equal(np.asarray([d["score"] for d in dl]), z[f"{c['tag']}/eval/{b}/score"])
+        np.testing.assert_array_equal(np.asarray([d["category_id"] for d in dl], np.int64), z[f"{c['tag']}/eval/{b}/cat"])
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_fallback_pipeline_matches_reference(golden_dir, idx):
+    z = _load(golden_dir, "pipelines.npz")
+    c = _pipe_cases(golden_dir)[idx]
+    lv = [torch.from_numpy(z[f"{c['tag']}/level{j}"]) for j in range(3)]
+    out = opost.pipeline_fallback(lv, c["img"], conf_th=c["conf"], iou_th=c["iou"], topk=300)
+    for b in range(c["B"]):
+        rb, rs, rc = (z[f"{c['tag']}/fallback/{b}/{k}"] for k in ("boxes", "scores", "classes"))
+        assert out["boxes"][b].shape == rb.shape, (c["tag"], b)
+        if c["tag"] == "c3" and b == 0:
+            # this image holds deliberate exact score ties; torch.argsort(descending) is not stable, so
+            # compare as sets of (class, score, box) rows
+            a = np.concatenate([out["classes"][b][:, None], out["scores"][b][:, None], out["boxes"][b]], 1)
+            r = np.concatenate([rc[:, None], rs[:, None], rb], 1)
+            assert sorted(map(tuple, a.tolist())) == sorted(map(tuple, r.tolist()))
+        else:
+            np.testing.assert_array_equal(out["boxes"][b], rb)
+            np.testing.assert_array_equal(out["scores"][b], rs)
+            np.testing.assert_array_equal(out["classes"][b], rc)
+
+
+def test_nms_wrapper_cap_and_greedy(golden_dir):
+    z = _load(golden_dir, "pipelines.npz")
+    bx, sc = z["nms/boxes"], z["nms/scores"]
+    np.testing.assert_array_equal(opost.nms(bx, sc, 0.9, 300, "torchvision"), z["nms/keep_tv_cap300_iou09"])
+    np.testing.assert_array_equal(opost.nms(bx, sc, 0.5, 20, "torchvision"), z["nms/keep_tv_cap20_iou05"])
+    np.testing.assert_array_equal(opost.nms(bx, sc, 0.5, 300, "fallback"), z["nms/keep_greedy_iou05"])
+    np.testing.assert_array_equal(opost.nms(bx, sc, 0.3, 300, "fallback"), z["nms/keep_greedy_iou03"])
+
+
+def test_tv_restatement_agrees_with_reference_greedy_on_tiefree_input(golden_dir):
+    """Cross-check of the (unpinned) torchvision.ops.nms restatement: on inputs with no score ties and
+    no IoU within 1e-4 of the threshold it must keep exactly what the reference's own pure-torch NMS
+    (pinned above) keeps -- the two differ only by the 1e-6 in the denominator."""
+    z = _load(golden_dir, "pipelines.npz")
+    bx, sc = z["nms/boxes"], z["nms/scores"]
+    assert np.unique(sc).size == sc.size
+    for thr in (0.3, 0.5):
+        np.testing.assert_array_equal(opost.nms_torchvision(bx, sc, thr), opost.nms_greedy_fallback(bx, sc, thr))
+
+
+# --------------------------------------------------------------------------- whole tools/infer.py flow
+@pytest.mark.parametrize("name", ["sq", "wide"])
+def test_infer_main_flow(golden_dir, name):
+    """Reference main() (letterbox -> normalise -> forward -> decode -> score -> per-class NMS (cap 300)
+    -> back-map -> JSON) on a tiny seeded checkpoint vs. the oracle restatement of the same flow."""
+    z = _load(golden_dir, "infer_main.npz")
+    with open(os.path.join(golden_dir, "infer_main_meta.json")) as f:
+        meta = json.load(f)
+    m = omodel.build_from_meta(meta).eval()
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+    img0 = z[f"img_{name}"]
+    S = meta["img_size"]
+    h, w = img0.shape[:2]
+    scale = min(S / h, S / w)
+    nh, nw = int(round(h * scale)), int(round(w * scale))
+    assert (nh, nw) == (h, w)                       # fixtures avoid cv2.resize interpolation
+    top, left = (S - nh) // 2, (S - nw) // 2
+    lb = np.full((S, S, 3), 114, np.uint8)
+    lb[top:top + nh, left:left + nw] = img0
+    im = lb[..., ::-1].astype(np.float32) / 255.0
+    im = (im - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)
+    x = torch.from_numpy(np.ascontiguousarray(im.transpose(2, 0, 1))[None])
+    with torch.no_grad():
+        lv = m(x)
+    out = opost.pipeline_main(lv, S, conf=0.4, iou=0.5, per_class_cap=300)
+    boxes = opost.backmap(out["boxes"][0], left, top, scale, w, h)
+    assert boxes.shape[0] == z[f"{name}/bbox_xyxy"].shape[0] > 20
+    np.testing.assert_array_equal(out["classes"][0], z[f"{name}/class_id"])
+    np.testing.assert_array_equal(out["scores"][0].astype(np.float64), z[f"{name}/score"])
+    np.testing.assert_array_equal(boxes.astype(np.float64), z[f"{name}/bbox_xyxy"])
+
+
+# --------------------------------------------------------------------------- checksums
+def test_param_count_checksum():
+    """edge_n at C=3: 0.5524 M parameters (published 0.553 M, reference BENCHMARK.md:353);
+    edge_m: 2.949 M (published 2.950 M, BENCHMARK.md:355)."""
+    n = sum(p.numel() for p in omodel.DetectorOracle(num_classes=3, **omodel.MODEL_ZOO["edge_n"]).parameters())
+    assert n == 552408
+    n = sum(p.numel() for p in omodel.DetectorOracle(num_classes=3, **omodel.MODEL_ZOO["edge_m"]).parameters())
+    assert abs(n - 2.950e6) < 0.002e6
