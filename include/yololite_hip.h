@@ -1,0 +1,176 @@
+/*
+ * yololite_hip.h -- C ABI of the MI355X-native (gfx950) YoloLite inference hot path.
+ *
+ * The reference (Lillthorin/YoloLite-Official-Repo) is pure Python and has no FFI / operator
+ * registry; its hot path sits behind plain Python calls.  This header is the boundary a native
+ * replacement introduces.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - All *_dev pointers are device (HBM) pointers owned by the CALLER (e.g. torch tensors'
+ *     data_ptr()); the context owns weights, activations and workspaces.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous
+ *     on that stream and never synchronise implicitly, except yl_forward_timed.
+ *   - Every function returns YL_OK (0) or a negative yl_status; nothing throws across the ABI.
+ *   - One context per device; a context is not thread-safe (one stream at a time).
+ *   - Deterministic: results are bitwise repeatable run to run (no floating-point atomics).
+ *   - Arithmetic is fp32 throughout (the reference CPU path is fp32).
+ */
+#ifndef YOLOLITE_HIP_H
+#define YOLOLITE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YL_ABI_VERSION 1
+#define YL_MAX_LEVELS 8
+
+typedef struct yl_ctx yl_ctx;
+typedef int32_t yl_status;
+
+enum {
+  YL_OK = 0,
+  YL_ERR_INVALID = -1,      /* bad argument / inconsistent model description          */
+  YL_ERR_HIP = -2,          /* a HIP runtime call failed (see yl_last_error)          */
+  YL_ERR_NOMEM = -3,        /* device or host allocation failed                       */
+  YL_ERR_STATE = -4,        /* call not valid for this context (e.g. no layers)       */
+  YL_ERR_UNSUPPORTED = -5,  /* valid request the kernels do not implement             */
+  YL_ERR_CAPACITY = -6      /* a caller-provided buffer is too small                  */
+};
+
+/* activations fused into conv epilogues (reference: nn.ReLU / nn.SiLU in model_v2.py:21,34,132,299;
+ * timm ReLU / ReLU6 inside the backbones) */
+enum { YL_ACT_NONE = 0, YL_ACT_RELU = 1, YL_ACT_RELU6 = 2, YL_ACT_SILU = 3 };
+
+/* layer kinds of the forward program */
+enum {
+  YL_OP_STEM = 0,  /* dense kxk conv reading the NCHW fp32 network input (Cin<=4), writes NHWC   */
+  YL_OP_CONV = 1,  /* dense kxk conv (groups=1) on NHWC, optional depthwise prologue, fused
+                      bias/act/residual/nearest-upsample-add epilogue, optional head-layout store  */
+  YL_OP_DW = 2     /* stand-alone depthwise kxk conv on NHWC with bias/act                         */
+};
+
+/*
+ * One fused layer.  Weights are HOST pointers in PyTorch layout with BatchNorm already folded
+ * (w' = w * gamma/sqrt(var+eps), b' = beta - mean*gamma/sqrt(var+eps)); yl_create repacks them into
+ * the MFMA fragment order and uploads them.  Replaces the nn.Conv2d / nn.BatchNorm2d / activation /
+ * F.interpolate(nearest)+add / view-cat-permute sequences of scripts/model/model_v2.py:15-53,
+ * 179-192,337-350 and of the timm backbone (model_v2.py:94-100,266-272).
+ */
+typedef struct {
+  int32_t op;                 /* YL_OP_*                                                         */
+  int32_t in_slot;            /* input tensor slot (ignored for YL_OP_STEM: reads the net input)  */
+  int32_t out_slot;           /* output tensor slot, or -1 when head_level >= 0                   */
+  int32_t res_slot;           /* tensor added after bias+act (residual), -1 = none                */
+  int32_t up_slot;            /* tensor nearest-upsampled to the output size and added, -1 = none */
+  int32_t head_level;         /* >=0: store as detection level [B,A,S,S,5+C] (cout = A*(5+C))     */
+  int32_t cin, cout;
+  int32_t k, stride, pad_t, pad_l;
+  int32_t act;                /* YL_ACT_* applied after bias                                      */
+  int32_t dw_k;               /* YL_OP_CONV only: 0 = none, else depthwise kxk prologue on input  */
+  int32_t dw_stride, dw_pad_t, dw_pad_l, dw_act;
+  const float* w;             /* CONV/STEM: [cout][cin][k][k]; DW: [cout][1][k][k]                */
+  const float* b;             /* [cout] or NULL                                                   */
+  const float* dw_w;          /* [cin][1][dw_k][dw_k] or NULL                                     */
+  const float* dw_b;          /* [cin] or NULL                                                    */
+} yl_layer;
+
+/*
+ * Model + detection-head geometry.  Mirrors what build_model_from_meta() (tools/infer.py:34-77)
+ * derives from a checkpoint's meta and what forward() returns (model_v2.py:352-383):
+ * level l is a tensor [B, level_anchors[l], level_size[l], level_size[l], 5+num_classes],
+ * last-dim order [tx,ty,tw,th,tobj,cls_0..cls_{C-1}] (model_v2.py:345-350).
+ */
+typedef struct {
+  int32_t abi_version;        /* YL_ABI_VERSION                                                   */
+  int32_t img_size;           /* square network input S (x is [B,3,S,S] NCHW fp32)                */
+  int32_t in_channels;        /* 3                                                                */
+  int32_t num_classes;        /* C                                                                */
+  int32_t num_levels;         /* L <= YL_MAX_LEVELS                                               */
+  int32_t level_size[YL_MAX_LEVELS];
+  int32_t level_anchors[YL_MAX_LEVELS];
+  int32_t num_slots;          /* activation tensors                                               */
+  const int32_t* slot_h;      /* [num_slots]                                                      */
+  const int32_t* slot_w;
+  const int32_t* slot_c;
+  int32_t num_layers;         /* 0 = post-processing-only context                                 */
+  const yl_layer* layers;
+} yl_model_desc;
+
+/* post-processing pipelines */
+enum {
+  YL_POST_MAIN = 0,      /* tools/infer.py:460-493  torchvision-nms semantics, per-class cap        */
+  YL_POST_FALLBACK = 1,  /* tools/infer.py:247-389  greedy nms (+1e-6), min-side>=2, global top-k   */
+  YL_POST_EVAL = 2       /* scripts/helpers/helpers.py:87-153  torchvision-nms semantics, no cap    */
+};
+enum { YL_CENTER_V8 = 0, YL_CENTER_SIMPLE = 1 };              /* utils_ms.py:83-88   */
+enum { YL_WH_SOFTPLUS = 0, YL_WH_V8 = 1, YL_WH_EXP = 2 };     /* utils_ms.py:91-99   */
+enum { YL_NMS_TORCHVISION = 0, YL_NMS_GREEDY = 1 };           /* tools/infer.py:134-163 */
+
+typedef struct {
+  int32_t mode;               /* YL_POST_*                                                        */
+  float conf_thr;             /* keep iff score > conf_thr (strict)                               */
+  float iou_thr;
+  int32_t per_class_cap;      /* keep[:cap] per class (300 in the reference's nms()); <=0 = none  */
+  int32_t topk;               /* FALLBACK only: global top-k by score; <=0 = none                 */
+  int32_t max_out;            /* rows per image available in dets_dev / keep_idx_dev              */
+  int32_t center_mode;        /* YL_CENTER_*                                                      */
+  int32_t wh_mode;            /* YL_WH_*                                                          */
+  const float* backmap_dev;   /* optional [B][5] = padx,pady,scale,w0,h0 (tools/infer.py:508-516) */
+} yl_post_cfg;
+
+/* ---- lifetime ---------------------------------------------------------------------------------
+ * yl_create replaces build_model_from_meta + load_state_dict + .to(device).eval()
+ * (tools/infer.py:34-102): it validates the layer program, packs and uploads the weights.        */
+yl_status yl_create(const yl_model_desc* desc, int32_t device_id, yl_ctx** out);
+void yl_destroy(yl_ctx* ctx);
+const char* yl_strerror(yl_status s);
+const char* yl_last_error(const yl_ctx* ctx);   /* detail of the last failure on this context     */
+int32_t yl_abi_version(void);
+
+/* ---- forward ----------------------------------------------------------------------------------
+ * Replaces model(x) (model_v2.py:352-377 / :194-224): x_dev is [B,3,S,S] NCHW fp32; level_out_dev
+ * holds num_levels device pointers, level l receiving the contiguous tensor [B,A_l,S_l,S_l,5+C].  */
+yl_status yl_forward(yl_ctx* ctx, const float* x_dev, int32_t batch, float* const* level_out_dev,
+                     void* stream);
+/* Same, but records a HIP event pair around every layer on `stream`, synchronises, and returns the
+ * per-layer durations (ms) in layer_ms[num_layers].  Measurement aid for bench.py (roofline).      */
+yl_status yl_forward_timed(yl_ctx* ctx, const float* x_dev, int32_t batch, float* const* level_out_dev,
+                           void* stream, float* layer_ms);
+/* Copies activation slot `slot` (NHWC fp32, [B,h,w,c]) of the last forward to dst_dev (testing aid). */
+yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev, void* stream);
+/* Options: "graph" (0/1: replay the forward from a captured hipGraph), "tile_m" (conv M-tile hint) */
+yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
+
+/* ---- decode -----------------------------------------------------------------------------------
+ * Replaces decode_preds_anchorfree (scripts/helpers/utils_ms.py:26-123): levels -> box [B,N,4]
+ * xyxy pixels clamped to [0,S-1], obj [B,N,1] logits, cls [B,N,C] logits; N = sum A_l*S_l^2.        */
+yl_status yl_decode(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, int32_t center_mode,
+                    int32_t wh_mode, float* box_dev, float* obj_dev, float* cls_dev, void* stream);
+
+/* ---- post-processing --------------------------------------------------------------------------
+ * Replaces the score/threshold/per-class-NMS/(top-k)/(back-map) code of tools/infer.py:460-516
+ * (MAIN), tools/infer.py:247-389 (FALLBACK) and helpers.py:87-136 (EVAL).
+ * dets_dev  [B][max_out][6] = x1,y1,x2,y2,score,class   (class asc, score desc; FALLBACK after a
+ *           fired top-k: score desc)
+ * counts_dev[B] = number of detections produced (may exceed max_out: rows beyond it are dropped)
+ * keep_idx_dev optional [B][max_out] candidate index n of every detection (NULL to skip).          */
+yl_status yl_postprocess(yl_ctx* ctx, const float* const* levels_dev, int32_t batch,
+                         const yl_post_cfg* cfg, float* dets_dev, int32_t* counts_dev,
+                         int32_t* keep_idx_dev, void* stream);
+/* forward + postprocess on the context's own level buffers (YoloLite.predict hot loop).            */
+yl_status yl_predict(yl_ctx* ctx, const float* x_dev, int32_t batch, const yl_post_cfg* cfg,
+                     float* dets_dev, int32_t* counts_dev, void* stream);
+/* Replaces nms(boxes, scores, iou_th, max_det) (tools/infer.py:134-152): keep_dev[max_det] receives
+ * the kept indices in score-descending order, count_dev[0] their number (<= max_det).              */
+yl_status yl_nms(yl_ctx* ctx, const float* boxes_dev, const float* scores_dev, int32_t n, float iou_thr,
+                 int32_t nms_impl, int32_t max_det, int32_t* keep_dev, int32_t* count_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOLITE_HIP_H */

@@ -1,0 +1,157 @@
+"""CPU-only checks of the host side: C-ABI symbols, program builder, synthetic weights, sharding,
+gloo all-gather.  No HIP compute here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import yololite_amd as ya
+from yololite_amd import _lib
+from yololite_amd.program import build_program, synth_state_dict, zoo_meta, make_meta
+from yololite_amd import dist as ydist
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "yololite_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(yl_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    """build() has produced the .so; it loads and exports exactly what include/yololite_hip.h declares."""
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _header_symbols()
+    assert declared == sorted(n for n, _, _ in _lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().yl_abi_version() == _lib.YL_ABI_VERSION
+    assert _lib.load().yl_strerror(-5).decode() == "unsupported configuration"
+
+
+def test_no_cpu_fallback_fails_loudly():
+    """Without a HIP device the product path raises; it never routes to a CPU implementation."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    meta = zoo_meta("edge_n", 3, 64)
+    m = ya.build_model_from_meta(meta)
+    m.load_state_dict(synth_state_dict(meta))
+    with pytest.raises(ya.YoloLiteHipError):
+        m.to("cuda:0")
+    with pytest.raises(ya.YoloLiteHipError):
+        m.to("cpu")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "yololite-official-repo_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_program_edge_n_macs_and_layout():
+    """edge_n C=80 640^2 = 0.7964 GMAC over 63 conv layers; fused into 42 launches."""
+    meta = zoo_meta("edge_n", 80, 640)
+    p = build_program(meta, synth_state_dict(meta))
+    assert abs(p.macs - 796.39e6) < 0.05e6
+    assert p.level_size == [80, 40, 20] and p.level_anchors == [1, 1, 1] and p.strides == [8, 16, 32]
+    assert [p.slots[p.feature_slots[k]] for k in ("c3", "c4", "c5")] == [(80, 80, 32), (40, 40, 48), (20, 20, 480)]
+    nconv = sum(1 + (l.dw_k > 0) for l in p.layers)     # SURVEY App. A counts the head box/obj/cls convs as one row
+    assert nconv == 63
+    p2 = build_program(meta, synth_state_dict(meta), fuse_dw=False)
+    assert len(p2.layers) > len(p.layers) and p2.macs == p.macs
+
+
+@pytest.mark.parametrize("name,feat", [("edge_m", [(80, 80, 64), (40, 40, 96), (20, 20, 960)]),
+                                       ("yololite_m", [(80, 80, 48), (40, 40, 120), (20, 20, 352)])])
+def test_program_other_configs(name, feat):
+    meta = zoo_meta(name, 80, 640)
+    p = build_program(meta, synth_state_dict(meta))
+    assert [p.slots[p.feature_slots[k]] for k in ("c3", "c4", "c5")] == feat
+    assert p.level_size == [80, 40, 20]
+
+
+def test_state_dict_keys_match_oracle_model():
+    """Key set / shapes the builder consumes == the reference-compatible module's state_dict."""
+    from oracle import model as om
+    for name in ("edge_n", "yololite_m"):
+        meta = zoo_meta(name, 7, 128, use_p6=(name == "edge_n"))
+        sd = synth_state_dict(meta)
+        m = om.build_from_meta(meta)
+        msd = m.state_dict()
+        assert set(sd) <= set(msd)
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(msd[k].shape), k
+        p = build_program(meta, msd)
+        assert [k for k in msd if k not in p.known_keys] == []
+
+
+def test_missing_weight_raises_and_meta_errors():
+    meta = zoo_meta("edge_n", 3, 64)
+    sd = synth_state_dict(meta)
+    del sd["lateral4.bias"]
+    with pytest.raises(RuntimeError):
+        ya.build_model_from_meta(meta).load_state_dict(sd)
+    bad = dict(meta, arch="nope")
+    with pytest.raises(ValueError):
+        ya.build_model_from_meta(bad)
+    nokey = dict(meta, config=dict(model=meta["config"]["model"], training={}))
+    with pytest.raises(KeyError):                       # tools/infer.py:49-50 behaviour
+        ya.build_model_from_meta(nokey)
+
+
+def test_shard_range_partitions():
+    for total in (1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [ydist.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import yololite_amd
+from yololite_amd import dist as ydist
+rank, world, total = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys.argv[2])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[3]}", rank=rank, world_size=world)
+g = torch.Generator().manual_seed(5)
+full_d = torch.randn(total, 4, 6, generator=g)
+full_c = torch.randint(0, 5, (total,), generator=g, dtype=torch.int32)
+def fake_predict(x):            # stands in for HipContext.predict on this rank's shard
+    lo, hi = ydist.shard_range(total, rank, world)
+    assert x.shape[0] == hi - lo
+    return full_d[lo:hi].clone(), full_c[lo:hi].clone()
+d, c = ydist.sharded_predict(fake_predict, torch.zeros(total, 1), "cpu")
+assert torch.equal(d, full_d) and torch.equal(c, full_c), (rank, d.shape)
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+@pytest.mark.parametrize("total", [8, 5])
+def test_allgather_dets_gloo_world2(tmp_path, total):
+    """N>1 path on CPU: two gloo ranks, sharded 'predict', one all-gather, image order preserved
+    (also with an uneven shard)."""
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = 29600 + (os.getpid() + total) % 300
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(total), str(port)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

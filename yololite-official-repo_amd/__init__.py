@@ -1,0 +1,17 @@
+"""yololite-official-repo_amd -- MI355X-native (gfx950) YoloLite inference hot path.
+
+backbone -> FPN -> heads -> anchor-free decode -> class-wise NMS as hand-written HIP kernels
+behind a C ABI (include/yololite_hip.h, libyololite_hip.so); this package is the Python host
+side mirroring the reference's call surface.  Importable as `yololite_amd` (see yololite_amd.py
+at the repository root: the directory name contains a hyphen).
+"""
+from ._lib import YoloLiteHipError, load as load_library  # noqa: F401
+from .model import (HipContext, YOLOLiteHIP, build_model_from_meta,  # noqa: F401
+                    load_model_names_imgsize_from_ckpt)
+from .postprocess import (_decode_batch_to_coco_dets, decode_anchorfree_like_train,  # noqa: F401
+                          decode_preds_anchorfree, infer_main_postprocess, nms)
+from .program import BACKBONES, Program, build_program  # noqa: F401
+
+__all__ = ["YoloLiteHipError", "load_library", "HipContext", "YOLOLiteHIP", "build_model_from_meta",
+           "load_model_names_imgsize_from_ckpt", "decode_preds_anchorfree", "_decode_batch_to_coco_dets",
+           "decode_anchorfree_like_train", "infer_main_postprocess", "nms", "build_program", "Program", "BACKBONES"]

@@ -1,0 +1,105 @@
+"""ctypes binding of the C ABI in include/yololite_hip.h (libyololite_hip.so, built for gfx950 by
+csrc/build.py).  There is NO CPU fallback: if the library is missing or fails to load, importing
+this module raises -- the product path must fail loudly rather than run somewhere else."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyololite_hip.so")
+
+YL_ABI_VERSION = 1
+YL_MAX_LEVELS = 8
+YL_OK = 0
+ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
+OP_STEM, OP_CONV, OP_DW = 0, 1, 2
+POST_MAIN, POST_FALLBACK, POST_EVAL = 0, 1, 2
+CENTER = {"v8": 0, "simple": 1}
+WH = {"softplus": 0, "v8": 1, "exp": 2}
+NMS_TORCHVISION, NMS_GREEDY = 0, 1
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class yl_layer(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "op", "in_slot", "out_slot", "res_slot", "up_slot", "head_level", "cin", "cout",
+        "k", "stride", "pad_t", "pad_l", "act", "dw_k", "dw_stride", "dw_pad_t", "dw_pad_l", "dw_act")] + [
+        ("w", _fp), ("b", _fp), ("dw_w", _fp), ("dw_b", _fp)]
+
+
+class yl_model_desc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("img_size", C.c_int32), ("in_channels", C.c_int32),
+                ("num_classes", C.c_int32), ("num_levels", C.c_int32),
+                ("level_size", C.c_int32 * YL_MAX_LEVELS), ("level_anchors", C.c_int32 * YL_MAX_LEVELS),
+                ("num_slots", C.c_int32), ("slot_h", _ip), ("slot_w", _ip), ("slot_c", _ip),
+                ("num_layers", C.c_int32), ("layers", C.POINTER(yl_layer))]
+
+
+class yl_post_cfg(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("conf_thr", C.c_float), ("iou_thr", C.c_float),
+                ("per_class_cap", C.c_int32), ("topk", C.c_int32), ("max_out", C.c_int32),
+                ("center_mode", C.c_int32), ("wh_mode", C.c_int32), ("backmap_dev", C.c_void_p)]
+
+
+# every symbol include/yololite_hip.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+SYMBOLS = [
+    ("yl_create", C.c_int32, [C.POINTER(yl_model_desc), C.c_int32, C.POINTER(_vp)]),
+    ("yl_destroy", None, [_vp]),
+    ("yl_strerror", C.c_char_p, [C.c_int32]),
+    ("yl_last_error", C.c_char_p, [_vp]),
+    ("yl_abi_version", C.c_int32, []),
+    ("yl_forward", C.c_int32, [_vp, _vp, C.c_int32, _vpp, _vp]),
+    ("yl_forward_timed", C.c_int32, [_vp, _vp, C.c_int32, _vpp, _vp, _fp]),
+    ("yl_read_slot", C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
+    ("yl_set_option", C.c_int32, [_vp, C.c_char_p, C.c_int32]),
+    ("yl_decode", C.c_int32, [_vp, _vpp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    ("yl_postprocess", C.c_int32, [_vp, _vpp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp, _vp]),
+    ("yl_predict", C.c_int32, [_vp, _vp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp]),
+    ("yl_nms", C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+]
+
+_lib = None
+
+
+class YoloLiteHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libyololite_hip.so once.  torch is imported first so that the HIP runtime the library
+    binds to (libamdhip64.so.7) is the one PyTorch-ROCm already mapped into the process -- device
+    pointers of torch tensors are then valid for our kernels."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YoloLiteHipError(
+            f"{LIB_PATH} not found: build it with `python yololite-official-repo_amd/csrc/build.py` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    import torch  # noqa: F401  (maps PyTorch's libamdhip64 first)
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise YoloLiteHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.yl_abi_version() != YL_ABI_VERSION:
+        raise YoloLiteHipError("libyololite_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, ctx=None, what: str = ""):
+    if status == YL_OK:
+        return
+    lib = load()
+    msg = lib.yl_strerror(status).decode()
+    detail = lib.yl_last_error(ctx).decode() if ctx else ""
+    raise YoloLiteHipError(f"{what or 'yololite_hip'}: {msg} ({status}) {detail}".strip())

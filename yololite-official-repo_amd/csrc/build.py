@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Build libyololite_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
+three translation units, one shared library with a plain C ABI (include/yololite_hip.h).
+
+    python yololite-official-repo_amd/csrc/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "libyololite_hip.so")
+OBJ = os.path.join(HERE, "_obj")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+UNITS = [
+    ("yl_api.hip", []),
+    ("yl_conv.hip", []),
+    # reference-exact fp32 arithmetic in decode/NMS: no fused multiply-add contraction
+    ("yl_post.hip", ["-ffp-contract=off"]),
+]
+DEPS = ["yl_internal.h", os.path.join("..", "..", "include", "yololite_hip.h")]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    deps = [os.path.join(HERE, d) for d in DEPS] + [os.path.abspath(__file__)]
+    jobs = []
+    for src, extra in UNITS:
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + deps):
+            jobs.append([hipcc] + COMMON + extra + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src, _ in UNITS]
+    if force or jobs or _stale(OUT, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

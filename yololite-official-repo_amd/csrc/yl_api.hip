@@ -1,0 +1,596 @@
+// C ABI (include/yololite_hip.h): context, weight packing, forward executor, post-processing driver.
+#include "yl_internal.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevLayer {
+  yl_layer d;            // host description (pointers nulled after packing)
+  float* wp = nullptr;   // packed weights (device)
+  float* bias = nullptr; // padded bias (device)
+  float* dw_w = nullptr; // [taps][Cin] (device)
+  float* dw_b = nullptr;
+  int in_h = 0, in_w = 0, out_h = 0, out_w = 0;
+  int head_anchor = -1;  // head layers: anchor index handled by this layer
+};
+
+struct Slot {
+  int h, w, c;
+  float* ptr = nullptr;
+};
+
+}  // namespace
+
+struct yl_ctx {
+  int device = 0;
+  int img_size = 0, in_ch = 3, C = 0, L = 0, N = 0, E = 0;
+  int level_S[YL_MAX_LEVELS] = {0}, level_A[YL_MAX_LEVELS] = {0}, level_off[YL_MAX_LEVELS + 1] = {0};
+  std::vector<Slot> slots;
+  std::vector<DevLayer> layers;
+  int cap_batch = 0;                       // activations / workspaces are sized for this batch
+  float* level_buf[YL_MAX_LEVELS] = {nullptr};
+  // post-processing workspace
+  float4* ws_boxes = nullptr;
+  float* ws_scores = nullptr;
+  int* ws_cls = nullptr;
+  int* ws_clsws = nullptr;
+  unsigned long long* ws_gkeys = nullptr;
+  int gP = 0;
+  float* ws_tmp_dets = nullptr;
+  int* ws_tmp_idx = nullptr;
+  int post_cap_batch = 0;
+  // standalone nms scratch
+  int* ws_nms_clsws = nullptr;
+  unsigned long long* ws_nms_gkeys = nullptr;
+  int nms_gP = 0;
+  // options
+  int opt_graph = 0, opt_tile_m = 0;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_batch = 0;
+  const float* graph_x = nullptr;
+  float* graph_out[YL_MAX_LEVELS] = {nullptr};
+  hipStream_t graph_stream = nullptr;
+  std::string err;
+};
+
+namespace {
+
+bool g_inited = false;
+
+yl_status fail(yl_ctx* c, yl_status s, const std::string& msg) {
+  if (c) c->err = msg;
+  return s;
+}
+
+#define HIPCHK(ctx, expr)                                                                        \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      char _b[512];                                                                              \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+               __LINE__);                                                                        \
+      return fail(ctx, (_e == hipErrorOutOfMemory) ? YL_ERR_NOMEM : YL_ERR_HIP, _b);             \
+    }                                                                                            \
+  } while (0)
+
+template <typename T>
+yl_status upload(yl_ctx* c, const std::vector<T>& h, T** d) {
+  *d = nullptr;
+  if (h.empty()) return YL_OK;
+  HIPCHK(c, hipMalloc((void**)d, h.size() * sizeof(T)));
+  HIPCHK(c, hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return YL_OK;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// MFMA fragment order: [tap][kblock][ntile][lane][s]  with
+//   n = ntile*16 + (lane & 15),  c = kblock*16 + 4*(lane >> 4) + s     (see yl_conv.hip)
+void pack_conv(const float* w, int cout, int cin, int k, std::vector<float>& out) {
+  const int KB = cdiv(cin, 16), NT = cdiv(cout, 16), taps = k * k;
+  out.assign((size_t)taps * KB * NT * 256, 0.0f);
+  for (int tap = 0; tap < taps; ++tap)
+    for (int kb = 0; kb < KB; ++kb)
+      for (int nt = 0; nt < NT; ++nt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            const int n = nt * 16 + (lane & 15);
+            const int c = kb * 16 + 4 * (lane >> 4) + s;
+            if (n < cout && c < cin)
+              out[((((size_t)tap * KB + kb) * NT + nt) * 64 + lane) * 4 + s] =
+                  w[((size_t)n * cin + c) * taps + tap];
+          }
+}
+
+// depthwise [c][1][k][k] -> [tap][c]
+void pack_dw(const float* w, int ch, int k, std::vector<float>& out) {
+  out.assign((size_t)k * k * ch, 0.0f);
+  for (int c = 0; c < ch; ++c)
+    for (int t = 0; t < k * k; ++t) out[(size_t)t * ch + c] = w[(size_t)c * k * k + t];
+}
+
+// stem [cout][cin][k][k] -> [ky][kx][c][cout]
+void pack_stem(const float* w, int cout, int cin, int k, std::vector<float>& out) {
+  out.assign((size_t)k * k * cin * cout, 0.0f);
+  for (int n = 0; n < cout; ++n)
+    for (int c = 0; c < cin; ++c)
+      for (int t = 0; t < k * k; ++t) out[((size_t)t * cin + c) * cout + n] = w[((size_t)n * cin + c) * k * k + t];
+}
+
+void free_post_ws(yl_ctx* c) {
+  hipFree(c->ws_boxes); hipFree(c->ws_scores); hipFree(c->ws_cls); hipFree(c->ws_clsws);
+  hipFree(c->ws_gkeys); hipFree(c->ws_tmp_dets); hipFree(c->ws_tmp_idx);
+  c->ws_boxes = nullptr; c->ws_scores = nullptr; c->ws_cls = nullptr; c->ws_clsws = nullptr;
+  c->ws_gkeys = nullptr; c->ws_tmp_dets = nullptr; c->ws_tmp_idx = nullptr;
+  c->post_cap_batch = 0;
+}
+
+void drop_graph(yl_ctx* c) {
+  if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+  c->graph_exec = nullptr;
+  c->graph_batch = 0;
+}
+
+void free_act(yl_ctx* c) {
+  drop_graph(c);
+  for (auto& s : c->slots) { hipFree(s.ptr); s.ptr = nullptr; }
+  for (int l = 0; l < YL_MAX_LEVELS; ++l) { hipFree(c->level_buf[l]); c->level_buf[l] = nullptr; }
+  c->cap_batch = 0;
+}
+
+int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
+
+yl_status ensure_act(yl_ctx* c, int B) {
+  if (B <= c->cap_batch) return YL_OK;
+  free_act(c);
+  for (auto& s : c->slots)
+    HIPCHK(c, hipMalloc((void**)&s.ptr, (size_t)B * s.h * s.w * s.c * sizeof(float)));
+  for (int l = 0; l < c->L; ++l)
+    HIPCHK(c, hipMalloc((void**)&c->level_buf[l],
+                        (size_t)B * c->level_A[l] * c->level_S[l] * c->level_S[l] * c->E * sizeof(float)));
+  c->cap_batch = B;
+  return YL_OK;
+}
+
+yl_status ensure_post(yl_ctx* c, int B) {
+  if (B <= c->post_cap_batch) return YL_OK;
+  free_post_ws(c);
+  const size_t n = (size_t)B * c->N;
+  HIPCHK(c, hipMalloc((void**)&c->ws_boxes, n * sizeof(float4)));
+  HIPCHK(c, hipMalloc((void**)&c->ws_scores, n * sizeof(float)));
+  HIPCHK(c, hipMalloc((void**)&c->ws_cls, n * sizeof(int)));
+  const int Cw = c->C > 0 ? c->C : 1;
+  HIPCHK(c, hipMalloc((void**)&c->ws_clsws, (size_t)B * 4 * Cw * sizeof(int)));
+  c->gP = pow2ceil(c->N);
+  if (c->gP > YL_LDS_KEYS_MAX) HIPCHK(c, hipMalloc((void**)&c->ws_gkeys, (size_t)B * c->gP * 8));
+  HIPCHK(c, hipMalloc((void**)&c->ws_tmp_dets, n * 6 * sizeof(float)));
+  HIPCHK(c, hipMalloc((void**)&c->ws_tmp_idx, n * sizeof(int)));
+  c->post_cap_batch = B;
+  return YL_OK;
+}
+
+void fill_levels(const yl_ctx* c, const float* const* ptrs, YlLevels& lv) {
+  memset(&lv, 0, sizeof(lv));
+  lv.L = c->L; lv.N = c->N; lv.E = c->E; lv.C = c->C;
+  lv.hi = (float)(c->img_size - 1);
+  for (int l = 0; l < c->L; ++l) {
+    lv.ptr[l] = ptrs[l];
+    lv.S[l] = c->level_S[l];
+    lv.A[l] = c->level_A[l];
+    lv.off[l] = c->level_off[l];
+    lv.stride[l] = (float)((double)c->img_size / (double)c->level_S[l]);   // utils_ms.py:71
+  }
+  lv.off[c->L] = c->N;
+}
+
+// builds the kernel parameter block of layer i for batch B
+void layer_params(const yl_ctx* c, const DevLayer& L, int B, const float* x, float* const* level_out, YlConvP& p) {
+  memset(&p, 0, sizeof(p));
+  const yl_layer& d = L.d;
+  p.wp = L.wp; p.bias = L.bias; p.dw_w = L.dw_w; p.dw_b = L.dw_b;
+  p.B = B; p.H = L.in_h; p.W = L.in_w; p.Cin = d.cin;
+  p.OH = L.out_h; p.OW = L.out_w; p.N = d.cout;
+  p.k = d.k; p.stride = d.stride; p.pad_t = d.pad_t; p.pad_l = d.pad_l; p.act = d.act;
+  p.dw_k = d.dw_k; p.dw_stride = d.dw_stride; p.dw_pad_t = d.dw_pad_t; p.dw_pad_l = d.dw_pad_l; p.dw_act = d.dw_act;
+  p.MH = L.out_h; p.MW = L.out_w;
+  p.KB = cdiv(d.cin, 16);
+  p.TK = d.k * d.k * p.KB;
+  p.NTtot = cdiv(d.cout, 16);
+  p.M = B * L.out_h * L.out_w;
+  p.x = (d.op == YL_OP_STEM) ? x : c->slots[d.in_slot].ptr;
+  if (d.res_slot >= 0) p.res = c->slots[d.res_slot].ptr;
+  if (d.up_slot >= 0) {
+    p.up = c->slots[d.up_slot].ptr;
+    p.UH = c->slots[d.up_slot].h; p.UW = c->slots[d.up_slot].w;
+  }
+  if (d.head_level >= 0) {
+    const int l = d.head_level;
+    const int ss = c->level_S[l] * c->level_S[l];
+    p.out = level_out[l] + (size_t)L.head_anchor * ss * c->E;
+    p.out_bstride = (long)c->level_A[l] * ss * c->E;
+  } else {
+    p.out = c->slots[d.out_slot].ptr;
+    p.out_bstride = (long)L.out_h * L.out_w * d.cout;
+  }
+}
+
+yl_status run_layers(yl_ctx* c, const float* x, int B, float* const* level_out, hipStream_t st,
+                     hipEvent_t* evs /*nullable: num_layers+1 events*/) {
+  if (evs) HIPCHK(c, hipEventRecord(evs[0], st));
+  for (size_t i = 0; i < c->layers.size(); ++i) {
+    YlConvP p;
+    layer_params(c, c->layers[i], B, x, level_out, p);
+    hipError_t e;
+    switch (c->layers[i].d.op) {
+      case YL_OP_STEM: e = yl_launch_stem(p, st); break;
+      case YL_OP_CONV: e = yl_launch_conv(p, c->opt_tile_m, st); break;
+      default: e = yl_launch_dw(p, st); break;
+    }
+    if (e != hipSuccess) {
+      char b[256];
+      snprintf(b, sizeof(b), "layer %zu launch failed: %s", i, hipGetErrorString(e));
+      return fail(c, YL_ERR_HIP, b);
+    }
+    if (evs) HIPCHK(c, hipEventRecord(evs[i + 1], st));
+  }
+  return YL_OK;
+}
+
+yl_status check_cfg(yl_ctx* c, const yl_post_cfg* cfg) {
+  if (!cfg) return fail(c, YL_ERR_INVALID, "cfg is NULL");
+  if (cfg->mode < YL_POST_MAIN || cfg->mode > YL_POST_EVAL) return fail(c, YL_ERR_INVALID, "bad post mode");
+  if (cfg->max_out <= 0) return fail(c, YL_ERR_INVALID, "max_out must be > 0");
+  if (cfg->center_mode < 0 || cfg->center_mode > 1 || cfg->wh_mode < 0 || cfg->wh_mode > 2)
+    return fail(c, YL_ERR_INVALID, "bad center/wh mode");
+  return YL_OK;
+}
+
+yl_status do_post(yl_ctx* c, const float* const* levels, int B, const yl_post_cfg* cfg, float* dets, int* counts,
+                  int* keep_idx, hipStream_t st) {
+  yl_status s = ensure_post(c, B);
+  if (s != YL_OK) return s;
+  YlLevels lv;
+  fill_levels(c, levels, lv);
+  YlDecodeP dp;
+  dp.mode = cfg->mode; dp.center_mode = cfg->center_mode; dp.wh_mode = cfg->wh_mode;
+  dp.boxes = c->ws_boxes; dp.scores = c->ws_scores; dp.cls = c->ws_cls;
+  HIPCHK(c, yl_launch_decode_score(lv, B, dp, st));
+  YlNmsP np;
+  memset(&np, 0, sizeof(np));
+  np.boxes = c->ws_boxes; np.scores = c->ws_scores; np.cls = c->ws_cls;
+  np.N = c->N; np.C = c->C > 0 ? c->C : 1;
+  np.conf_thr = cfg->conf_thr; np.iou_thr = cfg->iou_thr;
+  np.impl = (cfg->mode == YL_POST_FALLBACK) ? YL_NMS_GREEDY : YL_NMS_TORCHVISION;
+  np.cap = (cfg->per_class_cap > 0) ? cfg->per_class_cap : INT_MAX;
+  np.topk = (cfg->mode == YL_POST_FALLBACK && cfg->topk > 0) ? cfg->topk : 0;
+  np.max_out = cfg->max_out;
+  np.cls_ws = c->ws_clsws;
+  np.gkeys = c->ws_gkeys; np.gP = c->gP;
+  np.lds_cap = c->gP < YL_LDS_KEYS_MAX ? c->gP : YL_LDS_KEYS_MAX;
+  np.dets = dets; np.counts = counts; np.keep_idx = keep_idx; np.backmap = cfg->backmap_dev;
+  np.tmp_dets = c->ws_tmp_dets; np.tmp_idx = c->ws_tmp_idx;
+  HIPCHK(c, yl_launch_nms(np, B, st));
+  return YL_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int32_t yl_abi_version(void) { return YL_ABI_VERSION; }
+
+const char* yl_strerror(yl_status s) {
+  switch (s) {
+    case YL_OK: return "ok";
+    case YL_ERR_INVALID: return "invalid argument";
+    case YL_ERR_HIP: return "HIP runtime error";
+    case YL_ERR_NOMEM: return "out of memory";
+    case YL_ERR_STATE: return "invalid state for this call";
+    case YL_ERR_UNSUPPORTED: return "unsupported configuration";
+    case YL_ERR_CAPACITY: return "output buffer too small";
+    default: return "unknown yl_status";
+  }
+}
+
+const char* yl_last_error(const yl_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void yl_destroy(yl_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  free_act(c);
+  free_post_ws(c);
+  hipFree(c->ws_nms_clsws);
+  hipFree(c->ws_nms_gkeys);
+  for (auto& L : c->layers) { hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b); }
+  delete c;
+}
+
+yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
+  if (!d || !out) return YL_ERR_INVALID;
+  *out = nullptr;
+  if (d->abi_version != YL_ABI_VERSION) return YL_ERR_INVALID;
+  if (d->num_levels < 1 || d->num_levels > YL_MAX_LEVELS) return YL_ERR_INVALID;
+  if (d->num_classes < 0 || d->num_classes > 4096) return YL_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return YL_ERR_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return YL_ERR_HIP;
+  if (!g_inited) {
+    if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess) return YL_ERR_HIP;
+    g_inited = true;
+  }
+  yl_ctx* c = new (std::nothrow) yl_ctx();
+  if (!c) return YL_ERR_NOMEM;
+  *out = c;   // handed out even on failure so that yl_last_error() can be read; caller destroys it
+  c->device = device_id;
+  c->img_size = d->img_size; c->in_ch = d->in_channels; c->C = d->num_classes; c->L = d->num_levels;
+  c->E = 5 + c->C;
+  int off = 0;
+  for (int l = 0; l < c->L; ++l) {
+    c->level_S[l] = d->level_size[l]; c->level_A[l] = d->level_anchors[l];
+    if (c->level_S[l] < 1 || c->level_A[l] < 1) return fail(c, YL_ERR_INVALID, "bad level geometry");
+    c->level_off[l] = off;
+    off += c->level_A[l] * c->level_S[l] * c->level_S[l];
+  }
+  c->level_off[c->L] = off;
+  c->N = off;
+  if (c->N >= (1 << 20)) return fail(c, YL_ERR_UNSUPPORTED, "more than 2^20 candidates per image");
+  if (d->num_layers == 0) return YL_OK;
+  if (d->in_channels != 3) return fail(c, YL_ERR_UNSUPPORTED, "network input must have 3 channels");
+  if (!d->layers || !d->slot_h || !d->slot_w || !d->slot_c) return fail(c, YL_ERR_INVALID, "null layer/slot arrays");
+  c->slots.resize(d->num_slots);
+  for (int i = 0; i < d->num_slots; ++i) {
+    c->slots[i].h = d->slot_h[i]; c->slots[i].w = d->slot_w[i]; c->slots[i].c = d->slot_c[i];
+    if (c->slots[i].h < 1 || c->slots[i].w < 1 || c->slots[i].c < 1 || (c->slots[i].c & 3))
+      return fail(c, YL_ERR_UNSUPPORTED, "slot channels must be a positive multiple of 4");
+  }
+  std::vector<int> head_seen(c->L, 0);
+  char msg[256];
+  for (int i = 0; i < d->num_layers; ++i) {
+    const yl_layer& l = d->layers[i];
+    DevLayer L;
+    L.d = l;
+    auto bad = [&](const char* what) {
+      snprintf(msg, sizeof(msg), "layer %d: %s", i, what);
+      return fail(c, YL_ERR_INVALID, msg);
+    };
+    if (l.op < YL_OP_STEM || l.op > YL_OP_DW) return bad("unknown op");
+    if (!l.w) return bad("weights are NULL");
+    if (l.k < 1 || l.stride < 1) return bad("bad kernel geometry");
+    if (l.op == YL_OP_STEM) {
+      L.in_h = L.in_w = d->img_size;
+      if (l.cin != 3 || l.k != 3) return fail(c, YL_ERR_UNSUPPORTED, "stem must be 3x3 with 3 input channels");
+      if (l.cout != 16 && l.cout != 32) return fail(c, YL_ERR_UNSUPPORTED, "stem cout must be 16 or 32");
+    } else {
+      if (l.in_slot < 0 || l.in_slot >= d->num_slots) return bad("bad in_slot");
+      L.in_h = c->slots[l.in_slot].h; L.in_w = c->slots[l.in_slot].w;
+      if (c->slots[l.in_slot].c != l.cin) return bad("cin does not match the input slot");
+    }
+    // output geometry.  Sizes are declared by the host (slot / level dims); pad_t/pad_l are explicit
+    // and the bottom/right padding is implied, so only reachability is checked here.
+    if (l.op == YL_OP_CONV && l.dw_k > 0) {
+      if (l.k != 1 || l.stride != 1) return fail(c, YL_ERR_UNSUPPORTED, "dw prologue needs a 1x1 stride-1 main conv");
+      if (!l.dw_w) return bad("dw prologue weights are NULL");
+      if (l.dw_stride < 1) return bad("bad dw_stride");
+    }
+    if (l.head_level >= 0) {
+      if (l.op != YL_OP_CONV || l.head_level >= c->L) return bad("bad head_level");
+      L.out_h = L.out_w = c->level_S[l.head_level];
+      if (l.cout != c->E) return bad("head layers must have cout = 5+C (one layer per anchor)");
+      L.head_anchor = head_seen[l.head_level]++;
+      if (L.head_anchor >= c->level_A[l.head_level]) return bad("more head layers than anchors for this level");
+      if (l.res_slot >= 0 || l.up_slot >= 0) return bad("head layers take no residual/upsample input");
+    } else {
+      if (l.out_slot < 0 || l.out_slot >= d->num_slots) return bad("bad out_slot");
+      L.out_h = c->slots[l.out_slot].h; L.out_w = c->slots[l.out_slot].w;
+      if (c->slots[l.out_slot].c != l.cout) return bad("cout does not match the output slot");
+    }
+    {
+      const bool pro = (l.op == YL_OP_CONV && l.dw_k > 0);
+      const int st = pro ? l.dw_stride : l.stride, pt = pro ? l.dw_pad_t : l.pad_t, pl = pro ? l.dw_pad_l : l.pad_l;
+      const int kk = pro ? l.dw_k : l.k;
+      // the last window must start inside the tensor
+      if ((L.out_h - 1) * st - pt >= L.in_h || (L.out_w - 1) * st - pl >= L.in_w || pt >= kk || pl >= kk ||
+          L.out_h < 1 || L.out_w < 1)
+        return bad("output size inconsistent with stride/padding");
+    }
+    if (l.res_slot >= 0) {
+      if (l.res_slot >= d->num_slots) return bad("bad res_slot");
+      const Slot& r = c->slots[l.res_slot];
+      if (r.h != L.out_h || r.w != L.out_w || r.c != l.cout) return bad("residual shape mismatch");
+    }
+    if (l.up_slot >= 0) {
+      if (l.up_slot >= d->num_slots || l.op != YL_OP_CONV) return bad("bad up_slot");
+      if (c->slots[l.up_slot].c != l.cout) return bad("upsample source channel mismatch");
+    }
+    if (l.op == YL_OP_DW && l.cin != l.cout) return bad("depthwise needs cin == cout");
+    if (l.op != YL_OP_STEM && (l.cin & 3)) return fail(c, YL_ERR_UNSUPPORTED, "cin must be a multiple of 4");
+    if ((l.res_slot >= 0 || l.up_slot >= 0 || l.act == YL_ACT_SILU) && (l.cout & 3) && l.op == YL_OP_CONV)
+      return fail(c, YL_ERR_UNSUPPORTED, "residual/upsample/SiLU epilogue needs cout % 4 == 0");
+
+    // ---- pack + upload
+    std::vector<float> wp, bias;
+    yl_status s;
+    if (l.op == YL_OP_STEM) {
+      pack_stem(l.w, l.cout, l.cin, l.k, wp);
+      bias.assign(l.cout, 0.0f);
+      if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
+    } else if (l.op == YL_OP_CONV) {
+      pack_conv(l.w, l.cout, l.cin, l.k, wp);
+      bias.assign((size_t)cdiv(l.cout, 16) * 16 + 128, 0.0f);
+      if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
+      if (l.dw_k > 0) {
+        std::vector<float> dw, dwb;
+        pack_dw(l.dw_w, l.cin, l.dw_k, dw);
+        if ((s = upload(c, dw, &L.dw_w)) != YL_OK) return s;
+        if (l.dw_b) {
+          dwb.assign(l.dw_b, l.dw_b + l.cin);
+          if ((s = upload(c, dwb, &L.dw_b)) != YL_OK) return s;
+        }
+      }
+    } else {
+      pack_dw(l.w, l.cout, l.k, wp);
+      if (l.b) bias.assign(l.b, l.b + l.cout);
+    }
+    if ((s = upload(c, wp, &L.wp)) != YL_OK) return s;
+    if ((s = upload(c, bias, &L.bias)) != YL_OK) return s;
+    L.d.w = L.d.b = L.d.dw_w = L.d.dw_b = nullptr;
+    c->layers.push_back(L);
+  }
+  for (int l = 0; l < c->L; ++l)
+    if (head_seen[l] != c->level_A[l]) return fail(c, YL_ERR_INVALID, "every level needs one head layer per anchor");
+  return YL_OK;
+}
+
+yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
+  if (!c || !name) return YL_ERR_INVALID;
+  if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
+  return fail(c, YL_ERR_INVALID, std::string("unknown option ") + name);
+}
+
+static yl_status forward_impl(yl_ctx* c, const float* x, int B, float* const* level_out, hipStream_t st,
+                              float* layer_ms) {
+  if (!c) return YL_ERR_INVALID;
+  if (c->layers.empty()) return fail(c, YL_ERR_STATE, "context was created without layers");
+  if (!x || B < 1) return fail(c, YL_ERR_INVALID, "bad input");
+  HIPCHK(c, hipSetDevice(c->device));
+  yl_status s = ensure_act(c, B);
+  if (s != YL_OK) return s;
+  float* outs[YL_MAX_LEVELS];
+  for (int l = 0; l < c->L; ++l) outs[l] = (level_out && level_out[l]) ? level_out[l] : c->level_buf[l];
+  if (layer_ms) {
+    std::vector<hipEvent_t> ev(c->layers.size() + 1);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    s = run_layers(c, x, B, outs, st, ev.data());
+    if (s == YL_OK) {
+      HIPCHK(c, hipStreamSynchronize(st));
+      for (size_t i = 0; i < c->layers.size(); ++i) hipEventElapsedTime(&layer_ms[i], ev[i], ev[i + 1]);
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    return s;
+  }
+  if (c->opt_graph) {
+    bool same = c->graph_exec && c->graph_batch == B && c->graph_x == x;
+    for (int l = 0; same && l < c->L; ++l) same = (c->graph_out[l] == outs[l]);
+    if (!same) {
+      drop_graph(c);
+      hipStream_t cs;
+      HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      hipGraph_t g = nullptr;
+      HIPCHK(c, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+      s = run_layers(c, x, B, outs, cs, nullptr);
+      hipError_t e = hipStreamEndCapture(cs, &g);
+      if (s == YL_OK && e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+      if (g) hipGraphDestroy(g);
+      hipStreamDestroy(cs);
+      if (s != YL_OK) return s;
+      HIPCHK(c, e);
+      c->graph_batch = B; c->graph_x = x;
+      for (int l = 0; l < c->L; ++l) c->graph_out[l] = outs[l];
+    }
+    HIPCHK(c, hipGraphLaunch(c->graph_exec, st));
+    return YL_OK;
+  }
+  return run_layers(c, x, B, outs, st, nullptr);
+}
+
+yl_status yl_forward(yl_ctx* c, const float* x, int32_t B, float* const* level_out, void* stream) {
+  return forward_impl(c, x, B, level_out, (hipStream_t)stream, nullptr);
+}
+
+yl_status yl_forward_timed(yl_ctx* c, const float* x, int32_t B, float* const* level_out, void* stream,
+                           float* layer_ms) {
+  if (!layer_ms) return YL_ERR_INVALID;
+  return forward_impl(c, x, B, level_out, (hipStream_t)stream, layer_ms);
+}
+
+yl_status yl_read_slot(yl_ctx* c, int32_t slot, int32_t B, float* dst, void* stream) {
+  if (!c || !dst) return YL_ERR_INVALID;
+  if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, YL_ERR_INVALID, "bad slot");
+  if (B > c->cap_batch || !c->slots[slot].ptr) return fail(c, YL_ERR_STATE, "no forward has produced this slot");
+  HIPCHK(c, hipSetDevice(c->device));
+  const Slot& s = c->slots[slot];
+  HIPCHK(c, hipMemcpyAsync(dst, s.ptr, (size_t)B * s.h * s.w * s.c * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+  return YL_OK;
+}
+
+yl_status yl_decode(yl_ctx* c, const float* const* levels, int32_t B, int32_t center_mode, int32_t wh_mode,
+                    float* box, float* obj, float* cls, void* stream) {
+  if (!c || !levels || !box || !obj || B < 1) return YL_ERR_INVALID;
+  if (c->C > 0 && !cls) return fail(c, YL_ERR_INVALID, "cls_dev is NULL");
+  if (center_mode < 0 || center_mode > 1 || wh_mode < 0 || wh_mode > 2) return fail(c, YL_ERR_INVALID, "bad mode");
+  HIPCHK(c, hipSetDevice(c->device));
+  YlLevels lv;
+  fill_levels(c, levels, lv);
+  HIPCHK(c, yl_launch_decode_only(lv, B, center_mode, wh_mode, box, obj, cls, (hipStream_t)stream));
+  return YL_OK;
+}
+
+yl_status yl_postprocess(yl_ctx* c, const float* const* levels, int32_t B, const yl_post_cfg* cfg, float* dets,
+                         int32_t* counts, int32_t* keep_idx, void* stream) {
+  if (!c || !levels || !dets || !counts || B < 1) return YL_ERR_INVALID;
+  yl_status s = check_cfg(c, cfg);
+  if (s != YL_OK) return s;
+  HIPCHK(c, hipSetDevice(c->device));
+  return do_post(c, levels, B, cfg, dets, counts, keep_idx, (hipStream_t)stream);
+}
+
+yl_status yl_predict(yl_ctx* c, const float* x, int32_t B, const yl_post_cfg* cfg, float* dets, int32_t* counts,
+                     void* stream) {
+  if (!c || !dets || !counts) return YL_ERR_INVALID;
+  yl_status s = check_cfg(c, cfg);
+  if (s != YL_OK) return s;
+  s = forward_impl(c, x, B, nullptr, (hipStream_t)stream, nullptr);
+  if (s != YL_OK) return s;
+  return do_post(c, c->level_buf, B, cfg, dets, counts, nullptr, (hipStream_t)stream);
+}
+
+yl_status yl_nms(yl_ctx* c, const float* boxes, const float* scores, int32_t n, float iou_thr, int32_t impl,
+                 int32_t max_det, int32_t* keep, int32_t* count, void* stream) {
+  if (!c || !boxes || !scores || !keep || !count || n < 0 || max_det < 1) return YL_ERR_INVALID;
+  if (impl != YL_NMS_TORCHVISION && impl != YL_NMS_GREEDY) return fail(c, YL_ERR_INVALID, "bad nms_impl");
+  if (n >= (1 << 20)) return fail(c, YL_ERR_UNSUPPORTED, "n must be < 2^20");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    HIPCHK(c, hipMemsetAsync(count, 0, sizeof(int), st));
+    return YL_OK;
+  }
+  if (!c->ws_nms_clsws) HIPCHK(c, hipMalloc((void**)&c->ws_nms_clsws, 4 * sizeof(int)));
+  const int P = pow2ceil(n);
+  if (P > YL_LDS_KEYS_MAX && P > c->nms_gP) {
+    hipFree(c->ws_nms_gkeys);
+    c->ws_nms_gkeys = nullptr;
+    HIPCHK(c, hipMalloc((void**)&c->ws_nms_gkeys, (size_t)P * 8));
+    c->nms_gP = P;
+  }
+  // dets rows are not wanted here: reuse the top-k staging path's buffers? No -- a scratch dets
+  // buffer of max_det rows is taken from the tmp area sized for n rows.
+  float* scratch = nullptr;
+  HIPCHK(c, hipMallocAsync((void**)&scratch, (size_t)max_det * 6 * sizeof(float), st));
+  YlNmsP np;
+  memset(&np, 0, sizeof(np));
+  np.boxes = (const float4*)boxes; np.scores = scores; np.cls = nullptr;
+  np.N = n; np.C = 1;
+  np.conf_thr = -INFINITY; np.iou_thr = iou_thr; np.impl = impl;
+  np.cap = max_det; np.topk = 0; np.max_out = max_det;
+  np.cls_ws = c->ws_nms_clsws;
+  np.gkeys = c->ws_nms_gkeys; np.gP = c->nms_gP;
+  np.lds_cap = P < YL_LDS_KEYS_MAX ? P : YL_LDS_KEYS_MAX;
+  np.dets = scratch; np.counts = count; np.keep_idx = keep; np.backmap = nullptr;
+  hipError_t e = yl_launch_nms(np, 1, st);
+  hipFreeAsync(scratch, st);
+  HIPCHK(c, e);
+  return YL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,445 @@
+// Convolution kernels for gfx950 (MI355X / CDNA4), fp32 in / fp32 accumulate.
+//
+//   yl_conv_mfma_kernel  dense kxk conv (groups=1) as an implicit GEMM on v_mfma_f32_16x16x4_f32,
+//                        NHWC, im2col-free.  Computes D[n][p] = sum_k W[n][k] * X[p][k] (weights are
+//                        the MFMA A operand, activations the B operand) so that every lane ends up
+//                        with 4 CONSECUTIVE output channels of one pixel -> one float4 store per
+//                        16x16 tile, bias/act/residual/upsample-add applied in registers.
+//                        Optional depthwise kxk prologue computed on the fly in the B-operand path
+//                        (dw -> pw pairs of the reference's DWConvBlock / timm UIB never touch HBM
+//                        between the two convs).
+//   yl_stem_kernel       3x3 (Cin<=4) conv reading the NCHW network input, VALU with the weights as
+//                        scalar (SGPR) operands, writes NHWC.
+//   yl_dw_kernel         stand-alone depthwise kxk, NHWC, float4 over channels.
+//
+// The k dimension of the MFMA is permuted: inside each block of 16 input channels lane l supplies
+// channels 4*(l>>4)..4*(l>>4)+3 of pixel (l&15) from ONE float4 load and feeds them to 4 successive
+// MFMAs; the host packs the weights in the matching order ([tap][kblock][ntile][lane][4]) so that
+// the A fragments are a single conflict-free ds_read_b128 per 16x16x16 step.
+//
+// Replaces nn.Conv2d/BatchNorm2d(eval, folded)/ReLU/ReLU6/SiLU, F.interpolate(nearest)+add and the
+// head's view/cat/permute of the reference (scripts/model/model_v2.py:15-53,179-192,337-350) and of
+// the timm backbones it wraps (model_v2.py:94-100,266-272).
+#include "yl_internal.h"
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float yl_act1(float v, int act) {
+  switch (act) {
+    case YL_ACT_RELU: return fmaxf(v, 0.0f);
+    case YL_ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
+    case YL_ACT_SILU: return v / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+__device__ __forceinline__ f32x4 yl_act4(f32x4 v, int act) {
+  f32x4 r;
+  r.x = yl_act1(v.x, act); r.y = yl_act1(v.y, act); r.z = yl_act1(v.z, act); r.w = yl_act1(v.w, act);
+  return r;
+}
+__device__ __forceinline__ f32x4 yl_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+enum { YL_CM_PW = 0, YL_CM_KXK = 1, YL_CM_DWPRO = 2 };
+
+// ------------------------------------------------------------------------------------------------
+// B-operand fetch: 4 consecutive input channels [c, c+4) of the lane's pixel for tap (ky,kx).
+// Branch-free: addresses are clamped into the tensor and out-of-range values are zeroed by a select,
+// so the hot loop stays straight-line code (loads issue early, MFMAs back to back).
+struct YlPix {
+  int b, oy, ox;     // output pixel (clamped to a valid pixel for address generation)
+  bool valid;        // false for the padding lanes of the last tile (never stored)
+  size_t lin;        // linear output pixel index (clamped)
+};
+
+__device__ __forceinline__ f32x4 yl_sel4(bool keep, f32x4 v) {
+  f32x4 r;
+  r.x = keep ? v.x : 0.f; r.y = keep ? v.y : 0.f; r.z = keep ? v.z : 0.f; r.w = keep ? v.w : 0.f;
+  return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int ky, int kx, int c) {
+  const bool cin_ok = c < p.Cin;
+  const int cs = cin_ok ? c : (p.Cin - 4);
+  if (MODE == YL_CM_PW) {
+    return yl_sel4(cin_ok, yl_ld4(p.x + px.lin * p.Cin + cs));
+  } else if (MODE == YL_CM_KXK) {
+    const int iy = px.oy * p.stride - p.pad_t + ky;
+    const int ix = px.ox * p.stride - p.pad_l + kx;
+    const bool in = cin_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+    return yl_sel4(in, yl_ld4(p.x + (((size_t)px.b * p.H + iyc) * p.W + ixc) * p.Cin + cs));
+  } else {  // depthwise prologue feeding a 1x1 conv: value of the dw output at (oy,ox)
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (p.dw_b) s = yl_ld4(p.dw_b + cs);
+    const int y0 = px.oy * p.dw_stride - p.dw_pad_t;
+    const int x0 = px.ox * p.dw_stride - p.dw_pad_l;
+    const float* xb = p.x + (size_t)px.b * p.H * p.W * p.Cin + cs;
+    const float* wb = p.dw_w + cs;
+    for (int dy = 0; dy < p.dw_k; ++dy) {
+      const int iy = y0 + dy;
+      const bool yin = iy >= 0 && iy < p.H;
+      const int iyc = min(max(iy, 0), p.H - 1);
+      for (int dx = 0; dx < p.dw_k; ++dx) {
+        const int ix = x0 + dx;
+        const bool in = yin && ix >= 0 && ix < p.W;
+        const int ixc = min(max(ix, 0), p.W - 1);
+        const f32x4 v = yl_sel4(in, yl_ld4(xb + ((size_t)iyc * p.W + ixc) * p.Cin));
+        const f32x4 w = yl_ld4(wb + (dy * p.dw_k + dx) * p.Cin);
+        s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
+        s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
+      }
+    }
+    s = yl_act4(s, p.dw_act);
+    return yl_sel4(cin_ok, s);
+  }
+}
+
+// ---- epilogues.  Lane holds channels n..n+3 (n = ntile*16 + 4*kq) of pixel px[mt].
+// ReLU-family activations are a branch-free clamp to [lo,hi] (lo=-inf/0, hi=6/+inf).
+template <int NT, int MT>
+__device__ __forceinline__ void yl_epi_fast(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT], int nt0,
+                                            int kq, float lo, float hi) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (!px[mt].valid) continue;
+    float* orow = p.out + px[mt].lin * p.N;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (nt0 + nt) * 16 + 4 * kq;
+      f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
+      v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
+      v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
+      if (n < p.N) *reinterpret_cast<f32x4*>(orow + n) = v;
+    }
+  }
+}
+
+template <int NT, int MT>
+__device__ __forceinline__ void yl_epi_generic(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT],
+                                               int nt0, int kq) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (!px[mt].valid) continue;
+    const size_t obase = px[mt].lin * p.N;
+    size_t up_off = 0;
+    if (p.up) {
+      const int uy = (px[mt].oy * p.UH) / p.OH, ux = (px[mt].ox * p.UW) / p.OW;
+      up_off = (((size_t)px[mt].b * p.UH + uy) * p.UW + ux) * p.N;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (nt0 + nt) * 16 + 4 * kq;
+      if (n >= p.N) continue;
+      f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
+      v = yl_act4(v, p.act);
+      if (p.res) v += yl_ld4(p.res + obase + n);
+      if (p.up) v += yl_ld4(p.up + up_off + n);
+      *reinterpret_cast<f32x4*>(p.out + obase + n) = v;
+    }
+  }
+}
+
+// scalar-store variant for N % 4 != 0 (the detection head: N = 5+C, rows of one anchor of one level,
+// image pitch p.out_bstride) -- one 64-bit row base per pixel, immediate offsets per element.
+template <int NT, int MT>
+__device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT], int nt0,
+                                              int kq, float lo, float hi) {
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (!px[mt].valid) continue;
+    const int cell = px[mt].oy * p.OW + px[mt].ox;
+    float* orow = p.out + (size_t)px[mt].b * p.out_bstride + (size_t)cell * p.N + 4 * kq;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (nt0 + nt) * 16 + 4 * kq;
+      f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e = fminf(fmaxf(v[r], lo), hi);
+        if (p.act == YL_ACT_SILU) e = yl_act1(v[r], YL_ACT_SILU);
+        if (n + r < p.N) orow[(nt0 + nt) * 16 + r] = e;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid.x: persistent over M tiles (4 waves x MT x 16 pixels each), grid.y: chunks of NT n-tiles.
+// LDS: weight chunk [CH][NT][64] float4 (n-tiles beyond the layer's last one are zero-filled so the
+// hot loop needs no tile predicate).
+template <int NT, int MT, int MODE>
+__global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float yl_wlds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, pl = lane & 15;
+  const int nt0 = blockIdx.y * NT;
+  const int ntc = (p.NTtot - nt0) < NT ? (p.NTtot - nt0) : NT;
+  const int TK = p.TK, CH = p.CH;
+  const bool single = (CH >= TK);
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_wlds);
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
+  const int ohw = p.OH * p.OW;
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+
+  auto load_chunk = [&](int c0, int c1) {
+    for (int t = c0 + wave; t < c1; t += 4) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (nt < ntc) w = wg[((size_t)t * p.NTtot + nt0 + nt) * 64 + lane];
+        wl[((t - c0) * NT + nt) * 64 + lane] = w;
+      }
+    }
+  };
+  if (single) {
+    load_chunk(0, TK);
+    __syncthreads();
+  }
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    YlPix px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      size_t lin = ((size_t)tile * 4 + wave) * (MT * 16) + mt * 16 + pl;
+      px[mt].valid = lin < (size_t)p.M;
+      if (!px[mt].valid) lin = (size_t)p.M - 1;
+      px[mt].lin = lin;
+      const int b = (int)(lin / ohw);
+      const int rem = (int)(lin - (size_t)b * ohw);
+      px[mt].b = b;
+      px[mt].oy = rem / p.OW;
+      px[mt].ox = rem - px[mt].oy * p.OW;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < TK; c0 += CH) {
+      const int c1 = (c0 + CH) < TK ? (c0 + CH) : TK;
+      if (!single) {
+        __syncthreads();
+        load_chunk(c0, c1);
+        __syncthreads();
+      }
+      // running (tap, kblock) counters for step c0
+      int tap = c0 / p.KB, kb = c0 - tap * p.KB;
+      int ky = tap / p.k, kx = tap - ky * p.k;
+      f32x4 xq[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_fetch<MODE>(p, px[mt], ky, kx, kb * 16 + 4 * kq);
+      for (int t = c0; t < c1; ++t) {
+        // advance the counters and issue the next step's activation loads before this step's MFMAs
+        int kb2 = kb + 1, ky2 = ky, kx2 = kx;
+        if (kb2 == p.KB) { kb2 = 0; if (++kx2 == p.k) { kx2 = 0; ++ky2; } }
+        if (t + 1 == c1) { kb2 = kb; ky2 = ky; kx2 = kx; }     // last step: harmless re-fetch
+        f32x4 xn[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xn[mt] = yl_fetch<MODE>(p, px[mt], ky2, kx2, kb2 * 16 + 4 * kq);
+        const f32x4* wrow = wl + (size_t)(t - c0) * NT * 64 + lane;
+        f32x4 wq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[nt][s], xq[mt][s], acc[mt][nt], 0, 0, 0);
+        kb = kb2; ky = ky2; kx = kx2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xq[mt] = xn[mt];
+      }
+    }
+
+    if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+    else if (p.res || p.up || p.act == YL_ACT_SILU) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: 3x3 conv, Cin = 3 (NCHW input), one output pixel per lane, all COUT channels in registers.
+// Weights [ky][kx][c][COUT] + bias [COUT] are read through the constant address space with
+// wave-uniform addresses -> s_load, used as the scalar operand of v_fmac_f32.
+template <int COUT>
+__global__ __launch_bounds__(256) void yl_stem_kernel(YlConvP p) {
+  typedef const __attribute__((address_space(4))) float cfloat;
+  cfloat* wc = (cfloat*)p.wp;
+  cfloat* bc = (cfloat*)p.bias;
+  const size_t lin = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (lin >= (size_t)p.M) return;
+  const int ohw = p.OH * p.OW;
+  const int b = (int)(lin / ohw);
+  const int rem = (int)(lin - (size_t)b * ohw);
+  const int oy = rem / p.OW, ox = rem - oy * p.OW;
+  float acc[COUT];
+#pragma unroll
+  for (int n = 0; n < COUT; ++n) acc[n] = bc[n];
+  const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
+  const size_t plane = (size_t)p.H * p.W;
+  const float* xb = p.x + (size_t)b * 3 * plane;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = y0 + ky;
+    const bool yin = iy >= 0 && iy < p.H;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = x0 + kx;
+      const bool in = yin && ix >= 0 && ix < p.W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = in ? xb[c * plane + (size_t)iy * p.W + ix] : 0.0f;
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(v, wc[((ky * 3 + kx) * 3 + c) * COUT + n], acc[n]);
+      }
+    }
+  }
+  float* o = p.out + lin * COUT;
+#pragma unroll
+  for (int n = 0; n < COUT; n += 4) {
+    f32x4 v = {yl_act1(acc[n], p.act), yl_act1(acc[n + 1], p.act), yl_act1(acc[n + 2], p.act),
+               yl_act1(acc[n + 3], p.act)};
+    *reinterpret_cast<f32x4*>(o + n) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone depthwise kxk: lane = (pixel, 4 channels); weights [tap][C].
+__global__ __launch_bounds__(256) void yl_dw_kernel(YlConvP p) {
+  const int cq = p.Cin >> 2;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)p.M * cq) return;
+  const size_t lin = i / cq;
+  const int c = (int)(i - lin * cq) * 4;
+  const int ohw = p.OH * p.OW;
+  const int b = (int)(lin / ohw);
+  const int rem = (int)(lin - (size_t)b * ohw);
+  const int oy = rem / p.OW, ox = rem - oy * p.OW;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) s = yl_ld4(p.bias + c);
+  const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
+  const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin + c;
+  for (int dy = 0; dy < p.k; ++dy) {
+    const int iy = y0 + dy;
+    if (iy < 0 || iy >= p.H) continue;
+    for (int dx = 0; dx < p.k; ++dx) {
+      const int ix = x0 + dx;
+      if (ix < 0 || ix >= p.W) continue;
+      const f32x4 v = yl_ld4(xb + ((size_t)iy * p.W + ix) * p.Cin);
+      const f32x4 w = yl_ld4(p.wp + (dy * p.k + dx) * p.Cin + c);
+      s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
+      s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
+    }
+  }
+  s = yl_act4(s, p.act);
+  const size_t o = lin * p.N + c;
+  if (p.res) s += yl_ld4(p.res + o);
+  *reinterpret_cast<f32x4*>(p.out + o) = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+#define YL_CONV_LDS_MAX (96 * 1024)
+
+template <int NT, int MT, int MODE>
+static hipError_t yl_conv_attr() {
+  return hipFuncSetAttribute((const void*)yl_conv_mfma_kernel<NT, MT, MODE>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, YL_CONV_LDS_MAX);
+}
+template <int NT, int MT>
+static hipError_t yl_conv_attr_modes() {
+  hipError_t e;
+  if ((e = yl_conv_attr<NT, MT, YL_CM_PW>()) != hipSuccess) return e;
+  if ((e = yl_conv_attr<NT, MT, YL_CM_KXK>()) != hipSuccess) return e;
+  return yl_conv_attr<NT, MT, YL_CM_DWPRO>();
+}
+template <int MT>
+static hipError_t yl_conv_attr_nt() {
+  hipError_t e;
+  if ((e = yl_conv_attr_modes<1, MT>()) != hipSuccess) return e;
+  if ((e = yl_conv_attr_modes<2, MT>()) != hipSuccess) return e;
+  if ((e = yl_conv_attr_modes<3, MT>()) != hipSuccess) return e;
+  if ((e = yl_conv_attr_modes<4, MT>()) != hipSuccess) return e;
+  if ((e = yl_conv_attr_modes<6, MT>()) != hipSuccess) return e;
+  return yl_conv_attr_modes<8, MT>();
+}
+hipError_t yl_conv_init() {
+  hipError_t e = yl_conv_attr_nt<1>();
+  if (e != hipSuccess) return e;
+  return yl_conv_attr_nt<2>();
+}
+
+template <int NT, int MT>
+static void yl_conv_go(const YlConvP& p, int mode, dim3 grid, size_t lds, hipStream_t st) {
+  if (mode == YL_CM_PW) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_PW>), grid, dim3(256), lds, st, p);
+  else if (mode == YL_CM_KXK) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_KXK>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DWPRO>), grid, dim3(256), lds, st, p);
+}
+template <int MT>
+static void yl_conv_go_nt(const YlConvP& p, int NT, int mode, dim3 grid, size_t lds, hipStream_t st) {
+  switch (NT) {
+    case 1: yl_conv_go<1, MT>(p, mode, grid, lds, st); break;
+    case 2: yl_conv_go<2, MT>(p, mode, grid, lds, st); break;
+    case 3: yl_conv_go<3, MT>(p, mode, grid, lds, st); break;
+    case 4: yl_conv_go<4, MT>(p, mode, grid, lds, st); break;
+    case 6: yl_conv_go<6, MT>(p, mode, grid, lds, st); break;
+    default: yl_conv_go<8, MT>(p, mode, grid, lds, st); break;
+  }
+}
+
+// choose (NT, MT, chunking) for a layer and launch.  tile_hint: 0 = auto, 1/2 = force MT.
+hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
+  YlConvP p = p0;
+  const int nts[6] = {1, 2, 3, 4, 6, 8};
+  int NT = 8;
+  if (p.NTtot <= 8) {
+    for (int i = 0; i < 6; ++i) if (nts[i] >= p.NTtot) { NT = nts[i]; break; }
+  } else {
+    // smallest number of chunks, then the least padding
+    int best = 8, bestc = (p.NTtot + 7) / 8;
+    for (int i = 5; i >= 3; --i) {
+      const int c = (p.NTtot + nts[i] - 1) / nts[i];
+      if (c < bestc || (c == bestc && nts[i] < best)) { best = nts[i]; bestc = c; }
+    }
+    NT = best;
+  }
+  const int gy = (p.NTtot + NT - 1) / NT;
+  int MT = 2;
+  const long tiles2 = ((long)p.M + 127) / 128;
+  if (tile_hint == 1 || (tile_hint == 0 && tiles2 * gy < 2 * YL_NUM_CU)) MT = 1;
+  p.ntiles = (int)(((long)p.M + 64 * MT - 1) / (64 * MT));
+  // LDS weight chunk: whole K if it fits, else stream 48 KiB chunks
+  const size_t step_bytes = (size_t)NT * 1024;
+  if ((size_t)p.TK * step_bytes <= YL_CONV_LDS_MAX) p.CH = p.TK;
+  else p.CH = (int)((48 * 1024) / step_bytes);
+  const size_t lds = (size_t)p.CH * step_bytes;
+  int gx = (4 * YL_NUM_CU) / gy;
+  if (gx < 8) gx = 8;
+  gx &= ~7;                         // multiple of 8: N-chunks of one M tile land on the same XCD/L2
+  if (gx > p.ntiles) gx = p.ntiles;
+  const int mode = p.dw_k > 0 ? YL_CM_DWPRO : ((p.k == 1 && p.stride == 1) ? YL_CM_PW : YL_CM_KXK);
+  dim3 grid(gx, gy);
+  if (MT == 2) yl_conv_go_nt<2>(p, NT, mode, grid, lds, st);
+  else yl_conv_go_nt<1>(p, NT, mode, grid, lds, st);
+  return hipGetLastError();
+}
+
+hipError_t yl_launch_stem(const YlConvP& p, hipStream_t st) {
+  dim3 grid((unsigned)(((size_t)p.M + 255) / 256));
+  if (p.N == 32) hipLaunchKernelGGL(yl_stem_kernel<32>, grid, dim3(256), 0, st, p);
+  else if (p.N == 16) hipLaunchKernelGGL(yl_stem_kernel<16>, grid, dim3(256), 0, st, p);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st) {
+  const size_t total = (size_t)p.M * (p.Cin >> 2);
+  hipLaunchKernelGGL(yl_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+  return hipGetLastError();
+}

@@ -1,0 +1,87 @@
+// Internal declarations shared by the HIP translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/yololite_hip.h"
+
+#define YL_NUM_CU 256          // MI355X: 8 XCDs x 32 CUs
+#define YL_LDS_KEYS_MAX 16384  // 64-bit sort keys that fit the 160 KiB LDS of one CU (128 KiB)
+
+// ---- detection-level geometry handed to the post-processing kernels by value -------------------
+struct YlLevels {
+  const float* ptr[YL_MAX_LEVELS];  // level l: [B, A, S, S, E] contiguous
+  int S[YL_MAX_LEVELS];
+  int A[YL_MAX_LEVELS];
+  int off[YL_MAX_LEVELS + 1];       // candidate offset of level l inside [0, N)
+  float stride[YL_MAX_LEVELS];      // img_size / float(S)   (utils_ms.py:71)
+  int L, N, E, C;
+  float hi;                         // img_size - 1
+};
+
+struct YlDecodeP {
+  int mode;            // YL_POST_*
+  int center_mode, wh_mode;
+  float4* boxes;       // [B][N]
+  float* scores;       // [B][N]   (-inf for candidates removed by the fallback min-side filter)
+  int* cls;            // [B][N]
+};
+
+struct YlNmsP {
+  const float4* boxes;   // [B][N]
+  const float* scores;   // [B][N]
+  const int* cls;        // [B][N] or nullptr (single class 0)
+  int N, C;
+  float conf_thr, iou_thr;
+  int impl;              // YL_NMS_*
+  int cap;               // per-class cap (INT_MAX = none)
+  int topk;              // global top-k (0 = none)
+  int max_out;
+  int* cls_ws;           // [B][4][C]: start, end, kept, off
+  unsigned long long* gkeys;  // [B][gP] global key storage when survivors exceed the LDS capacity
+  int gP;
+  int lds_cap;           // keys that fit the dynamic LDS of this launch
+  float* dets;           // [B][max_out][6]
+  int* counts;           // [B]
+  int* keep_idx;         // [B][max_out] or nullptr
+  const float* backmap;  // [B][5] or nullptr
+  float* tmp_dets;       // [B][N][6]  (fallback top-k staging) or nullptr
+  int* tmp_idx;          // [B][N]
+};
+
+// ---- conv layer parameters (one struct for all conv kernels) -----------------------------------
+struct YlConvP {
+  const float* x;        // input: NHWC [B,H,W,Cin]  (STEM: NCHW [B,Cin,H,W])
+  const float* wp;       // packed weights (see yl_api.cpp pack_* for the layouts)
+  const float* bias;     // [Npad16] (zero padded) or nullptr
+  const float* res;      // residual NHWC [B,OH,OW,N] or nullptr
+  const float* up;       // NHWC [B,UH,UW,N] nearest-upsampled and added, or nullptr
+  float* out;
+  const float* dw_w;     // [dw_k*dw_k][Cin] tap-major
+  const float* dw_b;     // [Cin] or nullptr
+  int B, H, W, Cin;      // input tensor
+  int OH, OW, N;         // output tensor (N = Cout)
+  int k, stride, pad_t, pad_l;
+  int act;
+  int dw_k, dw_stride, dw_pad_t, dw_pad_l, dw_act;
+  int MH, MW;            // grid the main conv reads (== H,W without prologue; dw output grid with it)
+  int KB;                // ceil(Cin/16): 16-wide k blocks per tap
+  int TK;                // taps * KB
+  int NTtot;             // ceil(N/16)
+  int CH;                // k-steps (of 16) per LDS weight chunk
+  int UH, UW;
+  long out_bstride;      // floats between images in `out` (OH*OW*N, or A*OH*OW*E for a head level)
+  int M;                 // B*OH*OW
+  int ntiles;            // M tiles
+};
+
+// launchers implemented in the .hip files
+hipError_t yl_launch_decode_score(const YlLevels& lv, int B, const YlDecodeP& p, hipStream_t st);
+hipError_t yl_launch_decode_only(const YlLevels& lv, int B, int center_mode, int wh_mode, float* box,
+                                 float* obj, float* cls, hipStream_t st);
+hipError_t yl_launch_nms(const YlNmsP& p, int B, hipStream_t st);
+hipError_t yl_post_init();   // one-time function attributes (large dynamic LDS)
+
+hipError_t yl_launch_stem(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv(const YlConvP& p, int tile_hint, hipStream_t st);
+hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st);
+hipError_t yl_conv_init();

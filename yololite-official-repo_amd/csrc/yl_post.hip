@@ -1,0 +1,429 @@
+// Post-processing kernels for gfx950 (MI355X): anchor-free decode + score + threshold, and batched
+// class-wise NMS (LDS bitonic sort + wave64 ballot suppression).
+//
+// Compiled with -ffp-contract=off: every expression below is evaluated with one rounding per
+// operation in the association order of the reference expressions, so that results on identical
+// inputs are identical to the reference's fp32 CPU arithmetic (up to libm ulp differences in
+// expf/log1pf).
+//
+// Reference semantics implemented here (paths in the reference repository):
+//   decode           scripts/helpers/utils_ms.py:71-106
+//   score/threshold  tools/infer.py:463-475 (main), :310-340 (fallback), scripts/helpers/helpers.py:106-123
+//   per-class NMS    tools/infer.py:476-493 + nms() :134-152 ; helpers.py:126-136
+//   torchvision nms  stable sort by score desc; suppress j iff inter/(a_i+a_j-inter) > thr (NaN keeps)
+//   greedy fallback  tools/infer.py:139-163  IoU = inter/(a1+a2-inter+1e-6); keep iff IoU <= thr
+//   global top-k     tools/infer.py:368-379
+//   back-map         tools/infer.py:508-516
+#include "yl_internal.h"
+#include <limits.h>
+#include <math.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float yl_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float yl_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float yl_clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+__device__ __forceinline__ int yl_level_of(const YlLevels& lv, int n) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < YL_MAX_LEVELS; ++i)
+    if (i < lv.L && n >= lv.off[i]) l = i;
+  return l;
+}
+
+__device__ __forceinline__ void yl_decode_box(const YlLevels& lv, int l, int r, float tx, float ty, float tw,
+                                              float th, int center_mode, int wh_mode, float& px, float& py,
+                                              float& pw, float& ph) {
+  const int S = lv.S[l];
+  const int cell = r % (S * S);
+  const float gx = (float)(cell % S), gy = (float)(cell / S);
+  const float st = lv.stride[l];
+  const float sx = yl_sigmoid(tx), sy = yl_sigmoid(ty);
+  if (center_mode == YL_CENTER_V8) {
+    px = ((sx * 2.0f - 0.5f) + gx) * st;
+    py = ((sy * 2.0f - 0.5f) + gy) * st;
+  } else {
+    px = (sx + gx) * st;
+    py = (sy + gy) * st;
+  }
+  if (wh_mode == YL_WH_SOFTPLUS) {
+    pw = yl_softplus(tw) * st;
+    ph = yl_softplus(th) * st;
+  } else if (wh_mode == YL_WH_V8) {
+    const float a = yl_sigmoid(tw) * 2.0f, b = yl_sigmoid(th) * 2.0f;
+    pw = (a * a) * st;
+    ph = (b * b) * st;
+  } else {
+    pw = expf(yl_clampf(tw, -4.0f, 4.0f)) * st;
+    ph = expf(yl_clampf(th, -4.0f, 4.0f)) * st;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode + score: one lane per candidate.  A wave stages its 64 candidate rows (64*E contiguous
+// floats inside one level) through a wave-private LDS region with coalesced reads, then every lane
+// walks its own row (odd row pitch -> conflict-free ds_read_b32).
+// grid = (ceil(N/128), B), block = 128 (2 waves).  HBM traffic: N*E*4 B read, N*24 B written / image.
+template <bool STAGE>
+__global__ __launch_bounds__(128) void yl_decode_score_kernel(YlLevels lv, int B, YlDecodeP p) {
+  extern __shared__ __attribute__((aligned(16))) float yl_smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int n0 = (blockIdx.x * 2 + wave) * 64;
+  const int E = lv.E, Ep = E | 1;
+  float* rows = yl_smem + wave * 64 * Ep;
+  if (STAGE) {
+    for (int r = 0; r < 64; ++r) {
+      const int n = n0 + r;
+      if (n >= lv.N) break;
+      const int l = yl_level_of(lv, n);
+      const int nl = lv.A[l] * lv.S[l] * lv.S[l];
+      const float* src = lv.ptr[l] + ((size_t)b * nl + (n - lv.off[l])) * E;
+      for (int c = lane; c < E; c += 64) rows[r * Ep + c] = src[c];
+    }
+    __syncthreads();
+  }
+  const int n = n0 + lane;
+  if (n >= lv.N) return;
+  const int l = yl_level_of(lv, n);
+  const int r = n - lv.off[l];
+  const float* row;
+  if (STAGE) {
+    row = rows + lane * Ep;
+  } else {
+    const int nl = lv.A[l] * lv.S[l] * lv.S[l];
+    row = lv.ptr[l] + ((size_t)b * nl + r) * E;
+  }
+  float px, py, pw, ph;
+  yl_decode_box(lv, l, r, row[0], row[1], row[2], row[3], p.center_mode, p.wh_mode, px, py, pw, ph);
+  const float obj = yl_sigmoid(row[4]);
+  float score;
+  int ci = 0;
+  const int C = lv.C;
+  if (C > 1) {
+    float best = yl_sigmoid(row[5]);
+    for (int c = 1; c < C; ++c) {                 // first maximum wins, like torch.max(dim)
+      const float s = yl_sigmoid(row[5 + c]);
+      if (s > best) { best = s; ci = c; }
+    }
+    score = obj * best;
+  } else if (C == 1 && p.mode == YL_POST_FALLBACK) {
+    score = obj * yl_sigmoid(row[5]);             // tools/infer.py:316-320
+  } else {
+    score = obj;                                  // tools/infer.py:470-472, helpers.py:113-115
+  }
+  if (p.mode == YL_POST_FALLBACK && !(pw >= 2.0f && ph >= 2.0f)) score = -INFINITY;  // :334-340
+  float4 bx;
+  bx.x = yl_clampf(px - pw * 0.5f, 0.0f, lv.hi);
+  bx.y = yl_clampf(py - ph * 0.5f, 0.0f, lv.hi);
+  bx.z = yl_clampf(px + pw * 0.5f, 0.0f, lv.hi);
+  bx.w = yl_clampf(py + ph * 0.5f, 0.0f, lv.hi);
+  const size_t o = (size_t)b * lv.N + n;
+  p.boxes[o] = bx;
+  p.scores[o] = score;
+  p.cls[o] = ci;
+}
+
+// decode only (decode_preds_anchorfree): box + obj logits; class logits copied by a second kernel.
+__global__ __launch_bounds__(256) void yl_decode_box_kernel(YlLevels lv, int B, int center_mode, int wh_mode,
+                                                           float4* box, float* obj) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= lv.N) return;
+  const int l = yl_level_of(lv, n);
+  const int r = n - lv.off[l];
+  const int nl = lv.A[l] * lv.S[l] * lv.S[l];
+  const float* row = lv.ptr[l] + ((size_t)b * nl + r) * lv.E;
+  float px, py, pw, ph;
+  yl_decode_box(lv, l, r, row[0], row[1], row[2], row[3], center_mode, wh_mode, px, py, pw, ph);
+  float4 bx;
+  bx.x = yl_clampf(px - pw * 0.5f, 0.0f, lv.hi);
+  bx.y = yl_clampf(py - ph * 0.5f, 0.0f, lv.hi);
+  bx.z = yl_clampf(px + pw * 0.5f, 0.0f, lv.hi);
+  bx.w = yl_clampf(py + ph * 0.5f, 0.0f, lv.hi);
+  box[(size_t)b * lv.N + n] = bx;
+  obj[(size_t)b * lv.N + n] = row[4];
+}
+
+__global__ __launch_bounds__(256) void yl_copy_cls_kernel(YlLevels lv, int B, float* cls) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // over N*C of one image
+  const int b = blockIdx.y;
+  const int C = lv.C;
+  if (i >= (size_t)lv.N * C) return;
+  const int n = (int)(i / C), c = (int)(i % C);
+  const int l = yl_level_of(lv, n);
+  const int nl = lv.A[l] * lv.S[l] * lv.S[l];
+  cls[(size_t)b * lv.N * C + i] = lv.ptr[l][((size_t)b * nl + (n - lv.off[l])) * lv.E + 5 + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// NMS.  One 1024-thread workgroup per image.
+//   key = class(12) | ~orderable(score)(32) | candidate index(20): an ascending sort yields
+//   class asc, score desc, index asc == per-class stable descending sort of the masked candidates.
+__device__ __forceinline__ u32 yl_desc_bits(float s) {
+  u32 u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable
+  return ~u;                                        // descending
+}
+
+__device__ __forceinline__ bool yl_suppress(const float4& bi, float ai, const float4& bj, float aj, float thr,
+                                            int impl) {
+  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+  const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+  const float inter = w * h;
+  if (impl == YL_NMS_TORCHVISION) {
+    const float ovr = inter / (ai + aj - inter);
+    return ovr > thr;                               // NaN (0/0) never suppresses
+  }
+  const float iou = inter / (ai + aj - inter + 1e-6f);
+  return !(iou <= thr);                             // reference keeps iff iou <= thr
+}
+
+__device__ __forceinline__ float4 yl_shfl4(const float4& v, int src) {
+  float4 r;
+  r.x = __shfl(v.x, src); r.y = __shfl(v.y, src); r.z = __shfl(v.z, src); r.w = __shfl(v.w, src);
+  return r;
+}
+
+template <typename KeyPtr>
+__device__ __forceinline__ void yl_bitonic_sort(KeyPtr keys, int P, int tid, int nthreads) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < (P >> 1); i += nthreads) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int hi = lo | j;
+        const u64 a = keys[lo], c = keys[hi];
+        const bool up = (lo & k) == 0;
+        if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// greedy NMS of one class segment [s,e) of the sorted key array by ONE wave.
+// k32 views the 64-bit keys as u32 pairs: [2*pos] = candidate index, [2*pos+1] = kept list of the
+// segment (entry s+k holds the sorted position of the k-th kept box).
+template <typename K32Ptr>
+__device__ __forceinline__ int yl_nms_segment(K32Ptr k32, int s, int e, const float4* __restrict__ boxes, float thr,
+                                              int impl, int cap, int lane) {
+  int nk = 0;
+  for (int cs = s; cs < e && nk < cap; cs += 64) {
+    const int pos = cs + lane;
+    const bool valid = pos < e;
+    const u32 idx = valid ? k32[2 * pos] : 0u;
+    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) bj = boxes[idx];
+    const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+    bool alive = valid;
+    for (int k = 0; k < nk; ++k) {                          // boxes kept by earlier chunks
+      const u32 q = k32[2 * (s + k) + 1];
+      const float4 bi = boxes[k32[2 * q]];
+      const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+      if (alive && yl_suppress(bi, ai, bj, aj, thr, impl)) alive = false;
+    }
+    u64 rem = __ballot(alive);
+    while (rem) {                                           // serial resolution inside the chunk
+      const int t = __ffsll((long long)rem) - 1;
+      rem &= rem - 1;
+      const float4 bt = yl_shfl4(bj, t);
+      const float at = __shfl(aj, t);
+      if (alive && lane > t && yl_suppress(bt, at, bj, aj, thr, impl)) alive = false;
+      rem &= __ballot(alive);
+    }
+    const u64 mask = __ballot(alive);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (alive && nk + rank < cap) k32[2 * (s + nk + rank) + 1] = (u32)pos;
+    nk += __popcll(mask);
+  }
+  return nk < cap ? nk : cap;
+}
+
+__device__ __forceinline__ void yl_write_det(const YlNmsP& p, int b, float* dst, int* dst_idx, int orow,
+                                             const float4& bx, float score, int c, int idx, bool mapped) {
+  float x1 = bx.x, y1 = bx.y, x2 = bx.z, y2 = bx.w;
+  if (mapped && p.backmap) {                                 // tools/infer.py:508-516
+    const float* m = p.backmap + b * 5;
+    x1 = (x1 - m[0]) / m[2]; x2 = (x2 - m[0]) / m[2];
+    y1 = (y1 - m[1]) / m[2]; y2 = (y2 - m[1]) / m[2];
+    x1 = yl_clampf(x1, 0.f, m[3] - 1.f); x2 = yl_clampf(x2, 0.f, m[3] - 1.f);
+    y1 = yl_clampf(y1, 0.f, m[4] - 1.f); y2 = yl_clampf(y2, 0.f, m[4] - 1.f);
+  }
+  float* d = dst + (size_t)orow * 6;
+  d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = score; d[5] = (float)c;
+  if (dst_idx) dst_idx[orow] = idx;
+}
+
+// Body of the NMS kernel, instantiated once for LDS key storage and once for the global-memory
+// fallback so that each gets address-space-specific code after inlining.
+template <bool LDS_KEYS>
+__device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, int nsurv, int b, int* s_misc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int N = p.N, C = p.C;
+  const float4* boxes = p.boxes + (size_t)b * N;
+  const float* scores = p.scores + (size_t)b * N;
+  const int* cls = p.cls ? p.cls + (size_t)b * N : nullptr;
+  int* ws_start = p.cls_ws + (size_t)b * 4 * C;
+  int* ws_end = ws_start + C;
+  int* ws_kept = ws_end + C;
+  int* ws_off = ws_kept + C;
+  u32* k32 = (u32*)keys;
+
+  if (tid == 0) s_misc[1] = 0;
+  for (int c = tid; c < C; c += blockDim.x) { ws_start[c] = -1; ws_end[c] = 0; ws_kept[c] = 0; ws_off[c] = 0; }
+  __syncthreads();
+  for (int n = tid; n < N; n += blockDim.x) {
+    const float sc = scores[n];
+    if (sc > p.conf_thr) {
+      const int slot = atomicAdd(&s_misc[1], 1);
+      const u64 c = cls ? (u64)cls[n] : 0ull;
+      keys[slot] = (c << 52) | ((u64)yl_desc_bits(sc) << 20) | (u64)n;
+    }
+  }
+  for (int i = nsurv + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
+  __syncthreads();
+  yl_bitonic_sort(keys, P, tid, blockDim.x);
+
+  for (int pos = tid; pos < nsurv; pos += blockDim.x) {
+    const int c = (int)(keys[pos] >> 52);
+    if (pos == 0 || (int)(keys[pos - 1] >> 52) != c) ws_start[c] = pos;
+    if (pos == nsurv - 1 || (int)(keys[pos + 1] >> 52) != c) ws_end[c] = pos + 1;
+  }
+  __syncthreads();
+  for (int pos = tid; pos < nsurv; pos += blockDim.x) keys[pos] = keys[pos] & 0xFFFFFull;
+  __syncthreads();
+
+  for (int c = wave; c < C; c += nwaves) {
+    const int s = ws_start[c];
+    if (s < 0) continue;
+    const int nk = yl_nms_segment(k32, s, ws_end[c], boxes, p.iou_thr, p.impl, p.cap, lane);
+    if (lane == 0) ws_kept[c] = nk;
+  }
+  __syncthreads();
+
+  // -- output offsets: exclusive scan of the kept counts over classes (wave 0)
+  if (wave == 0) {
+    int running = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      const int v = (c < C) ? ws_kept[c] : 0;
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (c < C) ws_off[c] = running + incl - v;
+      running += __shfl(incl, 63);
+    }
+    if (lane == 0) s_misc[2] = running;
+  }
+  __syncthreads();
+  const int total = s_misc[2];
+  const bool do_topk = (p.topk > 0) && (total > p.topk);
+  float* dst = do_topk ? p.tmp_dets + (size_t)b * N * 6 : p.dets + (size_t)b * p.max_out * 6;
+  int* dst_idx = do_topk ? p.tmp_idx + (size_t)b * N : (p.keep_idx ? p.keep_idx + (size_t)b * p.max_out : nullptr);
+  const int dst_rows = do_topk ? N : p.max_out;
+  for (int c = wave; c < C; c += nwaves) {
+    const int s = ws_start[c];
+    if (s < 0) continue;
+    const int nk = ws_kept[c], off = ws_off[c];
+    for (int k = lane; k < nk; k += 64) {
+      const int orow = off + k;
+      if (orow >= dst_rows) continue;
+      const u32 pos = k32[2 * (s + k) + 1];
+      const u32 idx = k32[2 * pos];
+      yl_write_det(p, b, dst, dst_idx, orow, boxes[idx], scores[idx], c, (int)idx, !do_topk);
+    }
+  }
+  if (!do_topk) {
+    if (tid == 0) p.counts[b] = total;
+    return;
+  }
+  // -- fallback global top-k (tools/infer.py:377-379): sort kept rows by score desc, take topk
+  __syncthreads();
+  int P2 = 64;
+  while (P2 < total) P2 <<= 1;
+  for (int i = tid; i < P2; i += blockDim.x)
+    keys[i] = (i < total) ? (((u64)yl_desc_bits(dst[(size_t)i * 6 + 4]) << 32) | (u64)i) : ~0ull;
+  __syncthreads();
+  yl_bitonic_sort(keys, P2, tid, blockDim.x);
+  float* fin = p.dets + (size_t)b * p.max_out * 6;
+  int* fin_idx = p.keep_idx ? p.keep_idx + (size_t)b * p.max_out : nullptr;
+  for (int r = tid; r < p.topk && r < p.max_out; r += blockDim.x) {
+    const u32 i = (u32)(keys[r] & 0xFFFFFFFFull);
+    const float* srow = dst + (size_t)i * 6;
+    const float4 bx = make_float4(srow[0], srow[1], srow[2], srow[3]);
+    yl_write_det(p, b, fin, fin_idx, r, bx, srow[4], (int)srow[5], dst_idx[i], true);
+  }
+  if (tid == 0) p.counts[b] = p.topk;
+}
+
+__global__ __launch_bounds__(1024) void yl_nms_kernel(YlNmsP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char yl_smem_raw[];
+  // dynamic LDS: [lds_cap] u64 keys, then 4 ints of scratch
+  u64* lkeys = (u64*)yl_smem_raw;
+  int* s_misc = (int*)(yl_smem_raw + (size_t)p.lds_cap * 8);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* scores = p.scores + (size_t)b * p.N;
+  if (tid == 0) s_misc[0] = 0;
+  __syncthreads();
+  int local = 0;
+  for (int n = tid; n < p.N; n += blockDim.x) local += (scores[n] > p.conf_thr) ? 1 : 0;
+  for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
+  if ((tid & 63) == 0 && local) atomicAdd(&s_misc[0], local);
+  __syncthreads();
+  const int nsurv = s_misc[0];
+  if (nsurv == 0) {
+    if (tid == 0) p.counts[b] = 0;
+    return;
+  }
+  int P = 64;
+  while (P < nsurv) P <<= 1;
+  if (P <= p.lds_cap) yl_nms_run<true>(p, lkeys, P, nsurv, b, s_misc);
+  else yl_nms_run<false>(p, p.gkeys + (size_t)b * p.gP, P, nsurv, b, s_misc);
+}
+
+// ------------------------------------------------------------------------------------------------
+static int g_nms_lds_max = 0;
+
+hipError_t yl_post_init() {
+  // 128 KiB of keys + scratch: needs the opt-in above the default 64 KiB dynamic-LDS limit
+  const int want = YL_LDS_KEYS_MAX * 8 + 64;
+  hipError_t e = hipFuncSetAttribute((const void*)yl_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+  if (e != hipSuccess) return e;
+  g_nms_lds_max = want;
+  return hipSuccess;
+}
+
+hipError_t yl_launch_decode_score(const YlLevels& lv, int B, const YlDecodeP& p, hipStream_t st) {
+  dim3 grid((lv.N + 127) / 128, B), block(128);
+  const size_t lds = (size_t)2 * 64 * (lv.E | 1) * sizeof(float);
+  if (lds <= 60 * 1024)
+    hipLaunchKernelGGL(yl_decode_score_kernel<true>, grid, block, lds, st, lv, B, p);
+  else
+    hipLaunchKernelGGL(yl_decode_score_kernel<false>, grid, block, 0, st, lv, B, p);
+  return hipGetLastError();
+}
+
+hipError_t yl_launch_decode_only(const YlLevels& lv, int B, int center_mode, int wh_mode, float* box, float* obj,
+                                 float* cls, hipStream_t st) {
+  dim3 g1((lv.N + 255) / 256, B);
+  hipLaunchKernelGGL(yl_decode_box_kernel, g1, dim3(256), 0, st, lv, B, center_mode, wh_mode, (float4*)box, obj);
+  if (lv.C > 0) {
+    dim3 g2((unsigned)(((size_t)lv.N * lv.C + 255) / 256), B);
+    hipLaunchKernelGGL(yl_copy_cls_kernel, g2, dim3(256), 0, st, lv, B, cls);
+  }
+  return hipGetLastError();
+}
+
+hipError_t yl_launch_nms(const YlNmsP& p, int B, hipStream_t st) {
+  const size_t lds = (size_t)p.lds_cap * 8 + 64;
+  if ((int)lds > g_nms_lds_max && lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(yl_nms_kernel, dim3(B), dim3(1024), lds, st, p);
+  return hipGetLastError();
+}

@@ -1,0 +1,324 @@
+"""HIP-backed detector with the reference's model interface.
+
+Mirrors (same names, argument meaning and error behaviour):
+  * build_model_from_meta(meta)                       /root/reference/tools/infer.py:34-77
+  * load_model_names_imgsize_from_ckpt(weights, dev)  /root/reference/tools/infer.py:80-102
+  * model(x) -> list of [B,A,S,S,5+C]; export_concat; get_strides(); get_num_anchors_per_level()
+                                                      /root/reference/scripts/model/model_v2.py:352-383
+All device arithmetic runs in libyololite_hip.so (hand-written gfx950 kernels); torch tensors are
+used only as owners of device memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .program import Program, build_program
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class HipContext:
+    """Owns one yl_ctx.  Post-processing-only contexts are created with no layers."""
+
+    def __init__(self, img_size: int, num_classes: int, level_size: Sequence[int], level_anchors: Sequence[int],
+                 program: Optional[Program] = None, device: int = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.YoloLiteHipError("no HIP device visible (torch.cuda.is_available() is False); "
+                                        "this package has no CPU execution path")
+        self.device = torch.device("cuda", device)
+        self.img_size, self.C = int(img_size), int(num_classes)
+        self.level_size, self.level_anchors = [int(s) for s in level_size], [int(a) for a in level_anchors]
+        self.L = len(self.level_size)
+        self.N = sum(a * s * s for a, s in zip(self.level_anchors, self.level_size))
+        self.E = 5 + self.C
+        d = _lib.yl_model_desc()
+        d.abi_version, d.img_size, d.in_channels = _lib.YL_ABI_VERSION, self.img_size, 3
+        d.num_classes, d.num_levels = self.C, self.L
+        for i in range(self.L):
+            d.level_size[i], d.level_anchors[i] = self.level_size[i], self.level_anchors[i]
+        keep = []                                        # host arrays must outlive yl_create
+        if program is not None and program.layers:
+            sh = np.ascontiguousarray([s[0] for s in program.slots], np.int32)
+            sw = np.ascontiguousarray([s[1] for s in program.slots], np.int32)
+            sc = np.ascontiguousarray([s[2] for s in program.slots], np.int32)
+            keep += [sh, sw, sc]
+            d.num_slots = len(program.slots)
+            d.slot_h = sh.ctypes.data_as(_lib._ip)
+            d.slot_w = sw.ctypes.data_as(_lib._ip)
+            d.slot_c = sc.ctypes.data_as(_lib._ip)
+            arr = (_lib.yl_layer * len(program.layers))()
+
+            def fp(a):
+                if a is None:
+                    return None
+                a = np.ascontiguousarray(a, np.float32)
+                keep.append(a)
+                return a.ctypes.data_as(_lib._fp)
+
+            for i, l in enumerate(program.layers):
+                y = arr[i]
+                y.op, y.in_slot, y.out_slot, y.res_slot, y.up_slot = l.op, l.in_slot, l.out_slot, l.res_slot, l.up_slot
+                y.head_level, y.cin, y.cout = l.head_level, l.cin, l.cout
+                y.k, y.stride, y.pad_t, y.pad_l, y.act = l.k, l.stride, l.pad_t, l.pad_l, l.act
+                y.dw_k, y.dw_stride, y.dw_pad_t, y.dw_pad_l, y.dw_act = l.dw_k, l.dw_stride, l.dw_pad_t, l.dw_pad_l, l.dw_act
+                y.w, y.b, y.dw_w, y.dw_b = fp(l.w), fp(l.b), fp(l.dw_w), fp(l.dw_b)
+            d.num_layers = len(program.layers)
+            d.layers = arr
+            keep.append(arr)
+        self.num_layers = int(d.num_layers)
+        h = C.c_void_p()
+        st = self.lib.yl_create(C.byref(d), device, C.byref(h))
+        self.handle = h
+        if st != _lib.YL_OK:
+            msg = self.lib.yl_last_error(h).decode() if h else ""
+            if h:
+                self.lib.yl_destroy(h)
+            self.handle = None
+            raise _lib.YoloLiteHipError(f"yl_create: {self.lib.yl_strerror(st).decode()} ({st}) {msg}")
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                self.lib.yl_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    # ---- helpers
+    def _ptr_array(self, tensors: Sequence[torch.Tensor]):
+        arr = (C.c_void_p * self.L)()
+        for i, t in enumerate(tensors):
+            arr[i] = t.data_ptr()
+        return arr
+
+    def _check_levels(self, levels: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        if len(levels) != self.L:
+            raise ValueError(f"expected {self.L} levels, got {len(levels)}")
+        out = []
+        B = levels[0].shape[0]
+        for t, s, a in zip(levels, self.level_size, self.level_anchors):
+            if t.dim() == 4:
+                t = t.unsqueeze(1)
+            if tuple(t.shape) != (B, a, s, s, self.E):
+                raise ValueError(f"level shape {tuple(t.shape)} != {(B, a, s, s, self.E)}")
+            if t.dtype != torch.float32 or t.device != self.device:
+                t = t.to(device=self.device, dtype=torch.float32)
+            out.append(t.contiguous())
+        return out
+
+    def set_option(self, name: str, value: int):
+        _lib.check(self.lib.yl_set_option(self.handle, name.encode(), int(value)), self.handle, "yl_set_option")
+
+    # ---- forward
+    def forward(self, x: torch.Tensor, timed: bool = False):
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
+            raise ValueError(f"input must be [B,3,{self.img_size},{self.img_size}], got {tuple(x.shape)}")
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        B = x.shape[0]
+        outs = [torch.empty((B, a, s, s, self.E), device=self.device, dtype=torch.float32)
+                for s, a in zip(self.level_size, self.level_anchors)]
+        arr = self._ptr_array(outs)
+        sp = _stream_ptr(self.device)
+        if timed:
+            ms = (C.c_float * self.num_layers)()
+            _lib.check(self.lib.yl_forward_timed(self.handle, x.data_ptr(), B, arr, sp, ms), self.handle, "yl_forward_timed")
+            return outs, list(ms)
+        _lib.check(self.lib.yl_forward(self.handle, x.data_ptr(), B, arr, sp), self.handle, "yl_forward")
+        return outs
+
+    def read_slot(self, slot: int, B: int, shape) -> torch.Tensor:
+        h, w, c = shape
+        t = torch.empty((B, h, w, c), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.yl_read_slot(self.handle, slot, B, t.data_ptr(), _stream_ptr(self.device)), self.handle,
+                   "yl_read_slot")
+        return t
+
+    # ---- decode / post-processing
+    def decode(self, levels, center_mode="v8", wh_mode="softplus"):
+        lv = self._check_levels(levels)
+        B = lv[0].shape[0]
+        box = torch.empty((B, self.N, 4), device=self.device, dtype=torch.float32)
+        obj = torch.empty((B, self.N, 1), device=self.device, dtype=torch.float32)
+        cls = torch.empty((B, self.N, self.C), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.yl_decode(self.handle, self._ptr_array(lv), B, _lib.CENTER[center_mode], _lib.WH[wh_mode],
+                                      box.data_ptr(), obj.data_ptr(), cls.data_ptr() if self.C else None,
+                                      _stream_ptr(self.device)), self.handle, "yl_decode")
+        return {"box": box, "obj": obj, "cls": cls}
+
+    def make_cfg(self, mode, conf, iou, per_class_cap, topk, max_out, center_mode="v8", wh_mode="softplus",
+                 backmap: Optional[torch.Tensor] = None):
+        cfg = _lib.yl_post_cfg()
+        cfg.mode, cfg.conf_thr, cfg.iou_thr = mode, float(conf), float(iou)
+        cfg.per_class_cap, cfg.topk, cfg.max_out = int(per_class_cap or 0), int(topk or 0), int(max_out)
+        cfg.center_mode, cfg.wh_mode = _lib.CENTER[center_mode], _lib.WH[wh_mode]
+        cfg.backmap_dev = backmap.data_ptr() if backmap is not None else None
+        return cfg
+
+    def default_max_out(self, mode, per_class_cap, topk):
+        if mode == _lib.POST_FALLBACK and topk and topk > 0:
+            return min(self.N, max(int(topk), 1))
+        if per_class_cap and per_class_cap > 0:
+            return min(self.N, max(1, self.C) * int(per_class_cap))
+        return self.N
+
+    def postprocess(self, levels, mode, conf, iou, per_class_cap=300, topk=0, max_out=None, center_mode="v8",
+                    wh_mode="softplus", backmap=None, want_idx=False):
+        """Returns dets [B,max_out,6] (x1,y1,x2,y2,score,class), counts [B] (int32, device) and
+        optionally the candidate index of every detection."""
+        lv = self._check_levels(levels)
+        B = lv[0].shape[0]
+        if max_out is None:
+            max_out = self.default_max_out(mode, per_class_cap, topk)
+        if backmap is not None:
+            backmap = backmap.to(device=self.device, dtype=torch.float32).contiguous()
+        cfg = self.make_cfg(mode, conf, iou, per_class_cap, topk, max_out, center_mode, wh_mode, backmap)
+        dets = torch.empty((B, max_out, 6), device=self.device, dtype=torch.float32)
+        counts = torch.empty((B,), device=self.device, dtype=torch.int32)
+        idx = torch.empty((B, max_out), device=self.device, dtype=torch.int32) if want_idx else None
+        _lib.check(self.lib.yl_postprocess(self.handle, self._ptr_array(lv), B, C.byref(cfg), dets.data_ptr(),
+                                           counts.data_ptr(), idx.data_ptr() if want_idx else None,
+                                           _stream_ptr(self.device)), self.handle, "yl_postprocess")
+        return (dets, counts, idx) if want_idx else (dets, counts)
+
+    def predict(self, x: torch.Tensor, mode, conf, iou, per_class_cap=300, topk=0, max_out=None, backmap=None,
+                out: Optional[tuple] = None):
+        """Fused forward + post-processing on the context's own level buffers (no raw output copy)."""
+        B = x.shape[0]
+        if max_out is None:
+            max_out = self.default_max_out(mode, per_class_cap, topk)
+        if backmap is not None:
+            backmap = backmap.to(device=self.device, dtype=torch.float32).contiguous()
+        cfg = self.make_cfg(mode, conf, iou, per_class_cap, topk, max_out, backmap=backmap)
+        if out is None:
+            dets = torch.empty((B, max_out, 6), device=self.device, dtype=torch.float32)
+            counts = torch.empty((B,), device=self.device, dtype=torch.int32)
+        else:
+            dets, counts = out
+        _lib.check(self.lib.yl_predict(self.handle, x.data_ptr(), B, C.byref(cfg), dets.data_ptr(), counts.data_ptr(),
+                                       _stream_ptr(self.device)), self.handle, "yl_predict")
+        return dets, counts
+
+    def nms(self, boxes: torch.Tensor, scores: torch.Tensor, iou_thr: float, max_det: int = 300,
+            impl: int = _lib.NMS_TORCHVISION) -> torch.Tensor:
+        boxes = boxes.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1, 4)
+        scores = scores.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        n = boxes.shape[0]
+        keep = torch.empty((max(max_det, 1),), device=self.device, dtype=torch.int32)
+        cnt = torch.zeros((1,), device=self.device, dtype=torch.int32)
+        _lib.check(self.lib.yl_nms(self.handle, boxes.data_ptr(), scores.data_ptr(), n, float(iou_thr), impl,
+                                   int(max_det), keep.data_ptr(), cnt.data_ptr(), _stream_ptr(self.device)),
+                   self.handle, "yl_nms")
+        return keep[:int(cnt.item())].to(torch.int64)
+
+
+class YOLOLiteHIP:
+    """Stands where the reference's nn.Module stands (YOLOLiteMS / YOLOLiteMS_CPU): built from a
+    checkpoint's meta, weights attached with load_state_dict(), moved with .to(device), called with
+    a [B,3,S,S] float tensor, returns the list of level tensors."""
+
+    def __init__(self, meta: dict, fuse_dw: bool = True):
+        self.meta = meta
+        self.fuse_dw = fuse_dw
+        self.export_concat = False
+        self.program: Optional[Program] = None
+        self.ctx: Optional[HipContext] = None
+        self._sd = None
+        self._device_index = 0
+        # validate arch / required config keys now, like the reference constructor would
+        cfg = meta.get("config", {}) or {}
+        _ = cfg["training"]["use_p6"], cfg["training"]["use_p2"]
+        arch = (meta.get("arch") or (cfg.get("model", {}) or {}).get("arch") or "YOLOLiteMS").lower()
+        if arch not in ("yololitems", "yololitems_cpu"):
+            raise ValueError(f"Okänd arch i meta/config: {arch}")
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = False):
+        """Returns (missing_keys, unexpected_keys) like nn.Module.load_state_dict(strict=False).
+        Unlike the reference, a key the forward pass needs cannot be left at its random init:
+        missing weights raise."""
+        try:
+            self.program = build_program(self.meta, state_dict, fuse_dw=self.fuse_dw)
+        except KeyError as e:
+            raise RuntimeError(f"checkpoint lacks a weight the forward pass needs: {e.args[0]}") from None
+        self._sd = state_dict
+        unexpected = [k for k in state_dict if k not in self.program.known_keys]
+        missing: List[str] = []
+        if strict and unexpected:
+            raise RuntimeError(f"unexpected keys in state_dict: {unexpected[:8]}")
+        return missing, unexpected
+
+    def to(self, device):
+        dev = torch.device(device) if not isinstance(device, torch.device) else device
+        if dev.type != "cuda":
+            raise _lib.YoloLiteHipError("YOLOLiteHIP runs on a HIP device only (no CPU path)")
+        if self.program is None:
+            raise RuntimeError("load_state_dict() first")
+        self._device_index = dev.index or 0
+        self._ctxs = {}
+        self.ctx = self._ctx_for(self.program.img_size)
+        return self
+
+    def _ctx_for(self, img_size: int) -> HipContext:
+        """The reference module is input-size agnostic (tools/infer.py --img_size); the HIP program is
+        planned per size, so contexts are cached by input size."""
+        if img_size not in self._ctxs:
+            p = self.program if img_size == self.program.img_size else \
+                build_program(self.meta, self._sd, fuse_dw=self.fuse_dw, img_size=img_size)
+            self._ctxs[img_size] = (p, HipContext(p.img_size, p.num_classes, p.level_size, p.level_anchors, p,
+                                                  self._device_index))
+        return self._ctxs[img_size][1]
+
+    def eval(self):
+        return self
+
+    def get_strides(self):
+        return list(self.program.strides)
+
+    def get_num_anchors_per_level(self):
+        return tuple(self.program.level_anchors)
+
+    @property
+    def num_classes(self):
+        return self.program.num_classes
+
+    def __call__(self, x: torch.Tensor):
+        if self.ctx is None:
+            raise RuntimeError("model.to('cuda') first")
+        outs = self._ctx_for(int(x.shape[-1])).forward(x)
+        if self.export_concat:                      # model_v2.py:57-64
+            B = outs[0].shape[0]
+            return torch.cat([o.view(B, -1, o.shape[-1]) for o in outs], dim=1)
+        return outs
+
+    forward = __call__
+
+
+def build_model_from_meta(meta: dict, fuse_dw: bool = True) -> YOLOLiteHIP:
+    """tools/infer.py:34-77."""
+    return YOLOLiteHIP(meta, fuse_dw=fuse_dw)
+
+
+def load_model_names_imgsize_from_ckpt(weights: str, device):
+    """tools/infer.py:80-102: checkpoint {"state_dict","meta"} -> (model on device, names, img_size)."""
+    ckpt = torch.load(weights, map_location="cpu", weights_only=False)
+    if not (isinstance(ckpt, dict) and "state_dict" in ckpt and "meta" in ckpt):
+        raise RuntimeError("Checkpoint saknar 'state_dict'/'meta'. Spara vikter via save_checkpoint_state(...).")
+    meta = ckpt["meta"] or {}
+    model = build_model_from_meta(meta)
+    missing, unexpected = model.load_state_dict(ckpt["state_dict"], strict=False)
+    if missing:
+        print(f"[load_state_dict] missing keys: {len(missing)}")
+    if unexpected:
+        print(f"[load_state_dict] unexpected keys: {len(unexpected)}")
+    model.to(device).eval()
+    names = meta.get("names") or [str(i) for i in range(int(meta.get("num_classes", 80)))]
+    meta_img_size = int(meta.get("img_size", 640))
+    return model, names, meta_img_size

@@ -1,0 +1,463 @@
+"""Host-side "compiler": reference checkpoint (state_dict + meta)  ->  fused layer program for the
+HIP executor (include/yololite_hip.h: yl_layer / yl_model_desc).
+
+What it mirrors in the reference:
+  * build_model_from_meta            /root/reference/tools/infer.py:34-77   (which keys of `meta` are read)
+  * YOLOLiteMS / YOLOLiteMS_CPU      /root/reference/scripts/model/model_v2.py:77-247, 250-383
+      (FPN channel / depth arithmetic :106-107,:277-278; level order and anchors :138-152,:303-314;
+       forward order P5 -> P4 -> P3, heads P3,P4,P5(,P6) :352-377)
+  * the timm backbones behind timm.create_model(..., features_only=True) (model_v2.py:94-100,266-272),
+    given here as DATA (arch strings) -- see BACKBONES; recollection of timm's definitions, the
+    tables can be corrected without touching any kernel.
+
+What it adds (MI355X-side design, no reference counterpart): BatchNorm folding, fusion of
+depthwise -> pointwise pairs into one MFMA kernel with a depthwise prologue, residual /
+nearest-upsample-add / activation epilogues, one GEMM for the three head output convs.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------------------
+# backbone tables (timm arch-string notation):  type_r<repeat>_a<dw_start k>_k<kernel>_s<stride>_e<expand>_c<out>
+BACKBONES: Dict[str, dict] = {
+    "mobilenetv4_conv_small": dict(
+        arch=[["cn_r1_k3_s2_e1_c32", "cn_r1_k1_s1_e1_c32"],
+              ["cn_r1_k3_s2_e1_c96", "cn_r1_k1_s1_e1_c64"],
+              ["uir_r1_a5_k5_s2_e3_c96", "uir_r4_a0_k3_s1_e2_c96", "uir_r1_a3_k0_s1_e4_c96"],
+              ["uir_r1_a3_k3_s2_e6_c128", "uir_r1_a5_k5_s1_e4_c128", "uir_r1_a0_k5_s1_e4_c128",
+               "uir_r1_a0_k5_s1_e3_c128", "uir_r2_a0_k3_s1_e4_c128"],
+              ["cn_r1_k1_s1_e1_c960"]],
+        cmult=1.0, dmult=1.0, act="relu", eps=1e-5, same=False, fix_first_last=False, stem=32),
+    "tf_efficientnet_lite0": dict(
+        arch=[["ds_r1_k3_s1_e1_c16"], ["ir_r2_k3_s2_e6_c24"], ["ir_r2_k5_s2_e6_c40"], ["ir_r3_k3_s2_e6_c80"],
+              ["ir_r3_k5_s1_e6_c112"], ["ir_r4_k5_s2_e6_c192"], ["ir_r1_k3_s1_e6_c320"]],
+        cmult=1.0, dmult=1.0, act="relu6", eps=1e-3, same=True, fix_first_last=True, stem=32),
+    # tiny test vehicle (not a timm model): every block flavour at a few thousand parameters
+    "oracle_tiny": dict(
+        arch=[["cn_r1_k3_s2_e1_c8"], ["cn_r1_k3_s2_e1_c12", "cn_r1_k1_s1_e1_c8"],
+              ["uir_r1_a5_k5_s2_e3_c16", "uir_r1_a0_k3_s1_e2_c16", "uir_r1_a3_k0_s1_e4_c16"],
+              ["uir_r1_a3_k3_s2_e4_c24", "uir_r1_a0_k5_s1_e2_c24"], ["cn_r1_k1_s1_e1_c32"]],
+        cmult=1.0, dmult=1.0, act="relu", eps=1e-5, same=False, fix_first_last=False, stem=16),
+}
+BACKBONES["mobilenetv4_conv_small_050"] = dict(BACKBONES["mobilenetv4_conv_small"], cmult=0.5)
+BACKBONES["oracle_tiny_tf"] = dict(BACKBONES["oracle_tiny"], act="relu6", eps=1e-3, same=True)
+for _n, _c, _d in (("1", 1.0, 1.1), ("2", 1.1, 1.2), ("3", 1.2, 1.4), ("4", 1.4, 1.8)):
+    BACKBONES["tf_efficientnet_lite" + _n] = dict(BACKBONES["tf_efficientnet_lite0"], cmult=_c, dmult=_d)
+
+
+def _make_divisible(v, divisor=8, round_limit=0.9):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+def _parse(s: str) -> dict:
+    parts = s.split("_")
+    d = {"type": parts[0], "r": 1, "e": 1.0, "a": 0}
+    for p in parts[1:]:
+        d[p[0]] = float(p[1:]) if p[0] == "e" else int(p[1:])
+    return d
+
+
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class Layer:
+    op: int
+    in_slot: int
+    out_slot: int
+    cin: int
+    cout: int
+    k: int
+    stride: int
+    pad_t: int
+    pad_l: int
+    act: int
+    w: np.ndarray
+    b: Optional[np.ndarray]
+    res_slot: int = -1
+    up_slot: int = -1
+    head_level: int = -1
+    dw_k: int = 0
+    dw_stride: int = 1
+    dw_pad_t: int = 0
+    dw_pad_l: int = 0
+    dw_act: int = 0
+    dw_w: Optional[np.ndarray] = None
+    dw_b: Optional[np.ndarray] = None
+    name: str = ""
+    macs: int = 0               # per image
+    bytes_in: int = 0           # algorithmic HBM bytes per image (read)
+    bytes_out: int = 0          # (written)
+
+
+@dataclass
+class Program:
+    img_size: int
+    num_classes: int
+    level_size: List[int]
+    level_anchors: List[int]
+    strides: List[int]
+    slots: List[Tuple[int, int, int]] = field(default_factory=list)       # (h, w, c)
+    layers: List[Layer] = field(default_factory=list)
+    used_keys: set = field(default_factory=set)
+    known_keys: set = field(default_factory=set)
+    feature_slots: Dict[str, int] = field(default_factory=dict)           # c3/c4/c5/p3/... for tests
+
+    @property
+    def macs(self):
+        return sum(l.macs for l in self.layers)
+
+
+class SynthStateDict(dict):
+    """Seeded synthetic weights, fabricated key by key while the program is built (there are no
+    checkpoints or downloads in this environment).  Distributions follow SURVEY 8(d): kaiming-normal
+    (fan_out) convs, BatchNorm gamma~U(.5,1.5) beta~N(0,.1) mean~N(0,.1) var~U(.5,1.5), detection bias
+    init (obj=-ln 99, cls=-ln C, box=0; model_v2.py:7-14) plus N(0,head_noise) so scores straddle the
+    thresholds.  Keys and shapes equal a reference checkpoint's state_dict."""
+
+    def __init__(self, seed: int = 0, num_classes: int = 80, head_noise: float = 0.5):
+        super().__init__()
+        self.rng = np.random.RandomState(seed)
+        self.C, self.head_noise = num_classes, head_noise
+
+    def make(self, key: str, shape):
+        if key in self:
+            return
+        r = self.rng
+        if ".out." in key:
+            if key.endswith(".weight"):
+                v = r.randn(*shape) * (math.sqrt(2.0 / shape[0]) + 0.2 * self.head_noise)
+            else:
+                base = {"obj": -math.log(99.0), "cls": (-math.log(self.C) if self.C > 1 else 0.0), "box": 0.0}
+                v = base[key.split(".")[-2]] + r.randn(*shape) * self.head_noise
+        elif key.endswith("running_var"):
+            v = r.rand(*shape) + 0.5
+        elif key.endswith("running_mean") or key.endswith(".bias"):
+            v = r.randn(*shape) * 0.1
+        elif len(shape) == 1:                       # BatchNorm gamma
+            v = r.rand(*shape) + 0.5
+        else:                                       # conv weight [cout, cin/groups, k, k]
+            v = r.randn(*shape) * math.sqrt(2.0 / (shape[0] * shape[2] * shape[3] / (1 if shape[1] > 1 or shape[0] == 1 else shape[0])))
+        self[key] = np.ascontiguousarray(v, np.float32)
+
+
+def synth_state_dict(meta: dict, seed: int = 0, head_noise: float = 0.5) -> Dict[str, np.ndarray]:
+    """state_dict (numpy) for the model `meta` describes, with seeded synthetic weights."""
+    sd = SynthStateDict(seed, int(meta.get("num_classes") or 80), head_noise)
+    build_program(meta, sd)
+    return dict(sd)
+
+
+def make_meta(arch: str, backbone: str, num_classes: int = 80, img_size: int = 640, fpn_channels: int = 128,
+              depth_multiple: float = 1.0, width_multiple: float = 1.0, head_depth: int = 1, use_p6: bool = False,
+              use_p2: bool = False, anchors: int = 1, names=None) -> dict:
+    """A `meta` dict shaped like the one the reference stores in checkpoints (tools/train.py:62-75)."""
+    nl = 3 + int(use_p6) + int(use_p2)
+    return dict(metric_key="map50", metric_value=-1.0, names=names, num_classes=num_classes, img_size=img_size,
+                arch=arch, backbone=backbone, num_anchors_per_level=(anchors,) * nl,
+                config=dict(model=dict(arch=arch, backbone=backbone, num_classes=num_classes, fpn_channels=fpn_channels,
+                                       depth_multiple=depth_multiple, width_multiple=width_multiple,
+                                       head_depth=head_depth),
+                            training=dict(img_size=img_size, use_p6=use_p6, use_p2=use_p2)))
+
+
+# /root/reference/configs/models/*.yaml
+MODEL_ZOO = {
+    "edge_n": dict(arch="YOLOLiteMS_CPU", backbone="mobilenetv4_conv_small_050", depth_multiple=0.65,
+                   width_multiple=0.60, fpn_channels=160, head_depth=1),
+    "edge_s": dict(arch="YOLOLiteMS_CPU", backbone="mobilenetv4_conv_small", depth_multiple=0.90,
+                   width_multiple=0.75, fpn_channels=256, head_depth=2),
+    "edge_m": dict(arch="YOLOLiteMS_CPU", backbone="mobilenetv4_conv_small", depth_multiple=0.95,
+                   width_multiple=0.85, fpn_channels=288, head_depth=2),
+    "edge_l": dict(arch="YOLOLiteMS_CPU", backbone="mobilenetv4_conv_small", depth_multiple=1.05,
+                   width_multiple=1.00, fpn_channels=320, head_depth=3),
+    "yololite_m": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite2", depth_multiple=1.0,
+                       width_multiple=1.0, fpn_channels=328, head_depth=2),
+}
+
+
+def zoo_meta(name: str, num_classes: int = 80, img_size: int = 640, **kw) -> dict:
+    return make_meta(num_classes=num_classes, img_size=img_size, **MODEL_ZOO[name], **kw)
+
+
+_ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
+_OP_STEM, _OP_CONV, _OP_DW = 0, 1, 2
+
+
+class _Builder:
+    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw: bool):
+        self.sd, self.p, self.fuse_dw = sd, prog, fuse_dw
+
+    # ---- state-dict access
+    def get(self, key: str, shape: Tuple[int, ...]) -> np.ndarray:
+        self.p.known_keys.add(key)
+        if isinstance(self.sd, SynthStateDict):
+            self.sd.make(key, shape)
+        if key not in self.sd:
+            raise KeyError(key)
+        self.p.used_keys.add(key)
+        a = np.asarray(self.sd[key], dtype=np.float64)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{key}: checkpoint shape {tuple(a.shape)} != expected {tuple(shape)}")
+        return a
+
+    def fold(self, conv: str, bn: Optional[str], eps: float, bias: bool, wshape: Tuple[int, ...]):
+        """conv weight (+bias) with eval-mode BatchNorm folded in (float64 arithmetic, fp32 result)."""
+        w = self.get(conv + ".weight", wshape)
+        co = (wshape[0],)
+        b = self.get(conv + ".bias", co) if bias else np.zeros(w.shape[0])
+        if bn is not None:
+            g, beta = self.get(bn + ".weight", co), self.get(bn + ".bias", co)
+            mu, var = self.get(bn + ".running_mean", co), self.get(bn + ".running_var", co)
+            self.p.known_keys.add(bn + ".num_batches_tracked")
+            sc = g / np.sqrt(var + eps)
+            w = w * sc[:, None, None, None]
+            b = (b - mu) * sc + beta
+        return np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32)
+
+    # ---- tensors
+    def slot(self, h, w, c) -> int:
+        self.p.slots.append((int(h), int(w), int(c)))
+        return len(self.p.slots) - 1
+
+    def dims(self, s):
+        return self.p.slots[s]
+
+    @staticmethod
+    def geom(h, k, s, same):
+        if same and s > 1:
+            out = -(-h // s)
+            total = max((out - 1) * s + k - h, 0)
+            return out, total // 2
+        p = k // 2
+        return (h + 2 * p - k) // s + 1, p
+
+    # ---- layer emitters
+    def stem(self, conv, bn, eps, act, cout, k, s, same):
+        S = self.p.img_size
+        oh, pad = self.geom(S, k, s, same)
+        w, b = self.fold(conv, bn, eps, False, (cout, 3, k, k))
+        o = self.slot(oh, oh, cout)
+        self.p.layers.append(Layer(_OP_STEM, -1, o, 3, cout, k, s, pad, pad, _ACT[act], w, b, name=conv,
+                                   macs=oh * oh * cout * 3 * k * k, bytes_in=4 * 3 * S * S,
+                                   bytes_out=4 * oh * oh * cout))
+        return o
+
+    def conv(self, x, conv, bn, eps, act, cout, k=1, s=1, same=False, bias=False, res=-1, up=-1, head_level=-1,
+             dw=None, out_hw=None, wb=None, name=None):
+        """dense conv; dw = dict(conv=..., bn=..., eps=..., act=..., k=..., s=..., bias=False) is a depthwise
+        conv applied to x first (fused as a prologue when enabled, otherwise emitted as its own layer)."""
+        h, wd, cin = self.dims(x)
+        pro = None
+        if dw is not None:
+            dww, dwb = self.fold(dw["conv"], dw.get("bn"), dw.get("eps", 1e-5), dw.get("bias", False),
+                                 (cin, 1, dw["k"], dw["k"]))
+            doh, dpad = self.geom(h, dw["k"], dw["s"], same)
+            dow, _ = self.geom(wd, dw["k"], dw["s"], same)
+            dmacs = doh * dow * cin * dw["k"] ** 2
+            if self.fuse_dw and k == 1 and s == 1:
+                pro = dict(k=dw["k"], s=dw["s"], pad=dpad, act=_ACT[dw["act"]], w=dww,
+                           b=dwb if (dw.get("bn") or dw.get("bias")) else None, macs=dmacs)
+                oh, ow = doh, dow
+            else:
+                y = self.slot(doh, dow, cin)
+                self.p.layers.append(Layer(_OP_DW, x, y, cin, cin, dw["k"], dw["s"], dpad, dpad, _ACT[dw["act"]],
+                                           dww, dwb, name=dw["conv"], macs=dmacs, bytes_in=4 * h * wd * cin,
+                                           bytes_out=4 * doh * dow * cin))
+                x, h, wd = y, doh, dow
+        if wb is None:
+            w, b = self.fold(conv, bn, eps, bias, (cout, cin, k, k))
+        else:
+            w, b = wb
+        if pro is None:
+            oh, pad = self.geom(h, k, s, same)
+            ow, _ = self.geom(wd, k, s, same)
+        else:
+            pad = 0
+        if head_level >= 0:
+            o = -1
+        else:
+            o = self.slot(oh, ow, cout)
+        L = Layer(_OP_CONV, x, o, cin, cout, k, s, pad, pad, _ACT[act], w, b, res_slot=res, up_slot=up,
+                  head_level=head_level, name=name or conv, macs=oh * ow * cout * cin * k * k,
+                  bytes_in=4 * h * wd * cin, bytes_out=4 * oh * ow * cout)
+        if res >= 0 or up >= 0:
+            L.bytes_in += 4 * oh * ow * cout if res >= 0 else 4 * self.dims(up)[0] * self.dims(up)[1] * cout
+        if pro is not None:
+            L.dw_k, L.dw_stride, L.dw_pad_t, L.dw_pad_l, L.dw_act = pro["k"], pro["s"], pro["pad"], pro["pad"], pro["act"]
+            L.dw_w, L.dw_b = pro["w"], pro["b"]
+            L.macs += pro["macs"]
+        self.p.layers.append(L)
+        return o
+
+
+def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[int, int, int]]:
+    """Emit the feature extractor; returns [(slot, channels, reduction)] for every feature tap."""
+    if name not in BACKBONES:
+        raise ValueError(f"backbone '{name}' has no layer table (known: {sorted(BACKBONES)})")
+    spec = BACKBONES[name]
+    arch, act, eps, same = spec["arch"], spec["act"], spec["eps"], spec["same"]
+    x = b.stem(prefix + "conv_stem", prefix + "bn1", eps, act, spec["stem"], 3, 2, same)
+    cin, red = spec["stem"], 2
+    feats = []
+    if _parse(arch[0][0])["s"] > 1:
+        feats.append((x, cin, red))
+    ns = len(arch)
+    for si, stage in enumerate(arch):
+        bi = 0
+        for bstr in stage:
+            d = _parse(bstr)
+            rep = d["r"]
+            if spec["dmult"] != 1.0 and not (spec["fix_first_last"] and si in (0, ns - 1)):
+                rep = int(math.ceil(rep * spec["dmult"]))
+            cout = _make_divisible(d["c"] * spec["cmult"], 8)
+            for r in range(rep):
+                s = d["s"] if r == 0 else 1
+                pre = f"{prefix}blocks.{si}.{bi}."
+                skip = (cin == cout and s == 1)
+                if d["type"] == "cn":
+                    x = b.conv(x, pre + "conv", pre + "bn1", eps, act, cout, d["k"], s, same)
+                elif d["type"] == "uir":
+                    mid = _make_divisible(cin * d["e"], 8)
+                    dws = None
+                    if d["a"]:
+                        dws = dict(conv=pre + "dw_start.conv", bn=pre + "dw_start.bn", eps=eps, act="none",
+                                   k=d["a"], s=(s if not d["k"] else 1))
+                    y = b.conv(x, pre + "pw_exp.conv", pre + "pw_exp.bn", eps, act, mid, same=same, dw=dws)
+                    dwm = None
+                    if d["k"]:
+                        dwm = dict(conv=pre + "dw_mid.conv", bn=pre + "dw_mid.bn", eps=eps, act=act, k=d["k"], s=s)
+                    x = b.conv(y, pre + "pw_proj.conv", pre + "pw_proj.bn", eps, "none", cout, same=same, dw=dwm,
+                               res=(x if skip else -1))
+                elif d["type"] == "ds":
+                    dw = dict(conv=pre + "conv_dw", bn=pre + "bn1", eps=eps, act=act, k=d["k"], s=s)
+                    x = b.conv(x, pre + "conv_pw", pre + "bn2", eps, "none", cout, same=same, dw=dw,
+                               res=(x if skip else -1))
+                elif d["type"] == "ir":
+                    mid = _make_divisible(cin * d["e"], 8)
+                    y = b.conv(x, pre + "conv_pw", pre + "bn1", eps, act, mid, same=same)
+                    dw = dict(conv=pre + "conv_dw", bn=pre + "bn2", eps=eps, act=act, k=d["k"], s=s)
+                    x = b.conv(y, pre + "conv_pwl", pre + "bn3", eps, "none", cout, same=same, dw=dw,
+                               res=(x if skip else -1))
+                else:
+                    raise ValueError(bstr)
+                red *= s
+                cin = cout
+                bi += 1
+        nxt = _parse(arch[si + 1][0])["s"] if si + 1 < ns else 2
+        if nxt > 1:
+            feats.append((x, cin, red))
+    return feats
+
+
+def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw: bool = True,
+                  img_size: Optional[int] = None) -> Program:
+    """meta: the checkpoint's `meta` dict (tools/train.py:62-75); reads the keys
+    build_model_from_meta reads (tools/infer.py:35-50)."""
+    cfg = meta.get("config", {}) or {}
+    mcfg = cfg.get("model", {}) or {}
+    tcfg = cfg.get("training", {}) or {}
+    arch = (meta.get("arch") or mcfg.get("arch") or "YOLOLiteMS").lower()
+    backbone = (meta.get("backbone") or mcfg.get("backbone") or "resnet18")
+    C = int(meta.get("num_classes") or mcfg.get("num_classes") or 80)
+    apl = tuple(meta.get("num_anchors_per_level") or (1, 1, 1))
+    fpn = int(mcfg.get("fpn_channels", 128))
+    depth_multiple = float(mcfg.get("depth_multiple", 1.0))
+    width_multiple = float(mcfg.get("width_multiple", 1.0))
+    head_depth = int(mcfg.get("head_depth", 1))
+    use_p6 = cfg["training"]["use_p6"]                     # KeyError like the reference (tools/infer.py:49-50)
+    use_p2 = cfg["training"]["use_p2"]
+    S = int(img_size or tcfg.get("img_size", meta.get("img_size", 640)))
+    if arch not in ("yololitems", "yololitems_cpu"):
+        raise ValueError(f"Okänd arch i meta/config: {arch}")
+    cpu_arch = arch == "yololitems_cpu"
+
+    if isinstance(state_dict, SynthStateDict):
+        sd = state_dict
+    else:
+        sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
+    prog = Program(img_size=S, num_classes=C, level_size=[], level_anchors=[], strides=[])
+    b = _Builder(sd, prog, fuse_dw)
+
+    feats = _backbone(b, backbone)
+    take = 4 if use_p2 else 3
+    feats = feats[-take:]
+    F_ = int(fpn * width_multiple)
+    d = max(1, round(2 * depth_multiple))
+    pyr = (["p2"] if use_p2 else []) + ["p3", "p4", "p5"]
+    levels = pyr + (["p6"] if use_p6 else [])
+    if len(apl) >= 3:
+        a3, a4, a5 = (int(v) for v in apl[:3])
+        amap = dict(p2=a3, p3=a3, p4=a4, p5=a5, p6=a5)
+    else:
+        a = int(apl[0]) if len(apl) else 1
+        amap = dict(p2=a, p3=a, p4=a, p5=a, p6=a)
+    for n_, (slot, ch, red) in zip(pyr, feats):
+        prog.feature_slots["c" + n_[1]] = slot
+
+    def smooth(x, key):
+        """smooth block: CPU arch d x [dw3 -> pw -> BN -> ReLU] (model_v2.py:23-39); GPU arch
+        d x [conv3 -> BN -> SiLU] (model_v2.py:15-22)."""
+        for i in range(d):
+            if cpu_arch:
+                p = f"{key}.block."
+                x = b.conv(x, f"{p}{4 * i + 1}", f"{p}{4 * i + 2}", 1e-5, "relu", F_,
+                           dw=dict(conv=f"{p}{4 * i}", act="none", k=3, s=1))
+            else:
+                x = b.conv(x, f"{key}.{3 * i}", f"{key}.{3 * i + 1}", 1e-5, "silu", F_, k=3)
+        return x
+
+    # top-down pass, P5 first (model_v2.py:359-361)
+    P = {}
+    prev = None
+    for n_ in reversed(pyr):
+        k = n_[1]
+        cslot = prog.feature_slots["c" + k]
+        lat = b.conv(cslot, f"lateral{k}", None, 0.0, "none", F_, bias=True, up=(P[prev] if prev else -1))
+        P[n_] = smooth(lat, f"smooth{k}")
+        prev = n_
+    if use_p6:                                             # model_v2.py:373-375
+        x6 = b.conv(P["p5"], "p6_down", "p6_bn", 1e-5, "relu" if cpu_arch else "silu", F_, k=3, s=2)
+        P["p6"] = smooth(x6, "smooth6")
+    else:                                                  # parameters exist in every reference checkpoint
+        for i in range(d):
+            ks = ([f"smooth6.block.{4 * i}.weight", f"smooth6.block.{4 * i + 1}.weight"] +
+                  [f"smooth6.block.{4 * i + 2}.{s}" for s in ("weight", "bias", "running_mean", "running_var",
+                                                               "num_batches_tracked")]) if cpu_arch else \
+                 ([f"smooth6.{3 * i}.weight"] + [f"smooth6.{3 * i + 1}.{s}" for s in
+                                                  ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")])
+            prog.known_keys.update(ks)
+        prog.known_keys.update(["p6_down.weight"] + [f"p6_bn.{s}" for s in
+                                                    ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")])
+    for n_ in levels:
+        prog.feature_slots[n_] = P[n_]
+
+    # heads (model_v2.py:42-53,340-350): trunk, then box/obj/cls 1x1 convs fused into ONE GEMM per anchor
+    for li, n_ in enumerate(levels):
+        k = n_[1]
+        x = P[n_]
+        A = amap[n_]
+        for t in range(head_depth):
+            p = f"head{k}.trunk.{t}.block."
+            x = b.conv(x, p + "1", p + "2", 1e-5, "relu", F_, dw=dict(conv=p + "0", act="none", k=3, s=1))
+        hs = b.dims(x)[0]
+        wbox, bbox_ = b.get(f"head{k}.out.box.weight", (4 * A, F_, 1, 1)), b.get(f"head{k}.out.box.bias", (4 * A,))
+        wobj, bobj = b.get(f"head{k}.out.obj.weight", (A, F_, 1, 1)), b.get(f"head{k}.out.obj.bias", (A,))
+        wcls, bcls = b.get(f"head{k}.out.cls.weight", (A * C, F_, 1, 1)), b.get(f"head{k}.out.cls.bias", (A * C,))
+        for a in range(A):                                  # conv channels are anchor-major (view(B,A,4,S,S))
+            w = np.concatenate([wbox[4 * a:4 * a + 4], wobj[a:a + 1], wcls[C * a:C * (a + 1)]], 0)
+            bb = np.concatenate([bbox_[4 * a:4 * a + 4], bobj[a:a + 1], bcls[C * a:C * (a + 1)]], 0)
+            b.conv(x, None, None, 0.0, "none", 5 + C, head_level=li,
+                   wb=(np.ascontiguousarray(w, np.float32), np.ascontiguousarray(bb, np.float32)),
+                   name=f"head{k}.out[a={a}]")
+        prog.level_size.append(hs)
+        prog.level_anchors.append(A)
+    reds = [r for (_, _, r) in feats]
+    prog.strides = reds + ([reds[-1] * 2] if use_p6 else [])
+    return prog
