@@ -43,11 +43,13 @@ def _x(B, S, seed=1234):
     return torch.from_numpy(np.ascontiguousarray(im.transpose(0, 3, 1, 2)))
 
 
-def _cmp_levels(outs, ref, atol=2e-3):
+def _cmp_levels(outs, ref, atol=1e-4, rtol=1e-4):
+    """max |err| <= atol + rtol * max|ref| per level (fp32 drift over ~60 layers is ~1e-6 relative)."""
     for l, (o, r) in enumerate(zip(outs, ref)):
         assert tuple(o.shape) == tuple(r.shape)
         err = (o.cpu() - r).abs().max().item()
-        assert err <= atol, f"level {l}: max abs err {err}"
+        bound = atol + rtol * r.abs().max().item()
+        assert err <= bound, f"level {l}: max abs err {err} > {bound}"
 
 
 # ------------------------------------------------------------------------------------------ forward
@@ -74,7 +76,7 @@ def test_forward_tiny_models(idx, fuse):
         ref = _oracle_for(meta, sd)(x)
     m = _hip_for(meta, sd, fuse_dw=fuse)
     outs = m(x.to(DEV))
-    _cmp_levels(outs, ref, atol=5e-4)
+    _cmp_levels(outs, ref)
     assert m.get_strides() == _oracle_for(meta, sd).get_strides()
     m.export_concat = True
     cat = m(x.to(DEV))
@@ -97,8 +99,9 @@ def test_forward_reference_fixture_weights(golden_dir):
         m = _hip_for(meta, sd)
         outs = m(torch.from_numpy(z[f"{tag}/x"]).to(DEV))
         for j, o in enumerate(outs):
-            err = np.abs(o.cpu().numpy() - z[f"{tag}/out{j}"]).max()
-            assert err < 5e-4, (tag, j, err)
+            r = z[f"{tag}/out{j}"]
+            err = np.abs(o.cpu().numpy() - r).max()
+            assert err <= 1e-4 + 1e-4 * np.abs(r).max(), (tag, j, err)
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_n", 2, 640), ("edge_m", 1, 320), ("yololite_m", 1, 256)])
@@ -109,7 +112,7 @@ def test_forward_zoo_models(name, B, S):
     with torch.no_grad():
         ref = _oracle_for(meta, sd)(x)
     outs = _hip_for(meta, sd)(x.to(DEV))
-    _cmp_levels(outs, ref, atol=2e-3)
+    _cmp_levels(outs, ref)
 
 
 def test_forward_batch_invariance_and_determinism_full_size():
@@ -270,14 +273,14 @@ def test_predict_fused_equals_forward_plus_postprocess_and_graph():
     x = _x(4, 320).to(DEV)
     outs = m(x)
     ctx = m._ctx_for(320)
-    d1, c1 = ctx.postprocess(outs, _lib.POST_MAIN, 0.25, 0.5, 300)
-    d2, c2 = ctx.predict(x, _lib.POST_MAIN, 0.25, 0.5, 300)
+    d1, c1 = ctx.postprocess(outs, _lib.POST_MAIN, 0.02, 0.5, 300)
+    d2, c2 = ctx.predict(x, _lib.POST_MAIN, 0.02, 0.5, 300)
     assert torch.equal(c1, c2) and int(c1.min()) > 0
     for b in range(4):
         assert torch.equal(d1[b, :int(c1[b])], d2[b, :int(c2[b])])
     ctx.set_option("graph", 1)                      # hipGraph replay of the same launch list
     for _ in range(2):
-        d3, c3 = ctx.predict(x, _lib.POST_MAIN, 0.25, 0.5, 300)
+        d3, c3 = ctx.predict(x, _lib.POST_MAIN, 0.02, 0.5, 300)
         assert torch.equal(c1, c3)
         for b in range(4):
             assert torch.equal(d1[b, :int(c1[b])], d3[b, :int(c3[b])])

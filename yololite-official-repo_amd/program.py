@@ -117,7 +117,7 @@ class Program:
 class SynthStateDict(dict):
     """Seeded synthetic weights, fabricated key by key while the program is built (there are no
     checkpoints or downloads in this environment).  Distributions follow SURVEY 8(d): kaiming-normal
-    (fan_out) convs, BatchNorm gamma~U(.5,1.5) beta~N(0,.1) mean~N(0,.1) var~U(.5,1.5), detection bias
+    (fan_in-scaled, see make()) convs, BatchNorm gamma~U(.5,1.5) beta~N(0,.1) mean~N(0,.1) var~U(.5,1.5), detection bias
     init (obj=-ln 99, cls=-ln C, box=0; model_v2.py:7-14) plus N(0,head_noise) so scores straddle the
     thresholds.  Keys and shapes equal a reference checkpoint's state_dict."""
 
@@ -132,7 +132,7 @@ class SynthStateDict(dict):
         r = self.rng
         if ".out." in key:
             if key.endswith(".weight"):
-                v = r.randn(*shape) * (math.sqrt(2.0 / shape[0]) + 0.2 * self.head_noise)
+                v = r.randn(*shape) * (math.sqrt(1.0 / shape[1]) * (1.0 + self.head_noise))
             else:
                 base = {"obj": -math.log(99.0), "cls": (-math.log(self.C) if self.C > 1 else 0.0), "box": 0.0}
                 v = base[key.split(".")[-2]] + r.randn(*shape) * self.head_noise
@@ -143,7 +143,9 @@ class SynthStateDict(dict):
         elif len(shape) == 1:                       # BatchNorm gamma
             v = r.rand(*shape) + 0.5
         else:                                       # conv weight [cout, cin/groups, k, k]
-            v = r.randn(*shape) * math.sqrt(2.0 / (shape[0] * shape[2] * shape[3] / (1 if shape[1] > 1 or shape[0] == 1 else shape[0])))
+            # fan_in scaling (not SURVEY's fan_out): keeps activations O(1) through ~60 layers so the
+            # head logits are not saturated and fp32 tolerances stay meaningful
+            v = r.randn(*shape) * math.sqrt(1.0 / (shape[1] * shape[2] * shape[3]))
         self[key] = np.ascontiguousarray(v, np.float32)
 
 
