@@ -64,7 +64,7 @@ TINY = [
 
 
 @pytest.mark.parametrize("idx", range(len(TINY)))
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("fuse", [True, False, "auto"])
 def test_forward_tiny_models(idx, fuse):
     """every block flavour (cn k3/k1, UIB with dw_start / dw_mid / both / strided / residual, TF-SAME
     padding, ReLU/ReLU6/SiLU, dense and depthwise smooth blocks, P2/P6 levels, A=2) on a tiny net;

@@ -61,7 +61,7 @@ def test_product_never_imports_oracle():
 def test_program_edge_n_macs_and_layout():
     """edge_n C=80 640^2 = 0.7964 GMAC over 63 conv layers; fused into 42 launches."""
     meta = zoo_meta("edge_n", 80, 640)
-    p = build_program(meta, synth_state_dict(meta))
+    p = build_program(meta, synth_state_dict(meta), fuse_dw=True)
     assert abs(p.macs - 796.39e6) < 0.05e6
     assert p.level_size == [80, 40, 20] and p.level_anchors == [1, 1, 1] and p.strides == [8, 16, 32]
     assert [p.slots[p.feature_slots[k]] for k in ("c3", "c4", "c5")] == [(80, 80, 32), (40, 40, 48), (20, 20, 480)]

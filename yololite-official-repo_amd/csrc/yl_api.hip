@@ -116,12 +116,17 @@ void pack_dw(const float* w, int ch, int k, std::vector<float>& out) {
     for (int t = 0; t < k * k; ++t) out[(size_t)t * ch + c] = w[(size_t)c * k * k + t];
 }
 
-// stem [cout][cin][k][k] -> [ky][kx][c][cout]
+// stem [cout][3][3][3] -> MFMA A fragments [kstep(7)][ntile][lane]: n = ntile*16 + (lane&15),
+// k = 4*kstep + (lane>>4) with k = c*9 + ky*3 + kx (PyTorch OIHW flattening), zero for k >= 27
 void pack_stem(const float* w, int cout, int cin, int k, std::vector<float>& out) {
-  out.assign((size_t)k * k * cin * cout, 0.0f);
-  for (int n = 0; n < cout; ++n)
-    for (int c = 0; c < cin; ++c)
-      for (int t = 0; t < k * k; ++t) out[((size_t)t * cin + c) * cout + n] = w[((size_t)n * cin + c) * k * k + t];
+  const int K = cin * k * k, KS = cdiv(K, 4), NT = cdiv(cout, 16);
+  out.assign((size_t)KS * NT * 64, 0.0f);
+  for (int s = 0; s < KS; ++s)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int n = nt * 16 + (lane & 15), kk = 4 * s + (lane >> 4);
+        if (n < cout && kk < K) out[((size_t)s * NT + nt) * 64 + lane] = w[(size_t)n * K + kk];
+      }
 }
 
 void free_post_ws(yl_ctx* c) {

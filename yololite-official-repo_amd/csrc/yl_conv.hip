@@ -8,8 +8,8 @@
 //                        Optional depthwise kxk prologue computed on the fly in the B-operand path
 //                        (dw -> pw pairs of the reference's DWConvBlock / timm UIB never touch HBM
 //                        between the two convs).
-//   yl_stem_kernel       3x3 (Cin<=4) conv reading the NCHW network input, VALU with the weights as
-//                        scalar (SGPR) operands, writes NHWC.
+//   yl_stem_mfma_kernel  3x3 Cin=3 conv reading the NCHW network input (K=27 padded to 28), weights
+//                        resident in registers as MFMA A fragments, writes NHWC.
 //   yl_dw_kernel         stand-alone depthwise kxk, NHWC, float4 over channels.
 //
 // The k dimension of the MFMA is permuted: inside each block of 16 input channels lane l supplies
@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x4 yl_act4(f32x4 v, int act) {
 }
 __device__ __forceinline__ f32x4 yl_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-enum { YL_CM_PW = 0, YL_CM_KXK = 1, YL_CM_DWPRO = 2 };
+enum { YL_CM_PW = 0, YL_CM_KXK = 1, YL_CM_DWPRO = 2, YL_CM_DW3 = 3, YL_CM_DW5 = 5 };
 
 // ------------------------------------------------------------------------------------------------
 // B-operand fetch: 4 consecutive input channels [c, c+4) of the lane's pixel for tap (ky,kx).
@@ -77,18 +77,67 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
     const int x0 = px.ox * p.dw_stride - p.dw_pad_l;
     const float* xb = p.x + (size_t)px.b * p.H * p.W * p.Cin + cs;
     const float* wb = p.dw_w + cs;
-    for (int dy = 0; dy < p.dw_k; ++dy) {
-      const int iy = y0 + dy;
-      const bool yin = iy >= 0 && iy < p.H;
-      const int iyc = min(max(iy, 0), p.H - 1);
-      for (int dx = 0; dx < p.dw_k; ++dx) {
-        const int ix = x0 + dx;
-        const bool in = yin && ix >= 0 && ix < p.W;
-        const int ixc = min(max(ix, 0), p.W - 1);
-        const f32x4 v = yl_sel4(in, yl_ld4(xb + ((size_t)iyc * p.W + ixc) * p.Cin));
-        const f32x4 w = yl_ld4(wb + (dy * p.dw_k + dx) * p.Cin);
-        s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
-        s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
+    if (MODE == YL_CM_DW5) {
+      // 5x5: one row of taps (5 loads) in flight at a time keeps the register footprint small
+#pragma unroll 1
+      for (int dy = 0; dy < 5; ++dy) {
+        const int iy = y0 + dy;
+        const bool yin = iy >= 0 && iy < p.H;
+        const int iyc = min(max(iy, 0), p.H - 1);
+        f32x4 v[5];
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const int ix = x0 + dx;
+          const bool in = yin && ix >= 0 && ix < p.W;
+          const int ixc = min(max(ix, 0), p.W - 1);
+          v[dx] = yl_sel4(in, yl_ld4(xb + ((size_t)iyc * p.W + ixc) * p.Cin));
+        }
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const f32x4 w = yl_ld4(wb + (dy * 5 + dx) * p.Cin);
+          s.x = fmaf(v[dx].x, w.x, s.x); s.y = fmaf(v[dx].y, w.y, s.y);
+          s.z = fmaf(v[dx].z, w.z, s.z); s.w = fmaf(v[dx].w, w.w, s.w);
+        }
+      }
+    } else if (MODE == YL_CM_DW3) {
+      // compile-time kernel size: every tap load is issued before the first use (memory-level parallelism)
+      constexpr int DK = 3;
+      f32x4 v[DK][DK];
+#pragma unroll
+      for (int dy = 0; dy < DK; ++dy) {
+        const int iy = y0 + dy;
+        const bool yin = iy >= 0 && iy < p.H;
+        const int iyc = min(max(iy, 0), p.H - 1);
+#pragma unroll
+        for (int dx = 0; dx < DK; ++dx) {
+          const int ix = x0 + dx;
+          const bool in = yin && ix >= 0 && ix < p.W;
+          const int ixc = min(max(ix, 0), p.W - 1);
+          v[dy][dx] = yl_sel4(in, yl_ld4(xb + ((size_t)iyc * p.W + ixc) * p.Cin));
+        }
+      }
+#pragma unroll
+      for (int dy = 0; dy < DK; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < DK; ++dx) {
+          const f32x4 w = yl_ld4(wb + (dy * DK + dx) * p.Cin);
+          s.x = fmaf(v[dy][dx].x, w.x, s.x); s.y = fmaf(v[dy][dx].y, w.y, s.y);
+          s.z = fmaf(v[dy][dx].z, w.z, s.z); s.w = fmaf(v[dy][dx].w, w.w, s.w);
+        }
+    } else {
+      for (int dy = 0; dy < p.dw_k; ++dy) {
+        const int iy = y0 + dy;
+        const bool yin = iy >= 0 && iy < p.H;
+        const int iyc = min(max(iy, 0), p.H - 1);
+        for (int dx = 0; dx < p.dw_k; ++dx) {
+          const int ix = x0 + dx;
+          const bool in = yin && ix >= 0 && ix < p.W;
+          const int ixc = min(max(ix, 0), p.W - 1);
+          const f32x4 v = yl_sel4(in, yl_ld4(xb + ((size_t)iyc * p.W + ixc) * p.Cin));
+          const f32x4 w = yl_ld4(wb + (dy * p.dw_k + dx) * p.Cin);
+          s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
+          s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
+        }
       }
     }
     s = yl_act4(s, p.dw_act);
@@ -230,17 +279,27 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
       // running (tap, kblock) counters for step c0
       int tap = c0 / p.KB, kb = c0 - tap * p.KB;
       int ky = tap / p.k, kx = tap - ky * p.k;
+      constexpr bool DWM = (MODE == YL_CM_DWPRO || MODE == YL_CM_DW3 || MODE == YL_CM_DW5);
       f32x4 xq[MT];
+      if (!DWM) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_fetch<MODE>(p, px[mt], ky, kx, kb * 16 + 4 * kq);
+        for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_fetch<MODE>(p, px[mt], ky, kx, kb * 16 + 4 * kq);
+      }
       for (int t = c0; t < c1; ++t) {
-        // advance the counters and issue the next step's activation loads before this step's MFMAs
         int kb2 = kb + 1, ky2 = ky, kx2 = kx;
         if (kb2 == p.KB) { kb2 = 0; if (++kx2 == p.k) { kx2 = 0; ++ky2; } }
         if (t + 1 == c1) { kb2 = kb; ky2 = ky; kx2 = kx; }     // last step: harmless re-fetch
         f32x4 xn[MT];
+        if (DWM) {
+          // depthwise prologue: 9/25 tap loads + FMAs per step; latency is covered by the other
+          // waves of the SIMD (register budget keeps >= 3 waves resident), not by a software prefetch
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xn[mt] = yl_fetch<MODE>(p, px[mt], ky2, kx2, kb2 * 16 + 4 * kq);
+          for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_fetch<MODE>(p, px[mt], ky, kx, kb * 16 + 4 * kq);
+        } else {
+          // issue the next step's activation loads before this step's MFMAs
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) xn[mt] = yl_fetch<MODE>(p, px[mt], ky2, kx2, kb2 * 16 + 4 * kq);
+        }
         const f32x4* wrow = wl + (size_t)(t - c0) * NT * 64 + lane;
         f32x4 wq[NT];
 #pragma unroll
@@ -253,8 +312,10 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
             for (int mt = 0; mt < MT; ++mt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[nt][s], xq[mt][s], acc[mt][nt], 0, 0, 0);
         kb = kb2; ky = ky2; kx = kx2;
+        if (!DWM) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xq[mt] = xn[mt];
+          for (int mt = 0; mt < MT; ++mt) xq[mt] = xn[mt];
+        }
       }
     }
 
@@ -265,48 +326,87 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// stem: 3x3 conv, Cin = 3 (NCHW input), one output pixel per lane, all COUT channels in registers.
-// Weights [ky][kx][c][COUT] + bias [COUT] are read through the constant address space with
-// wave-uniform addresses -> s_load, used as the scalar operand of v_fmac_f32.
-template <int COUT>
-__global__ __launch_bounds__(256) void yl_stem_kernel(YlConvP p) {
-  typedef const __attribute__((address_space(4))) float cfloat;
-  cfloat* wc = (cfloat*)p.wp;
-  cfloat* bc = (cfloat*)p.bias;
-  const size_t lin = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (lin >= (size_t)p.M) return;
+// stem: 3x3 conv on the NCHW network input (Cin = 3, K = 27 padded to 28 = 7 MFMA k-steps).
+// Same transposed GEMM as above: A = weights (7*NT floats per lane, resident in registers for the whole
+// kernel), B = one input scalar per lane per k-step gathered straight from the three input planes
+// (lane = (pixel, k mod 4); k = c*9 + ky*3 + kx), D = 4 consecutive output channels per lane -> float4
+// NHWC stores.  Persistent over tiles of 4 waves x MT x 16 pixels.
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void yl_stem_mfma_kernel(YlConvP p) {
+  constexpr int KS = 7;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, pl = lane & 15;
+  float wa[KS][NT];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wa[s][nt] = p.wp[(s * NT + nt) * 64 + lane];
+  int tky[KS], tkx[KS], tc[KS];
+  bool tok[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + kq;
+    tok[s] = k < 27;
+    const int kc = tok[s] ? k : 26;
+    tc[s] = kc / 9;
+    const int r = kc - 9 * tc[s];
+    tky[s] = r / 3;
+    tkx[s] = r - 3 * tky[s];
+  }
   const int ohw = p.OH * p.OW;
-  const int b = (int)(lin / ohw);
-  const int rem = (int)(lin - (size_t)b * ohw);
-  const int oy = rem / p.OW, ox = rem - oy * p.OW;
-  float acc[COUT];
-#pragma unroll
-  for (int n = 0; n < COUT; ++n) acc[n] = bc[n];
-  const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
   const size_t plane = (size_t)p.H * p.W;
-  const float* xb = p.x + (size_t)b * 3 * plane;
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    float xv[MT][KS];
+    size_t lins[MT];
+    bool valid[MT];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = y0 + ky;
-    const bool yin = iy >= 0 && iy < p.H;
+    for (int mt = 0; mt < MT; ++mt) {
+      size_t lin = ((size_t)tile * 4 + wave) * (MT * 16) + mt * 16 + pl;
+      valid[mt] = lin < (size_t)p.M;
+      if (!valid[mt]) lin = (size_t)p.M - 1;
+      lins[mt] = lin;
+      const int b = (int)(lin / ohw);
+      const int rem = (int)(lin - (size_t)b * ohw);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
+      const float* xb = p.x + (size_t)b * 3 * plane;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = x0 + kx;
-      const bool in = yin && ix >= 0 && ix < p.W;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float v = in ? xb[c * plane + (size_t)iy * p.W + ix] : 0.0f;
-#pragma unroll
-        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(v, wc[((ky * 3 + kx) * 3 + c) * COUT + n], acc[n]);
+      for (int s = 0; s < KS; ++s) {
+        const int iy = y0 + tky[s], ix = x0 + tkx[s];
+        const bool in = tok[s] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+        const float t = xb[tc[s] * plane + (size_t)iyc * p.W + ixc];
+        xv[mt][s] = in ? t : 0.0f;
       }
     }
-  }
-  float* o = p.out + lin * COUT;
+    f32x4 acc[MT][NT];
 #pragma unroll
-  for (int n = 0; n < COUT; n += 4) {
-    f32x4 v = {yl_act1(acc[n], p.act), yl_act1(acc[n + 1], p.act), yl_act1(acc[n + 2], p.act),
-               yl_act1(acc[n + 3], p.act)};
-    *reinterpret_cast<f32x4*>(o + n) = v;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], xv[mt][s], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (!valid[mt]) continue;
+      float* orow = p.out + lins[mt] * p.N;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + 4 * kq;
+        f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
+        if (p.act == YL_ACT_SILU) v = yl_act4(v, YL_ACT_SILU);
+        v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
+        v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
+        *reinterpret_cast<f32x4*>(orow + n) = v;
+      }
+    }
   }
 }
 
@@ -357,6 +457,8 @@ static hipError_t yl_conv_attr_modes() {
   hipError_t e;
   if ((e = yl_conv_attr<NT, MT, YL_CM_PW>()) != hipSuccess) return e;
   if ((e = yl_conv_attr<NT, MT, YL_CM_KXK>()) != hipSuccess) return e;
+  if ((e = yl_conv_attr<NT, MT, YL_CM_DW3>()) != hipSuccess) return e;
+  if ((e = yl_conv_attr<NT, MT, YL_CM_DW5>()) != hipSuccess) return e;
   return yl_conv_attr<NT, MT, YL_CM_DWPRO>();
 }
 template <int MT>
@@ -379,6 +481,8 @@ template <int NT, int MT>
 static void yl_conv_go(const YlConvP& p, int mode, dim3 grid, size_t lds, hipStream_t st) {
   if (mode == YL_CM_PW) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_PW>), grid, dim3(256), lds, st, p);
   else if (mode == YL_CM_KXK) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_KXK>), grid, dim3(256), lds, st, p);
+  else if (mode == YL_CM_DW3) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DW3>), grid, dim3(256), lds, st, p);
+  else if (mode == YL_CM_DW5) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DW5>), grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DWPRO>), grid, dim3(256), lds, st, p);
 }
 template <int MT>
@@ -413,6 +517,7 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
   int MT = 2;
   const long tiles2 = ((long)p.M + 127) / 128;
   if (tile_hint == 1 || (tile_hint == 0 && tiles2 * gy < 2 * YL_NUM_CU)) MT = 1;
+  if (p.dw_k > 0) MT = 1;           // depthwise prologue: one m-tile per wave (register budget -> occupancy)
   p.ntiles = (int)(((long)p.M + 64 * MT - 1) / (64 * MT));
   // LDS weight chunk: whole K if it fits, else stream 48 KiB chunks
   const size_t step_bytes = (size_t)NT * 1024;
@@ -423,17 +528,22 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
   if (gx < 8) gx = 8;
   gx &= ~7;                         // multiple of 8: N-chunks of one M tile land on the same XCD/L2
   if (gx > p.ntiles) gx = p.ntiles;
-  const int mode = p.dw_k > 0 ? YL_CM_DWPRO : ((p.k == 1 && p.stride == 1) ? YL_CM_PW : YL_CM_KXK);
+  const int mode = p.dw_k == 3 ? YL_CM_DW3 : p.dw_k == 5 ? YL_CM_DW5 : p.dw_k > 0 ? YL_CM_DWPRO
+                   : ((p.k == 1 && p.stride == 1) ? YL_CM_PW : YL_CM_KXK);
   dim3 grid(gx, gy);
   if (MT == 2) yl_conv_go_nt<2>(p, NT, mode, grid, lds, st);
   else yl_conv_go_nt<1>(p, NT, mode, grid, lds, st);
   return hipGetLastError();
 }
 
-hipError_t yl_launch_stem(const YlConvP& p, hipStream_t st) {
-  dim3 grid((unsigned)(((size_t)p.M + 255) / 256));
-  if (p.N == 32) hipLaunchKernelGGL(yl_stem_kernel<32>, grid, dim3(256), 0, st, p);
-  else if (p.N == 16) hipLaunchKernelGGL(yl_stem_kernel<16>, grid, dim3(256), 0, st, p);
+hipError_t yl_launch_stem(const YlConvP& p0, hipStream_t st) {
+  YlConvP p = p0;
+  constexpr int MT = 4;
+  p.ntiles = (int)(((long)p.M + 64 * MT - 1) / (64 * MT));
+  int gx = 8 * YL_NUM_CU;
+  if (gx > p.ntiles) gx = p.ntiles;
+  if (p.N == 32) hipLaunchKernelGGL((yl_stem_mfma_kernel<2, MT>), dim3(gx), dim3(256), 0, st, p);
+  else if (p.N == 16) hipLaunchKernelGGL((yl_stem_mfma_kernel<1, MT>), dim3(gx), dim3(256), 0, st, p);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

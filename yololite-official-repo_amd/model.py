@@ -225,7 +225,7 @@ class YOLOLiteHIP:
     checkpoint's meta, weights attached with load_state_dict(), moved with .to(device), called with
     a [B,3,S,S] float tensor, returns the list of level tensors."""
 
-    def __init__(self, meta: dict, fuse_dw: bool = True):
+    def __init__(self, meta: dict, fuse_dw="auto"):
         self.meta = meta
         self.fuse_dw = fuse_dw
         self.export_concat = False
@@ -301,7 +301,7 @@ class YOLOLiteHIP:
     forward = __call__
 
 
-def build_model_from_meta(meta: dict, fuse_dw: bool = True) -> YOLOLiteHIP:
+def build_model_from_meta(meta: dict, fuse_dw="auto") -> YOLOLiteHIP:
     """tools/infer.py:34-77."""
     return YOLOLiteHIP(meta, fuse_dw=fuse_dw)
 

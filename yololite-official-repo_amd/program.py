@@ -193,7 +193,7 @@ _OP_STEM, _OP_CONV, _OP_DW = 0, 1, 2
 
 
 class _Builder:
-    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw: bool):
+    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw):
         self.sd, self.p, self.fuse_dw = sd, prog, fuse_dw
 
     # ---- state-dict access
@@ -263,7 +263,8 @@ class _Builder:
             doh, dpad = self.geom(h, dw["k"], dw["s"], same)
             dow, _ = self.geom(wd, dw["k"], dw["s"], same)
             dmacs = doh * dow * cin * dw["k"] ** 2
-            if self.fuse_dw and k == 1 and s == 1:
+            fuse = (dw["k"] == 3) if self.fuse_dw == "auto" else bool(self.fuse_dw)
+            if fuse and k == 1 and s == 1:
                 pro = dict(k=dw["k"], s=dw["s"], pad=dpad, act=_ACT[dw["act"]], w=dww,
                            b=dwb if (dw.get("bn") or dw.get("bias")) else None, macs=dmacs)
                 oh, ow = doh, dow
@@ -358,10 +359,12 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
     return feats
 
 
-def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw: bool = True,
+def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto",
                   img_size: Optional[int] = None) -> Program:
     """meta: the checkpoint's `meta` dict (tools/train.py:62-75); reads the keys
-    build_model_from_meta reads (tools/infer.py:35-50)."""
+    build_model_from_meta reads (tools/infer.py:35-50).
+    fuse_dw: True = every depthwise conv becomes the prologue of the following 1x1 conv, False = none,
+    "auto" = measured policy (3x3 fused; 5x5 run as their own bandwidth-bound launch)."""
     cfg = meta.get("config", {}) or {}
     mcfg = cfg.get("model", {}) or {}
     tcfg = cfg.get("training", {}) or {}
