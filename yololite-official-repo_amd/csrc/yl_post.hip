@@ -76,13 +76,42 @@ __global__ __launch_bounds__(128) void yl_decode_score_kernel(YlLevels lv, int B
   const int E = lv.E, Ep = E | 1;
   float* rows = yl_smem + wave * 64 * Ep;
   if (STAGE) {
-    for (int r = 0; r < 64; ++r) {
-      const int n = n0 + r;
-      if (n >= lv.N) break;
-      const int l = yl_level_of(lv, n);
-      const int nl = lv.A[l] * lv.S[l] * lv.S[l];
-      const float* src = lv.ptr[l] + ((size_t)b * nl + (n - lv.off[l])) * E;
-      for (int c = lane; c < E; c += 64) rows[r * Ep + c] = src[c];
+    const int l0 = yl_level_of(lv, n0);
+    const int nend = (n0 + 64 < lv.N) ? n0 + 64 : lv.N;
+    if (n0 < lv.N && nend <= lv.off[l0 + 1]) {
+      // fast path: the wave's rows are one contiguous run of (nend-n0)*E floats inside level l0.
+      // Flat coalesced copy (256 B per wave instruction, 8 loads in flight), scattered into the
+      // odd-pitch row layout; (row, col) of element lane+64*j is tracked incrementally.
+      const int nl = lv.A[l0] * lv.S[l0] * lv.S[l0];
+      const float* src = lv.ptr[l0] + ((size_t)b * nl + (n0 - lv.off[l0])) * E;
+      const int total = (nend - n0) * E;
+      const int qs = 64 / E, rs = 64 - qs * E;           // per-iteration (row, col) increments
+      int row = lane / E, col = lane - row * E;
+      for (int i0 = 0; i0 < total; i0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 64 + lane;
+          v[u] = (i < total) ? src[i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 64 + lane;
+          if (i < total) rows[row * Ep + col] = v[u];
+          row += qs; col += rs;
+          if (col >= E) { col -= E; ++row; }
+        }
+      }
+    } else {
+      // generic path (level boundary inside the wave's run): row by row
+      for (int r = 0; r < 64; ++r) {
+        const int n = n0 + r;
+        if (n >= lv.N) break;
+        const int l = yl_level_of(lv, n);
+        const int nl = lv.A[l] * lv.S[l] * lv.S[l];
+        const float* src = lv.ptr[l] + ((size_t)b * nl + (n - lv.off[l])) * E;
+        for (int c = lane; c < E; c += 64) rows[r * Ep + c] = src[c];
+      }
     }
     __syncthreads();
   }
