@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 
+#define YL_DW_LDS_MAX (32 * 1024)
+
 namespace {
 
 struct DevLayer {
@@ -384,6 +386,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       if (l.k != 1 || l.stride != 1) return fail(c, YL_ERR_UNSUPPORTED, "dw prologue needs a 1x1 stride-1 main conv");
       if (!l.dw_w) return bad("dw prologue weights are NULL");
       if (l.dw_stride < 1) return bad("bad dw_stride");
+      if ((size_t)(l.dw_k * l.dw_k + 1) * l.cin * sizeof(float) > YL_DW_LDS_MAX)
+        return fail(c, YL_ERR_UNSUPPORTED, "dw prologue: taps+bias of all input channels must fit 32 KiB of LDS");
     }
     if (l.head_level >= 0) {
       if (l.op != YL_OP_CONV || l.head_level >= c->L) return bad("bad head_level");

@@ -59,7 +59,8 @@ __device__ __forceinline__ f32x4 yl_sel4(bool keep, f32x4 v) {
 }
 
 template <int MODE>
-__device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int ky, int kx, int c) {
+__device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int ky, int kx, int c,
+                                          const float* dwl /*LDS: [taps][Cin] weights then [Cin] bias*/) {
   const bool cin_ok = c < p.Cin;
   const int cs = cin_ok ? c : (p.Cin - 4);
   if (MODE == YL_CM_PW) {
@@ -71,12 +72,13 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
     const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
     return yl_sel4(in, yl_ld4(p.x + (((size_t)px.b * p.H + iyc) * p.W + ixc) * p.Cin + cs));
   } else {  // depthwise prologue feeding a 1x1 conv: value of the dw output at (oy,ox)
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (p.dw_b) s = yl_ld4(p.dw_b + cs);
+    // depthwise taps and bias come from LDS (staged once per block): the vector-memory pipe only
+    // carries the activation taps
+    f32x4 s = yl_ld4(dwl + p.dw_k * p.dw_k * p.Cin + cs);
     const int y0 = px.oy * p.dw_stride - p.dw_pad_t;
     const int x0 = px.ox * p.dw_stride - p.dw_pad_l;
     const float* xb = p.x + (size_t)px.b * p.H * p.W * p.Cin + cs;
-    const float* wb = p.dw_w + cs;
+    const float* wb = dwl + cs;
     if (MODE == YL_CM_DW5) {
       // 5x5: one row of taps (5 loads) in flight at a time keeps the register footprint small
 #pragma unroll 1
@@ -244,10 +246,16 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
       }
     }
   };
-  if (single) {
-    load_chunk(0, TK);
-    __syncthreads();
+  constexpr bool DWM = (MODE == YL_CM_DWPRO || MODE == YL_CM_DW3 || MODE == YL_CM_DW5);
+  // LDS carve: [CH*NT*64 float4 weight chunk][dw taps*Cin + Cin floats]
+  float* dwl = yl_wlds + (size_t)CH * NT * 256;
+  if (DWM) {
+    const int nw = p.dw_k * p.dw_k * p.Cin;
+    for (int i = tid; i < nw; i += 256) dwl[i] = p.dw_w[i];
+    for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = p.dw_b ? p.dw_b[i] : 0.0f;
   }
+  if (single) load_chunk(0, TK);
+  bool need_sync = single || DWM;     // first LDS read happens after the first activation loads are in flight
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     YlPix px[MT];
@@ -279,11 +287,14 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
       // running (tap, kblock) counters for step c0
       int tap = c0 / p.KB, kb = c0 - tap * p.KB;
       int ky = tap / p.k, kx = tap - ky * p.k;
-      constexpr bool DWM = (MODE == YL_CM_DWPRO || MODE == YL_CM_DW3 || MODE == YL_CM_DW5);
       f32x4 xq[MT];
       if (!DWM) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_fetch<MODE>(p, px[mt], ky, kx, kb * 16 + 4 * kq);
+        for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_fetch<MODE>(p, px[mt], ky, kx, kb * 16 + 4 * kq, dwl);
+      }
+      if (need_sync) {
+        __syncthreads();
+        need_sync = false;
       }
       for (int t = c0; t < c1; ++t) {
         int kb2 = kb + 1, ky2 = ky, kx2 = kx;
@@ -294,11 +305,11 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
           // depthwise prologue: 9/25 tap loads + FMAs per step; latency is covered by the other
           // waves of the SIMD (register budget keeps >= 3 waves resident), not by a software prefetch
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_fetch<MODE>(p, px[mt], ky, kx, kb * 16 + 4 * kq);
+          for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_fetch<MODE>(p, px[mt], ky, kx, kb * 16 + 4 * kq, dwl);
         } else {
           // issue the next step's activation loads before this step's MFMAs
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) xn[mt] = yl_fetch<MODE>(p, px[mt], ky2, kx2, kb2 * 16 + 4 * kq);
+          for (int mt = 0; mt < MT; ++mt) xn[mt] = yl_fetch<MODE>(p, px[mt], ky2, kx2, kb2 * 16 + 4 * kq, dwl);
         }
         const f32x4* wrow = wl + (size_t)(t - c0) * NT * 64 + lane;
         f32x4 wq[NT];
@@ -521,9 +532,10 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
   p.ntiles = (int)(((long)p.M + 64 * MT - 1) / (64 * MT));
   // LDS weight chunk: whole K if it fits, else stream 48 KiB chunks
   const size_t step_bytes = (size_t)NT * 1024;
-  if ((size_t)p.TK * step_bytes <= YL_CONV_LDS_MAX) p.CH = p.TK;
+  const size_t dw_bytes = p.dw_k > 0 ? (size_t)(p.dw_k * p.dw_k + 1) * p.Cin * sizeof(float) : 0;
+  if ((size_t)p.TK * step_bytes + dw_bytes <= YL_CONV_LDS_MAX) p.CH = p.TK;
   else p.CH = (int)((48 * 1024) / step_bytes);
-  const size_t lds = (size_t)p.CH * step_bytes;
+  const size_t lds = (size_t)p.CH * step_bytes + dw_bytes;
   int gx = (4 * YL_NUM_CU) / gy;
   if (gx < 8) gx = 8;
   gx &= ~7;                         // multiple of 8: N-chunks of one M tile land on the same XCD/L2

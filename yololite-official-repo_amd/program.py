@@ -190,6 +190,7 @@ def zoo_meta(name: str, num_classes: int = 80, img_size: int = 640, **kw) -> dic
 
 _ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
 _OP_STEM, _OP_CONV, _OP_DW = 0, 1, 2
+DW_PROLOGUE_LDS_MAX = 32 * 1024      # bytes; mirrors YL_DW_LDS_MAX in csrc/yl_api.hip
 
 
 class _Builder:
@@ -264,6 +265,8 @@ class _Builder:
             dow, _ = self.geom(wd, dw["k"], dw["s"], same)
             dmacs = doh * dow * cin * dw["k"] ** 2
             fuse = (dw["k"] == 3) if self.fuse_dw == "auto" else bool(self.fuse_dw)
+            # the prologue keeps the depthwise taps + bias of all Cin channels in LDS (yl_conv.hip)
+            fuse = fuse and (dw["k"] ** 2 + 1) * cin * 4 <= DW_PROLOGUE_LDS_MAX
             if fuse and k == 1 and s == 1:
                 pro = dict(k=dw["k"], s=dw["s"], pad=dpad, act=_ACT[dw["act"]], w=dww,
                            b=dwb if (dw.get("bn") or dw.get("bias")) else None, macs=dmacs)
