@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="replay the forward from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-dw", default="auto", help="auto | 1 | 0: fuse depthwise convs into the following 1x1 conv")
+    ap.add_argument("--fuse-stem", type=int, default=1, help="fused stem+blocks.0 entry kernel")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
     args = ap.parse_args()
 
@@ -94,7 +95,8 @@ def main():
     B, S = args.batch, args.img
     meta = zoo_meta(args.model, 80, S)
     sd = synth_state_dict(meta, seed=0, head_noise=2.0)
-    model = ya.build_model_from_meta(meta, fuse_dw=("auto" if args.fuse_dw == "auto" else bool(int(args.fuse_dw))))
+    model = ya.build_model_from_meta(meta, fuse_dw=("auto" if args.fuse_dw == "auto" else bool(int(args.fuse_dw))),
+                                     fuse_stem=bool(args.fuse_stem))
     model.load_state_dict(sd)
     model.to(dev)
     ctx, prog = model._ctx_for(S), model.program

@@ -51,7 +51,10 @@ enum {
   YL_OP_STEM = 0,  /* dense kxk conv reading the NCHW fp32 network input (Cin<=4), writes NHWC   */
   YL_OP_CONV = 1,  /* dense kxk conv (groups=1) on NHWC, optional depthwise prologue, fused
                       bias/act/residual/nearest-upsample-add epilogue, optional head-layout store  */
-  YL_OP_DW = 2     /* stand-alone depthwise kxk conv on NHWC with bias/act                         */
+  YL_OP_DW = 2,    /* stand-alone depthwise kxk conv on NHWC with bias/act                         */
+  YL_OP_STEMBLOCK = 3 /* fused network entry: stem 3x3 s2 (w,b,act) -> dense 3x3 s2 pad 1 (w2,b2,act2, cout c2)
+                         -> optional 1x1 (w3,b3,act3, cout c3), NCHW input to NHWC output; the stem's
+                         full-resolution activation (the largest tensor of the network) never reaches HBM  */
 };
 
 /*
@@ -77,6 +80,13 @@ typedef struct {
   const float* b;             /* [cout] or NULL                                                   */
   const float* dw_w;          /* [cin][1][dw_k][dw_k] or NULL                                     */
   const float* dw_b;          /* [cin] or NULL                                                    */
+  /* YL_OP_STEMBLOCK only (0 / NULL otherwise): second and optional third conv of the fused entry block */
+  int32_t c2, act2;           /* 3x3 stride-2 pad-1 conv: [c2][cout][3][3]                        */
+  int32_t c3, act3;           /* 1x1 conv: [c3][c2][1][1]; c3 = 0 -> absent                       */
+  const float* w2;
+  const float* b2;
+  const float* w3;
+  const float* b3;
 } yl_layer;
 
 /*

@@ -29,8 +29,8 @@ def _oracle_for(meta, sd):
     return m
 
 
-def _hip_for(meta, sd, fuse_dw=True):
-    m = ya.build_model_from_meta(meta, fuse_dw=fuse_dw)
+def _hip_for(meta, sd, fuse_dw="auto", fuse_stem=True):
+    m = ya.build_model_from_meta(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem)
     m.load_state_dict(sd)
     return m.to(DEV)
 
@@ -74,7 +74,7 @@ def test_forward_tiny_models(idx, fuse):
     x = _x(3, 96, seed=idx)
     with torch.no_grad():
         ref = _oracle_for(meta, sd)(x)
-    m = _hip_for(meta, sd, fuse_dw=fuse)
+    m = _hip_for(meta, sd, fuse_dw=fuse, fuse_stem=(fuse != False))
     outs = m(x.to(DEV))
     _cmp_levels(outs, ref)
     assert m.get_strides() == _oracle_for(meta, sd).get_strides()

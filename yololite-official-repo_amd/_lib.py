@@ -13,7 +13,7 @@ YL_ABI_VERSION = 1
 YL_MAX_LEVELS = 8
 YL_OK = 0
 ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
-OP_STEM, OP_CONV, OP_DW = 0, 1, 2
+OP_STEM, OP_CONV, OP_DW, OP_STEMBLOCK = 0, 1, 2, 3
 POST_MAIN, POST_FALLBACK, POST_EVAL = 0, 1, 2
 CENTER = {"v8": 0, "simple": 1}
 WH = {"softplus": 0, "v8": 1, "exp": 2}
@@ -27,7 +27,9 @@ class yl_layer(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "op", "in_slot", "out_slot", "res_slot", "up_slot", "head_level", "cin", "cout",
         "k", "stride", "pad_t", "pad_l", "act", "dw_k", "dw_stride", "dw_pad_t", "dw_pad_l", "dw_act")] + [
-        ("w", _fp), ("b", _fp), ("dw_w", _fp), ("dw_b", _fp)]
+        ("w", _fp), ("b", _fp), ("dw_w", _fp), ("dw_b", _fp),
+        ("c2", C.c_int32), ("act2", C.c_int32), ("c3", C.c_int32), ("act3", C.c_int32),
+        ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp)]
 
 
 class yl_model_desc(C.Structure):

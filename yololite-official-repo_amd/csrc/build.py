@@ -16,10 +16,11 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-re
 UNITS = [
     ("yl_api.hip", []),
     ("yl_conv.hip", []),
+    ("yl_stemblock.hip", []),
     # reference-exact fp32 arithmetic in decode/NMS: no fused multiply-add contraction
     ("yl_post.hip", ["-ffp-contract=off"]),
 ]
-DEPS = ["yl_internal.h", os.path.join("..", "..", "include", "yololite_hip.h")]
+DEPS = ["yl_internal.h", "yl_dev.h", os.path.join("..", "..", "include", "yololite_hip.h")]
 
 
 def _hipcc():
@@ -52,7 +53,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src, _ in UNITS]
     if force or jobs or _stale(OUT, objs):

@@ -19,6 +19,10 @@ struct DevLayer {
   float* bias = nullptr; // padded bias (device)
   float* dw_w = nullptr; // [taps][Cin] (device)
   float* dw_b = nullptr;
+  float* w2p = nullptr;  // stem block: packed second / third conv
+  float* b2 = nullptr;
+  float* w3p = nullptr;
+  float* b3 = nullptr;
   int in_h = 0, in_w = 0, out_h = 0, out_w = 0;
   int head_anchor = -1;  // head layers: anchor index handled by this layer
 };
@@ -211,7 +215,15 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int B, const float* x, flo
   p.TK = d.k * d.k * p.KB;
   p.NTtot = cdiv(d.cout, 16);
   p.M = B * L.out_h * L.out_w;
-  p.x = (d.op == YL_OP_STEM) ? x : c->slots[d.in_slot].ptr;
+  p.x = (d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? x : c->slots[d.in_slot].ptr;
+  if (d.op == YL_OP_STEMBLOCK) {
+    p.w2p = L.w2p; p.b2 = L.b2; p.w3p = L.w3p; p.b3 = L.b3;
+    p.C1 = d.cout; p.C2 = d.c2; p.C3 = d.c3; p.act2 = d.act2; p.act3 = d.act3;
+    p.SH = p.SW = (L.in_h + d.pad_t + (d.k - 1 - d.pad_t) - d.k) / d.stride + 1;
+    p.tiles_x = cdiv(L.out_w, 8); p.tiles_y = cdiv(L.out_h, 8);
+    p.ntiles = B * p.tiles_x * p.tiles_y;
+    p.N = d.c3 > 0 ? d.c3 : d.c2;
+  }
   if (d.res_slot >= 0) p.res = c->slots[d.res_slot].ptr;
   if (d.up_slot >= 0) {
     p.up = c->slots[d.up_slot].ptr;
@@ -238,6 +250,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int B, float* const* level_out, 
     switch (c->layers[i].d.op) {
       case YL_OP_STEM: e = yl_launch_stem(p, st); break;
       case YL_OP_CONV: e = yl_launch_conv(p, c->opt_tile_m, st); break;
+      case YL_OP_STEMBLOCK: e = yl_launch_stemblock(p, st); break;
       default: e = yl_launch_dw(p, st); break;
     }
     if (e != hipSuccess) {
@@ -316,7 +329,10 @@ void yl_destroy(yl_ctx* c) {
   free_post_ws(c);
   hipFree(c->ws_nms_clsws);
   hipFree(c->ws_nms_gkeys);
-  for (auto& L : c->layers) { hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b); }
+  for (auto& L : c->layers) {
+    hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b);
+    hipFree(L.w2p); hipFree(L.b2); hipFree(L.w3p); hipFree(L.b3);
+  }
   delete c;
 }
 
@@ -330,7 +346,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return YL_ERR_HIP;
   if (hipSetDevice(device_id) != hipSuccess) return YL_ERR_HIP;
   if (!g_inited) {
-    if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess) return YL_ERR_HIP;
+    if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess || yl_stemblock_init() != hipSuccess)
+      return YL_ERR_HIP;
     g_inited = true;
   }
   yl_ctx* c = new (std::nothrow) yl_ctx();
@@ -368,10 +385,16 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       snprintf(msg, sizeof(msg), "layer %d: %s", i, what);
       return fail(c, YL_ERR_INVALID, msg);
     };
-    if (l.op < YL_OP_STEM || l.op > YL_OP_DW) return bad("unknown op");
+    if (l.op < YL_OP_STEM || l.op > YL_OP_STEMBLOCK) return bad("unknown op");
     if (!l.w) return bad("weights are NULL");
     if (l.k < 1 || l.stride < 1) return bad("bad kernel geometry");
-    if (l.op == YL_OP_STEM) {
+    if (l.op == YL_OP_STEMBLOCK) {
+      L.in_h = L.in_w = d->img_size;
+      if (l.cin != 3 || l.k != 3) return fail(c, YL_ERR_UNSUPPORTED, "stem must be 3x3 with 3 input channels");
+      if (!l.w2 || l.c2 < 1 || l.c3 < 0 || (l.c3 > 0 && !l.w3)) return bad("stem block needs w2 (and w3 when c3 > 0)");
+      if (!yl_stemblock_supported(l.cout, l.c2, l.c3))
+        return fail(c, YL_ERR_UNSUPPORTED, "stem block: c1 in {16,32}, c2,c3 <= 32 and multiples of 4");
+    } else if (l.op == YL_OP_STEM) {
       L.in_h = L.in_w = d->img_size;
       if (l.cin != 3 || l.k != 3) return fail(c, YL_ERR_UNSUPPORTED, "stem must be 3x3 with 3 input channels");
       if (l.cout != 16 && l.cout != 32) return fail(c, YL_ERR_UNSUPPORTED, "stem cout must be 16 or 32");
@@ -399,9 +422,13 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     } else {
       if (l.out_slot < 0 || l.out_slot >= d->num_slots) return bad("bad out_slot");
       L.out_h = c->slots[l.out_slot].h; L.out_w = c->slots[l.out_slot].w;
-      if (c->slots[l.out_slot].c != l.cout) return bad("cout does not match the output slot");
+      const int oc = (l.op == YL_OP_STEMBLOCK) ? (l.c3 > 0 ? l.c3 : l.c2) : l.cout;
+      if (c->slots[l.out_slot].c != oc) return bad("cout does not match the output slot");
     }
-    {
+    if (l.op == YL_OP_STEMBLOCK) {
+      const int sh = (L.in_h + 2 * 0 + l.pad_t + (l.k - 1 - l.pad_t) - l.k) / l.stride + 1;   // symmetric / SAME stem
+      if (L.out_h != (sh + 2 - 3) / 2 + 1 || L.out_w != L.out_h) return bad("stem block output size mismatch");
+    } else {
       const bool pro = (l.op == YL_OP_CONV && l.dw_k > 0);
       const int st = pro ? l.dw_stride : l.stride, pt = pro ? l.dw_pad_t : l.pad_t, pl = pro ? l.dw_pad_l : l.pad_l;
       const int kk = pro ? l.dw_k : l.k;
@@ -420,17 +447,32 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       if (c->slots[l.up_slot].c != l.cout) return bad("upsample source channel mismatch");
     }
     if (l.op == YL_OP_DW && l.cin != l.cout) return bad("depthwise needs cin == cout");
-    if (l.op != YL_OP_STEM && (l.cin & 3)) return fail(c, YL_ERR_UNSUPPORTED, "cin must be a multiple of 4");
+    if (l.op != YL_OP_STEM && l.op != YL_OP_STEMBLOCK && (l.cin & 3)) return fail(c, YL_ERR_UNSUPPORTED, "cin must be a multiple of 4");
     if ((l.res_slot >= 0 || l.up_slot >= 0 || l.act == YL_ACT_SILU) && (l.cout & 3) && l.op == YL_OP_CONV)
       return fail(c, YL_ERR_UNSUPPORTED, "residual/upsample/SiLU epilogue needs cout % 4 == 0");
 
     // ---- pack + upload
     std::vector<float> wp, bias;
     yl_status s;
-    if (l.op == YL_OP_STEM) {
+    if (l.op == YL_OP_STEM || l.op == YL_OP_STEMBLOCK) {
       pack_stem(l.w, l.cout, l.cin, l.k, wp);
       bias.assign(l.cout, 0.0f);
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
+      if (l.op == YL_OP_STEMBLOCK) {
+        std::vector<float> w2, b2v((size_t)cdiv(l.c2, 16) * 16, 0.0f);
+        pack_conv(l.w2, l.c2, l.cout, 3, w2);
+        if (l.b2) memcpy(b2v.data(), l.b2, l.c2 * sizeof(float));
+        if ((s = upload(c, w2, &L.w2p)) != YL_OK) return s;
+        if ((s = upload(c, b2v, &L.b2)) != YL_OK) return s;
+        if (l.c3 > 0) {
+          // the 1x1 conv's k-blocks are the second conv's 16-wide n-tiles: pack with cin padded to that
+          std::vector<float> w3, b3v((size_t)cdiv(l.c3, 16) * 16, 0.0f);
+          pack_conv(l.w3, l.c3, l.c2, 1, w3);
+          if (l.b3) memcpy(b3v.data(), l.b3, l.c3 * sizeof(float));
+          if ((s = upload(c, w3, &L.w3p)) != YL_OK) return s;
+          if ((s = upload(c, b3v, &L.b3)) != YL_OK) return s;
+        }
+      }
     } else if (l.op == YL_OP_CONV) {
       pack_conv(l.w, l.cout, l.cin, l.k, wp);
       bias.assign((size_t)cdiv(l.cout, 16) * 16 + 128, 0.0f);
@@ -451,6 +493,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     if ((s = upload(c, wp, &L.wp)) != YL_OK) return s;
     if ((s = upload(c, bias, &L.bias)) != YL_OK) return s;
     L.d.w = L.d.b = L.d.dw_w = L.d.dw_b = nullptr;
+    L.d.w2 = L.d.b2 = L.d.w3 = L.d.b3 = nullptr;
     c->layers.push_back(L);
   }
   for (int l = 0; l < c->L; ++l)

@@ -72,6 +72,14 @@ struct YlConvP {
   long out_bstride;      // floats between images in `out` (OH*OW*N, or A*OH*OW*E for a head level)
   int M;                 // B*OH*OW
   int ntiles;            // M tiles
+  // fused stem block (yl_stemblock_kernel): stem -> 3x3 s2 -> optional 1x1
+  const float* w2p;      // packed [9][C1/16][ceil(C2/16)][64][4]
+  const float* b2;       // padded
+  const float* w3p;      // packed [ceil(C2/16)][ceil(C3/16)][64][4] or nullptr
+  const float* b3;
+  int C1, C2, C3, act2, act3;
+  int SH, SW;            // stem output grid
+  int tiles_x, tiles_y;  // 8x8 output tiles per image
 };
 
 // launchers implemented in the .hip files
@@ -84,4 +92,7 @@ hipError_t yl_post_init();   // one-time function attributes (large dynamic LDS)
 hipError_t yl_launch_stem(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv(const YlConvP& p, int tile_hint, hipStream_t st);
 hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_stemblock(const YlConvP& p, hipStream_t st);
+hipError_t yl_stemblock_init();
+bool yl_stemblock_supported(int c1, int c2, int c3);
 hipError_t yl_conv_init();

@@ -1,0 +1,253 @@
+// Fused network entry block for gfx950:  stem 3x3 s2 (3 -> C1)  ->  3x3 s2 pad 1 (C1 -> C2)  ->  optional 1x1
+// (C2 -> C3), NCHW fp32 input to NHWC fp32 output.
+//
+// Why: the stem's output (S/2 x S/2 x C1, 13.1 MB per 640x640 image for C1 = 32) is the largest tensor of
+// the network; written and re-read it costs 26 MB/image of HBM traffic, more than the rest of edge_n's
+// layer-fused traffic together.  Here it lives only in LDS: one WAVE produces a 2x8 tile of the second
+// conv's output from a 5x17 patch of stem pixels kept in its private LDS region.
+//
+// Phase 1  stem on the 5x17 patch: transposed MFMA GEMM (A = stem weights in registers, 7 k-steps,
+//          B = one input scalar per lane gathered from the NCHW planes), result (+bias, act; zero outside
+//          the image = the second conv's zero padding) -> LDS patch [96][C1+4].
+// Phase 2  3x3 s2 conv from LDS: one 16-pixel m-tile per wave, B operand = float4 of 4 channels read
+//          from the patch, A operand = packed weights in LDS (one ds_read_b128 per 16x16x16 step).
+// Phase 3  optional 1x1 conv chained in registers: the MFMA D layout (lane = pixel, 4 consecutive
+//          channels) IS the B-operand layout of the next GEMM's k-block, so no data movement at all.
+//
+// Replaces timm conv_stem+bn1 and blocks.0.{0,1} (ConvBnAct) of mobilenetv4_conv_small*, i.e. the
+// first three conv/BN/ReLU triples behind model_v2.py:94-100,266-272.
+#include "yl_internal.h"
+#include "yl_dev.h"
+
+#define SB_TR 2                     // wave tile: 2 rows x 8 columns of the second conv's output grid
+#define SB_TC 8
+#define SB_PR (2 * SB_TR + 1)       // stem patch: 5 rows x 17 columns
+#define SB_PC (2 * SB_TC + 1)
+#define SB_NPATCH (SB_PR * SB_PC)   // 85 stem pixels
+#define SB_MT1 ((SB_NPATCH + 15) / 16)   // 6 m-tiles
+
+// Every WAVE owns its tiles end to end (private LDS patch, no workgroup barrier in the loop): waves
+// drift apart and cover each other's gather latency / MFMA dependency stalls.
+template <int NT1 /*C1/16*/, int NT2 /*ceil(C2/16)*/, int NT3 /*ceil(C3/16), 0 = no 1x1*/>
+__global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
+  constexpr int C1 = NT1 * 16, P1 = C1 + 4, KS = 7, KB1 = NT1;
+  constexpr int PATCH_F = SB_MT1 * 16 * P1;                          // floats per wave patch (96 rows)
+  extern __shared__ __attribute__((aligned(16))) float sb_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, pl = lane & 15;
+  float* patch = sb_lds + wave * PATCH_F;                            // [96][P1], wave private
+  f32x4* w2l = reinterpret_cast<f32x4*>(sb_lds + 4 * PATCH_F);
+  f32x4* w3l = w2l + 9 * KB1 * NT2 * 64;
+
+  // ---- once per block: stem A fragments -> registers, conv2 / conv3 weights -> LDS
+  float wa[KS][NT1];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) wa[s][nt] = p.wp[(s * NT1 + nt) * 64 + lane];
+  {
+    const f32x4* g2 = reinterpret_cast<const f32x4*>(p.w2p);
+    for (int i = tid; i < 9 * KB1 * NT2 * 64; i += 256) w2l[i] = g2[i];
+    if (NT3 > 0) {
+      const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
+      for (int i = tid; i < NT2 * NT3 * 64; i += 256) w3l[i] = g3[i];
+    }
+  }
+  __syncthreads();
+
+  const size_t plane = (size_t)p.H * p.W;
+  // per-lane constants: tap decode of the lane's k slots and patch-pixel coordinates of its m-tile rows
+  int tky[KS], tkx[KS], tc[KS], gs[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + kq;
+    const int kc = k < 27 ? k : 26;                                  // k = 27 is the zero-weight pad slot
+    tc[s] = kc / 9;
+    const int r = kc - 9 * tc[s];
+    tky[s] = r / 3;
+    tkx[s] = r - 3 * tky[s];
+    gs[s] = tc[s] * (int)plane + tky[s] * p.W + tkx[s];
+  }
+  int ppi[SB_MT1], ppj[SB_MT1], gm[SB_MT1];
+#pragma unroll
+  for (int m = 0; m < SB_MT1; ++m) {
+    const int q = m * 16 + pl;
+    const int qq = q < SB_NPATCH ? q : SB_NPATCH - 1;
+    ppi[m] = qq / SB_PC;
+    ppj[m] = qq - ppi[m] * SB_PC;
+    gm[m] = (ppi[m] * p.stride) * p.W + ppj[m] * p.stride;
+  }
+  f32x4 bias1[NT1], bias2[NT2];
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) bias1[nt] = yl_ld4(p.bias + nt * 16 + 4 * kq);
+#pragma unroll
+  for (int nt = 0; nt < NT2; ++nt) bias2[nt] = yl_ld4(p.b2 + nt * 16 + 4 * kq);
+  const int lq = pl * P1 + 4 * kq;                                   // lane part of the patch write offset
+  const int ty = pl >> 3, tx = pl & 7;                               // lane's pixel inside the 2x8 tile
+  const int lr = ((2 * ty) * SB_PC + 2 * tx) * P1 + 4 * kq;          // lane part of the patch read offset
+  const int Nout = (NT3 > 0) ? p.C3 : p.C2;
+  const int tpr = (p.OW + SB_TC - 1) / SB_TC, tpc = (p.OH + SB_TR - 1) / SB_TR;
+  const int tiles_img = tpr * tpc;
+  const int ntiles = p.B * tiles_img;
+  const int wstride = gridDim.x * 4;
+
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tpr, txi = trem - tyi * tpr;
+    const int oy0 = tyi * SB_TR, ox0 = txi * SB_TC;                  // tile origin on the conv2 output grid
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;                  // patch origin on the stem grid
+    const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;   // input coords of patch(0,0) tap(0,0)
+    const float* xb = p.x + (size_t)b * 3 * plane;
+    // interior tiles (the common case) need no bounds logic at all: wave-uniform branch
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW && iy0 >= 0 && ix0 >= 0 &&
+                          iy0 + (SB_PR - 1) * p.stride + 3 <= p.H && ix0 + (SB_PC - 1) * p.stride + 3 <= p.W;
+    float xv[SB_MT1][KS];
+    if (interior) {
+      const float* xo = xb + (size_t)iy0 * p.W + ix0;
+#pragma unroll
+      for (int m = 0; m < SB_MT1; ++m)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xv[m][s] = xo[gm[m] + gs[s]];
+    } else {
+#pragma unroll
+      for (int m = 0; m < SB_MT1; ++m)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int iy = iy0 + ppi[m] * p.stride + tky[s], ix = ix0 + ppj[m] * p.stride + tkx[s];
+          const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+          const float t = xb[tc[s] * plane + (size_t)iyc * p.W + ixc];
+          xv[m][s] = in ? t : 0.0f;
+        }
+    }
+    // ---- phase 1: stem on the patch -> wave-private LDS
+#pragma unroll
+    for (int m = 0; m < SB_MT1; ++m) {
+      f32x4 a1[NT1];
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) a1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], xv[m][s], a1[nt], 0, 0, 0);
+      bool inside = true;
+      if (!interior) {
+        const int sy = sy0 + ppi[m], sx = sx0 + ppj[m];
+        inside = sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;       // else: zero padding of the second conv
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) {
+        f32x4 v = yl_act4(a1[nt] + bias1[nt], p.act);
+        if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(patch + m * 16 * P1 + lq + nt * 16) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // LDS writes of other lanes -> reads below
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 2: 3x3 stride-2 conv on the wave's 2x8 tile
+    f32x4 a2[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) a2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+          const f32x4 xq = *reinterpret_cast<const f32x4*>(patch + lr + (ky * SB_PC + kx) * P1 + kb * 16);
+          const f32x4* wrow = w2l + (((ky * 3 + kx) * KB1 + kb) * NT2) * 64 + lane;
+#pragma unroll
+          for (int nt = 0; nt < NT2; ++nt) {
+            const f32x4 wq = wrow[nt * 64];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s], xq[s], a2[nt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) a2[nt] = yl_act4(a2[nt] + bias2[nt], p.act2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // patch reads done before the next tile's writes
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 3: optional 1x1 conv chained in registers, then store
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    const bool valid = oy < p.OH && ox < p.OW;
+    float* orow = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * Nout;
+    if (NT3 > 0) {
+      f32x4 a3[NT3 > 0 ? NT3 : 1];
+#pragma unroll
+      for (int nt = 0; nt < NT3; ++nt) a3[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NT2; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT3; ++nt) {
+          const f32x4 wq = w3l[(kb * NT3 + nt) * 64 + lane];
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            a3[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s], a2[kb][s], a3[nt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int nt = 0; nt < NT3; ++nt) {
+        const int n = nt * 16 + 4 * kq;
+        const f32x4 v = yl_act4(a3[nt] + yl_ld4(p.b3 + n), p.act3);
+        if (valid && n < Nout) *reinterpret_cast<f32x4*>(orow + n) = v;
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt) {
+        const int n = nt * 16 + 4 * kq;
+        if (valid && n < Nout) *reinterpret_cast<f32x4*>(orow + n) = a2[nt];
+      }
+    }
+  }
+}
+
+template <int NT1, int NT2, int NT3>
+static hipError_t sb_go(const YlConvP& p, hipStream_t st, bool attr_only) {
+  constexpr int P1 = NT1 * 16 + 4;
+  const size_t lds = (size_t)(4 * SB_MT1 * 16 * P1) * 4 + (size_t)(9 * NT1 * NT2 + NT2 * NT3) * 1024;
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_stemblock_kernel<NT1, NT2, NT3>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  const int wtiles = p.B * ((p.OW + SB_TC - 1) / SB_TC) * ((p.OH + SB_TR - 1) / SB_TR);
+  int gx = 2 * YL_NUM_CU;
+  if (gx > (wtiles + 3) / 4) gx = (wtiles + 3) / 4;
+  hipLaunchKernelGGL((yl_stemblock_kernel<NT1, NT2, NT3>), dim3(gx), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int NT1>
+static hipError_t sb_dispatch(const YlConvP& p, hipStream_t st, bool attr_only) {
+  const int nt2 = (p.C2 + 15) / 16, nt3 = (p.C3 + 15) / 16;
+  hipError_t e = hipSuccess;
+  bool hit = false;
+#define SB_CASE(A, B)                                                     \
+  if (attr_only || (nt2 == A && nt3 == B)) {                              \
+    hit = true;                                                           \
+    if ((e = sb_go<NT1, A, B>(p, st, attr_only)) != hipSuccess) return e; \
+  }
+  SB_CASE(1, 0) SB_CASE(1, 1) SB_CASE(2, 0) SB_CASE(2, 2) SB_CASE(1, 2) SB_CASE(2, 1)
+#undef SB_CASE
+  return hit ? e : hipErrorInvalidValue;
+}
+
+hipError_t yl_stemblock_init() {
+  YlConvP p{};
+  hipError_t e = sb_dispatch<1>(p, nullptr, true);
+  if (e != hipSuccess) return e;
+  return sb_dispatch<2>(p, nullptr, true);
+}
+
+bool yl_stemblock_supported(int c1, int c2, int c3) {
+  const int nt2 = (c2 + 15) / 16, nt3 = (c3 + 15) / 16;
+  return (c1 == 16 || c1 == 32) && nt2 >= 1 && nt2 <= 2 && nt3 >= 0 && nt3 <= 2 && (c2 % 4 == 0) && (c3 % 4 == 0);
+}
+
+hipError_t yl_launch_stemblock(const YlConvP& p, hipStream_t st) {
+  if (p.C1 == 32) return sb_dispatch<2>(p, st, false);
+  if (p.C1 == 16) return sb_dispatch<1>(p, st, false);
+  return hipErrorInvalidValue;
+}

@@ -70,6 +70,8 @@ class HipContext:
                 y.k, y.stride, y.pad_t, y.pad_l, y.act = l.k, l.stride, l.pad_t, l.pad_l, l.act
                 y.dw_k, y.dw_stride, y.dw_pad_t, y.dw_pad_l, y.dw_act = l.dw_k, l.dw_stride, l.dw_pad_t, l.dw_pad_l, l.dw_act
                 y.w, y.b, y.dw_w, y.dw_b = fp(l.w), fp(l.b), fp(l.dw_w), fp(l.dw_b)
+                y.c2, y.act2, y.c3, y.act3 = l.c2, l.act2, l.c3, l.act3
+                y.w2, y.b2, y.w3, y.b3 = fp(l.w2), fp(l.b2), fp(l.w3), fp(l.b3)
             d.num_layers = len(program.layers)
             d.layers = arr
             keep.append(arr)
@@ -225,9 +227,9 @@ class YOLOLiteHIP:
     checkpoint's meta, weights attached with load_state_dict(), moved with .to(device), called with
     a [B,3,S,S] float tensor, returns the list of level tensors."""
 
-    def __init__(self, meta: dict, fuse_dw="auto"):
+    def __init__(self, meta: dict, fuse_dw="auto", fuse_stem: bool = True):
         self.meta = meta
-        self.fuse_dw = fuse_dw
+        self.fuse_dw, self.fuse_stem = fuse_dw, fuse_stem
         self.export_concat = False
         self.program: Optional[Program] = None
         self.ctx: Optional[HipContext] = None
@@ -245,7 +247,7 @@ class YOLOLiteHIP:
         Unlike the reference, a key the forward pass needs cannot be left at its random init:
         missing weights raise."""
         try:
-            self.program = build_program(self.meta, state_dict, fuse_dw=self.fuse_dw)
+            self.program = build_program(self.meta, state_dict, fuse_dw=self.fuse_dw, fuse_stem=self.fuse_stem)
         except KeyError as e:
             raise RuntimeError(f"checkpoint lacks a weight the forward pass needs: {e.args[0]}") from None
         self._sd = state_dict
@@ -271,7 +273,7 @@ class YOLOLiteHIP:
         planned per size, so contexts are cached by input size."""
         if img_size not in self._ctxs:
             p = self.program if img_size == self.program.img_size else \
-                build_program(self.meta, self._sd, fuse_dw=self.fuse_dw, img_size=img_size)
+                build_program(self.meta, self._sd, fuse_dw=self.fuse_dw, img_size=img_size, fuse_stem=self.fuse_stem)
             self._ctxs[img_size] = (p, HipContext(p.img_size, p.num_classes, p.level_size, p.level_anchors, p,
                                                   self._device_index))
         return self._ctxs[img_size][1]
@@ -301,9 +303,9 @@ class YOLOLiteHIP:
     forward = __call__
 
 
-def build_model_from_meta(meta: dict, fuse_dw="auto") -> YOLOLiteHIP:
+def build_model_from_meta(meta: dict, fuse_dw="auto", fuse_stem: bool = True) -> YOLOLiteHIP:
     """tools/infer.py:34-77."""
-    return YOLOLiteHIP(meta, fuse_dw=fuse_dw)
+    return YOLOLiteHIP(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem)
 
 
 def load_model_names_imgsize_from_ckpt(weights: str, device):

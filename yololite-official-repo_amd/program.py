@@ -90,6 +90,14 @@ class Layer:
     dw_act: int = 0
     dw_w: Optional[np.ndarray] = None
     dw_b: Optional[np.ndarray] = None
+    c2: int = 0                 # OP_STEMBLOCK: second (3x3 s2) and optional third (1x1) conv
+    act2: int = 0
+    c3: int = 0
+    act3: int = 0
+    w2: Optional[np.ndarray] = None
+    b2: Optional[np.ndarray] = None
+    w3: Optional[np.ndarray] = None
+    b3: Optional[np.ndarray] = None
     name: str = ""
     macs: int = 0               # per image
     bytes_in: int = 0           # algorithmic HBM bytes per image (read)
@@ -189,13 +197,13 @@ def zoo_meta(name: str, num_classes: int = 80, img_size: int = 640, **kw) -> dic
 
 
 _ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
-_OP_STEM, _OP_CONV, _OP_DW = 0, 1, 2
+_OP_STEM, _OP_CONV, _OP_DW, _OP_STEMBLOCK = 0, 1, 2, 3
 DW_PROLOGUE_LDS_MAX = 32 * 1024      # bytes; mirrors YL_DW_LDS_MAX in csrc/yl_api.hip
 
 
 class _Builder:
-    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw):
-        self.sd, self.p, self.fuse_dw = sd, prog, fuse_dw
+    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw, fuse_stem=True):
+        self.sd, self.p, self.fuse_dw, self.fuse_stem = sd, prog, fuse_dw, fuse_stem
 
     # ---- state-dict access
     def get(self, key: str, shape: Tuple[int, ...]) -> np.ndarray:
@@ -249,6 +257,25 @@ class _Builder:
         o = self.slot(oh, oh, cout)
         self.p.layers.append(Layer(_OP_STEM, -1, o, 3, cout, k, s, pad, pad, _ACT[act], w, b, name=conv,
                                    macs=oh * oh * cout * 3 * k * k, bytes_in=4 * 3 * S * S,
+                                   bytes_out=4 * oh * oh * cout))
+        return o
+
+    def stemblock(self, prefix, eps, act, c1, c2, c3):
+        """stem 3x3 s2 -> blocks.0.0 (3x3 s2) -> optional blocks.0.1 (1x1) as ONE launch (symmetric padding)."""
+        S = self.p.img_size
+        sh, pad = self.geom(S, 3, 2, False)
+        oh, _ = self.geom(sh, 3, 2, False)
+        w1, b1 = self.fold(prefix + "conv_stem", prefix + "bn1", eps, False, (c1, 3, 3, 3))
+        w2, b2 = self.fold(prefix + "blocks.0.0.conv", prefix + "blocks.0.0.bn1", eps, False, (c2, c1, 3, 3))
+        w3 = b3 = None
+        if c3:
+            w3, b3 = self.fold(prefix + "blocks.0.1.conv", prefix + "blocks.0.1.bn1", eps, False, (c3, c2, 1, 1))
+        cout = c3 or c2
+        o = self.slot(oh, oh, cout)
+        macs = sh * sh * c1 * 27 + oh * oh * c2 * c1 * 9 + oh * oh * c3 * c2
+        self.p.layers.append(Layer(_OP_STEMBLOCK, -1, o, 3, c1, 3, 2, pad, pad, _ACT[act], w1, b1,
+                                   c2=c2, act2=_ACT[act], c3=c3, act3=_ACT[act], w2=w2, b2=b2, w3=w3, b3=b3,
+                                   name=prefix + "conv_stem+blocks.0", macs=macs, bytes_in=4 * 3 * S * S,
                                    bytes_out=4 * oh * oh * cout))
         return o
 
@@ -309,13 +336,28 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
         raise ValueError(f"backbone '{name}' has no layer table (known: {sorted(BACKBONES)})")
     spec = BACKBONES[name]
     arch, act, eps, same = spec["arch"], spec["act"], spec["eps"], spec["same"]
-    x = b.stem(prefix + "conv_stem", prefix + "bn1", eps, act, spec["stem"], 3, 2, same)
-    cin, red = spec["stem"], 2
-    feats = []
-    if _parse(arch[0][0])["s"] > 1:
-        feats.append((x, cin, red))
     ns = len(arch)
+    s0 = [_parse(t) for t in arch[0]]
+    c_s0 = [_make_divisible(d["c"] * spec["cmult"], 8) for d in s0]
+    fused_entry = (b.fuse_stem and not same and spec["stem"] in (16, 32) and len(s0) in (1, 2)
+                   and s0[0]["type"] == "cn" and s0[0]["k"] == 3 and s0[0]["s"] == 2 and s0[0]["r"] == 1
+                   and (len(s0) == 1 or (s0[1]["type"] == "cn" and s0[1]["k"] == 1 and s0[1]["s"] == 1 and s0[1]["r"] == 1))
+                   and all(c <= 32 and c % 4 == 0 for c in c_s0))
+    feats = []
+    if fused_entry:
+        x = b.stemblock(prefix, eps, act, spec["stem"], c_s0[0], c_s0[1] if len(s0) == 2 else 0)
+        cin, red = c_s0[-1], 4
+        feats.append((-1, spec["stem"], 2))               # stem tap: never materialised, never consumed
+        if _parse(arch[1][0])["s"] > 1:
+            feats.append((x, cin, red))
+    else:
+        x = b.stem(prefix + "conv_stem", prefix + "bn1", eps, act, spec["stem"], 3, 2, same)
+        cin, red = spec["stem"], 2
+        if s0[0]["s"] > 1:
+            feats.append((x, cin, red))
     for si, stage in enumerate(arch):
+        if fused_entry and si == 0:
+            continue
         bi = 0
         for bstr in stage:
             d = _parse(bstr)
@@ -363,7 +405,7 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
 
 
 def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto",
-                  img_size: Optional[int] = None) -> Program:
+                  img_size: Optional[int] = None, fuse_stem: bool = True) -> Program:
     """meta: the checkpoint's `meta` dict (tools/train.py:62-75); reads the keys
     build_model_from_meta reads (tools/infer.py:35-50).
     fuse_dw: True = every depthwise conv becomes the prologue of the following 1x1 conv, False = none,
@@ -391,7 +433,7 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     else:
         sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
     prog = Program(img_size=S, num_classes=C, level_size=[], level_anchors=[], strides=[])
-    b = _Builder(sd, prog, fuse_dw)
+    b = _Builder(sd, prog, fuse_dw, fuse_stem)
 
     feats = _backbone(b, backbone)
     take = 4 if use_p2 else 3
