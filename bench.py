@@ -95,7 +95,7 @@ def main():
     B, S = args.batch, args.img
     meta = zoo_meta(args.model, 80, S)
     sd = synth_state_dict(meta, seed=0, head_noise=2.0)
-    model = ya.build_model_from_meta(meta, fuse_dw=("auto" if args.fuse_dw == "auto" else bool(int(args.fuse_dw))),
+    model = ya.build_model_from_meta(meta, fuse_dw=(args.fuse_dw if args.fuse_dw in ("auto", "dw3") else bool(int(args.fuse_dw))),
                                      fuse_stem=bool(args.fuse_stem))
     model.load_state_dict(sd)
     model.to(dev)

@@ -40,6 +40,7 @@ struct yl_ctx {
   int level_S[YL_MAX_LEVELS] = {0}, level_A[YL_MAX_LEVELS] = {0}, level_off[YL_MAX_LEVELS + 1] = {0};
   std::vector<Slot> slots;
   std::vector<DevLayer> layers;
+  float* zeros = nullptr;                  // 256 zero bytes (padding source for the conv kernels)
   int cap_batch = 0;                       // activations / workspaces are sized for this batch
   float* level_buf[YL_MAX_LEVELS] = {nullptr};
   // post-processing workspace
@@ -206,6 +207,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int B, const float* x, flo
   memset(&p, 0, sizeof(p));
   const yl_layer& d = L.d;
   p.wp = L.wp; p.bias = L.bias; p.dw_w = L.dw_w; p.dw_b = L.dw_b;
+  p.zeros = c->zeros;
   p.B = B; p.H = L.in_h; p.W = L.in_w; p.Cin = d.cin;
   p.OH = L.out_h; p.OW = L.out_w; p.N = d.cout;
   p.k = d.k; p.stride = d.stride; p.pad_t = d.pad_t; p.pad_l = d.pad_l; p.act = d.act;
@@ -328,6 +330,7 @@ void yl_destroy(yl_ctx* c) {
   free_act(c);
   free_post_ws(c);
   hipFree(c->ws_nms_clsws);
+  hipFree(c->zeros);
   hipFree(c->ws_nms_gkeys);
   for (auto& L : c->layers) {
     hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b);
@@ -367,6 +370,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   c->N = off;
   if (c->N >= (1 << 20)) return fail(c, YL_ERR_UNSUPPORTED, "more than 2^20 candidates per image");
   if (d->num_layers == 0) return YL_OK;
+  HIPCHK(c, hipMalloc((void**)&c->zeros, 256));
+  HIPCHK(c, hipMemset(c->zeros, 0, 256));
   if (d->in_channels != 3) return fail(c, YL_ERR_UNSUPPORTED, "network input must have 3 channels");
   if (!d->layers || !d->slot_h || !d->slot_w || !d->slot_c) return fail(c, YL_ERR_INVALID, "null layer/slot arrays");
   c->slots.resize(d->num_slots);

@@ -37,6 +37,14 @@ struct YlPix {
   size_t lin;        // linear output pixel index (clamped)
 };
 
+// ReLU-family activations as a clamp with wave-uniform bounds; SiLU behind a uniform branch
+__device__ __forceinline__ f32x4 yl_actc(f32x4 v, int act, float lo, float hi) {
+  if (act == YL_ACT_SILU) return yl_act4(v, YL_ACT_SILU);
+  v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
+  v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
+  return v;
+}
+
 __device__ __forceinline__ f32x4 yl_sel4(bool keep, f32x4 v) {
   f32x4 r;
   r.x = keep ? v.x : 0.f; r.y = keep ? v.y : 0.f; r.z = keep ? v.z : 0.f; r.w = keep ? v.w : 0.f;
@@ -48,14 +56,15 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
                                           const float* dwl /*LDS: [taps][Cin] weights then [Cin] bias*/) {
   const bool cin_ok = c < p.Cin;
   const int cs = cin_ok ? c : (p.Cin - 4);
+  // out-of-range taps / channels load from a zero buffer: the select happens on the ADDRESS, so the
+  // loaded registers are first touched by their consumer and the load latency stays hidden
   if (MODE == YL_CM_PW) {
-    return yl_sel4(cin_ok, yl_ld4(p.x + px.lin * p.Cin + cs));
+    return yl_ld4(cin_ok ? p.x + px.lin * p.Cin + cs : p.zeros);
   } else if (MODE == YL_CM_KXK) {
     const int iy = px.oy * p.stride - p.pad_t + ky;
     const int ix = px.ox * p.stride - p.pad_l + kx;
     const bool in = cin_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-    return yl_sel4(in, yl_ld4(p.x + (((size_t)px.b * p.H + iyc) * p.W + ixc) * p.Cin + cs));
+    return yl_ld4(in ? p.x + (((size_t)px.b * p.H + iy) * p.W + ix) * p.Cin + cs : p.zeros);
   } else {  // depthwise prologue feeding a 1x1 conv: value of the dw output at (oy,ox)
     // depthwise taps and bias come from LDS (staged once per block): the vector-memory pipe only
     // carries the activation taps
@@ -76,8 +85,7 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
         for (int dx = 0; dx < 5; ++dx) {
           const int ix = x0 + dx;
           const bool in = yin && ix >= 0 && ix < p.W;
-          const int ixc = min(max(ix, 0), p.W - 1);
-          v[dx] = yl_sel4(in, yl_ld4(xb + ((size_t)iyc * p.W + ixc) * p.Cin));
+          v[dx] = yl_ld4(in ? xb + ((size_t)iyc * p.W + ix) * p.Cin : p.zeros);
         }
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
@@ -99,8 +107,7 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
         for (int dx = 0; dx < DK; ++dx) {
           const int ix = x0 + dx;
           const bool in = yin && ix >= 0 && ix < p.W;
-          const int ixc = min(max(ix, 0), p.W - 1);
-          v[dy][dx] = yl_sel4(in, yl_ld4(xb + ((size_t)iyc * p.W + ixc) * p.Cin));
+          v[dy][dx] = yl_ld4(in ? xb + ((size_t)iyc * p.W + ix) * p.Cin : p.zeros);
         }
       }
 #pragma unroll
@@ -119,15 +126,16 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
         for (int dx = 0; dx < p.dw_k; ++dx) {
           const int ix = x0 + dx;
           const bool in = yin && ix >= 0 && ix < p.W;
-          const int ixc = min(max(ix, 0), p.W - 1);
-          const f32x4 v = yl_sel4(in, yl_ld4(xb + ((size_t)iyc * p.W + ixc) * p.Cin));
+          const f32x4 v = yl_ld4(in ? xb + ((size_t)iyc * p.W + ix) * p.Cin : p.zeros);
           const f32x4 w = yl_ld4(wb + (dy * p.dw_k + dx) * p.Cin);
           s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
           s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
         }
       }
     }
-    s = yl_act4(s, p.dw_act);
+    const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+    const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+    s = yl_actc(s, p.dw_act, dlo, dhi);
     return yl_sel4(cin_ok, s);
   }
 }
@@ -322,6 +330,159 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// depthwise (DK x DK, stride DS) -> 1x1 conv with the depthwise input staged through LDS.
+// Each wave owns a 4x4 output-pixel tile (m-tile) end to end.  Per block of 16 input channels it
+//   1. has the (3*DS+DK)^2-pixel x 16-channel halo patch in its private LDS region (coalesced float4
+//      loads issued one k-step ahead, zero-filled outside the image),
+//   2. forms its B fragment = act(bias + sum_taps w[tap] * patch[...]) from DK*DK conflict-free
+//      ds_read_b128 (taps and bias also in LDS),
+//   3. feeds 4 MFMA k-steps per n-tile,
+// so the depthwise input is fetched from L2/HBM once per tile instead of DK*DK times and the hot loop
+// has no bounds logic.  Requires OH % 4 == 0 and OW % 4 == 0 (else the DW3/DW5 global-tap modes run).
+template <int NT, int DK, int DS>
+__global__ __launch_bounds__(256) void yl_conv_dwh_kernel(YlConvP p) {
+  constexpr int HP = 3 * DS + DK;                         // halo edge in pixels
+  constexpr int PITCH = (HP % 4 == 1 || HP % 4 == 3) ? HP : HP + 1;   // row pitch (pixels): odd multiple of 64 B mod 256 B
+  constexpr int HF4 = HP * HP * 4;                        // float4 elements of one halo patch (16 ch)
+  constexpr int NSLOT = (HF4 + 63) / 64;                  // staging float4 per lane
+  constexpr int MT = 1;
+  extern __shared__ __attribute__((aligned(16))) float yl_wlds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, pl = lane & 15;
+  const int nt0 = blockIdx.y * NT;
+  const int ntc = (p.NTtot - nt0) < NT ? (p.NTtot - nt0) : NT;
+  const int KB = p.KB;
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_wlds);          // [KB][NT][64] float4 (whole K: checked by the launcher)
+  float* dwl = yl_wlds + (size_t)KB * NT * 256;           // [DK*DK][Cin] taps, [Cin] bias
+  float* halo = dwl + (size_t)(DK * DK + 1) * p.Cin + wave * (HP * PITCH * 16);
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+
+  for (int t = wave; t < KB; t += 4) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (nt < ntc) w = wg[((size_t)t * p.NTtot + nt0 + nt) * 64 + lane];
+      wl[(t * NT + nt) * 64 + lane] = w;
+    }
+  }
+  {
+    const int nw = DK * DK * p.Cin;
+    for (int i = tid; i < nw; i += 256) dwl[i] = p.dw_w[i];
+    for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = p.dw_b ? p.dw_b[i] : 0.0f;
+  }
+  __syncthreads();
+
+  const int tw = p.OW >> 2, th = p.OH >> 2;
+  const int tiles_img = tw * th;
+  const int ntiles = p.B * tiles_img;
+  const int wstride = gridDim.x * 4;
+  // lane constants: staging slots (halo pixel / channel quad) and the read base of the lane's output pixel
+  int s_hr[NSLOT], s_hc[NSLOT], s_lo[NSLOT];
+  bool s_ok[NSLOT];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int e = j * 64 + lane;
+    s_ok[j] = e < HF4;
+    const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
+    s_hr[j] = hp / HP;
+    s_hc[j] = hp - s_hr[j] * HP;
+    s_lo[j] = (s_hr[j] * PITCH + s_hc[j]) * 16 + quad * 4;
+  }
+  const int rbase = (((pl >> 2) * DS) * PITCH + (pl & 3) * DS) * 16 + 4 * kq;
+
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tw, txi = trem - tyi * tw;
+    YlPix px[MT];
+    px[0].b = b;
+    px[0].oy = 4 * tyi + (pl >> 2);
+    px[0].ox = 4 * txi + (pl & 3);
+    px[0].valid = true;
+    px[0].lin = ((size_t)b * p.OH + px[0].oy) * p.OW + px[0].ox;
+    // global element offsets of the lane's staging slots (channel block 0), -1 = outside the image
+    const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * txi * DS - p.dw_pad_l;
+    long goff[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int iy = iy0 + s_hr[j], ix = ix0 + s_hc[j];
+      const bool in = s_ok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      goff[j] = in ? ((((long)b * p.H + iy) * p.W + ix) * p.Cin + (lane & 3) * 4) : -1;
+    }
+    auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j) {
+        const int c = kb * 16 + (lane & 3) * 4;
+        const bool ok = goff[j] >= 0 && c < p.Cin;
+        r[j] = yl_ld4(ok ? p.x + goff[j] + kb * 16 : p.zeros);
+      }
+    };
+    auto stage_store = [&](const f32x4 (&r)[NSLOT]) {
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j)
+        if (s_ok[j]) *reinterpret_cast<f32x4*>(halo + s_lo[j]) = r[j];
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 stg[NSLOT];
+    stage_load(0, stg);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // previous tile's halo reads are complete
+    stage_store(stg);
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb + 1 < KB) stage_load(kb + 1, stg);                       // next channel block: loads in flight
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // halo writes (all lanes) -> tap reads
+      const int c = kb * 16 + 4 * kq;
+      const int cs = c < p.Cin ? c : p.Cin - 4;
+      f32x4 s = yl_ld4(dwl + DK * DK * p.Cin + cs);
+      if (DK == 3) {
+#pragma unroll
+        for (int dy = 0; dy < DK; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < DK; ++dx) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + (dy * PITCH + dx) * 16);
+            const f32x4 w = yl_ld4(dwl + (dy * DK + dx) * p.Cin + cs);
+            s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
+            s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
+          }
+      } else {
+#pragma unroll 1
+        for (int dy = 0; dy < DK; ++dy) {                 // one tap row at a time bounds the register footprint
+#pragma unroll
+          for (int dx = 0; dx < DK; ++dx) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + (dy * PITCH + dx) * 16);
+            const f32x4 w = yl_ld4(dwl + (dy * DK + dx) * p.Cin + cs);
+            s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
+            s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
+          }
+        }
+      }
+      const f32x4 xq = yl_sel4(c < p.Cin, yl_actc(s, p.dw_act, dlo, dhi));
+      const f32x4* wrow = wl + (size_t)kb * NT * 64 + lane;
+      f32x4 wq[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[nt][ss], xq[ss], acc[0][nt], 0, 0, 0);
+      if (kb + 1 < KB) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // this step's tap reads are complete
+        stage_store(stg);
+      }
+    }
+    if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+    else if (p.res || p.up || p.act == YL_ACT_SILU) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stem: 3x3 conv on the NCHW network input (Cin = 3, K = 27 padded to 28 = 7 MFMA k-steps).
 // Same transposed GEMM as above: A = weights (7*NT floats per lane, resident in registers for the whole
 // kernel), B = one input scalar per lane per k-step gathered straight from the three input planes
@@ -467,10 +628,40 @@ static hipError_t yl_conv_attr_nt() {
   if ((e = yl_conv_attr_modes<6, MT>()) != hipSuccess) return e;
   return yl_conv_attr_modes<8, MT>();
 }
+#define YL_DWH_LDS_MAX (144 * 1024)
+template <int NT, int DK, int DS>
+static hipError_t yl_dwh_attr() {
+  return hipFuncSetAttribute((const void*)yl_conv_dwh_kernel<NT, DK, DS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             YL_DWH_LDS_MAX);
+}
+template <int NT>
+static hipError_t yl_dwh_attr_all() {
+  hipError_t e;
+  if ((e = yl_dwh_attr<NT, 3, 1>()) != hipSuccess) return e;
+  if ((e = yl_dwh_attr<NT, 3, 2>()) != hipSuccess) return e;
+  if ((e = yl_dwh_attr<NT, 5, 1>()) != hipSuccess) return e;
+  return yl_dwh_attr<NT, 5, 2>();
+}
 hipError_t yl_conv_init() {
   hipError_t e = yl_conv_attr_nt<1>();
   if (e != hipSuccess) return e;
-  return yl_conv_attr_nt<2>();
+  if ((e = yl_conv_attr_nt<2>()) != hipSuccess) return e;
+  if ((e = yl_dwh_attr_all<1>()) != hipSuccess) return e;
+  if ((e = yl_dwh_attr_all<2>()) != hipSuccess) return e;
+  if ((e = yl_dwh_attr_all<3>()) != hipSuccess) return e;
+  if ((e = yl_dwh_attr_all<4>()) != hipSuccess) return e;
+  if ((e = yl_dwh_attr_all<6>()) != hipSuccess) return e;
+  return yl_dwh_attr_all<8>();
+}
+
+template <int NT>
+static bool yl_dwh_go(const YlConvP& p, dim3 grid, size_t lds, hipStream_t st) {
+  if (p.dw_k == 3 && p.dw_stride == 1) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 3, 1>), grid, dim3(256), lds, st, p);
+  else if (p.dw_k == 3 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 3, 2>), grid, dim3(256), lds, st, p);
+  else if (p.dw_k == 5 && p.dw_stride == 1) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 5, 1>), grid, dim3(256), lds, st, p);
+  else if (p.dw_k == 5 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 5, 2>), grid, dim3(256), lds, st, p);
+  else return false;
+  return true;
 }
 
 template <int NT, int MT>
@@ -510,6 +701,31 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
     NT = best;
   }
   const int gy = (p.NTtot + NT - 1) / NT;
+  // depthwise prologue with LDS-staged halo tiles (4x4 output pixels per wave)
+  if (p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.OH & 3) == 0 &&
+      (p.OW & 3) == 0 && tile_hint != 3) {
+    const int HP = 3 * p.dw_stride + p.dw_k;
+    const int PITCH = (HP % 4 == 1 || HP % 4 == 3) ? HP : HP + 1;
+    const size_t lds = (size_t)p.KB * NT * 1024 + (size_t)(p.dw_k * p.dw_k + 1) * p.Cin * 4 + (size_t)4 * HP * PITCH * 64;
+    if (lds <= YL_DWH_LDS_MAX) {
+      const long wtiles = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
+      int gx = (4 * YL_NUM_CU) / gy;
+      if (gx < 8) gx = 8;
+      gx &= ~7;
+      if (gx > (wtiles + 3) / 4) gx = (int)((wtiles + 3) / 4);
+      dim3 grid(gx, gy);
+      bool ok = false;
+      switch (NT) {
+        case 1: ok = yl_dwh_go<1>(p, grid, lds, st); break;
+        case 2: ok = yl_dwh_go<2>(p, grid, lds, st); break;
+        case 3: ok = yl_dwh_go<3>(p, grid, lds, st); break;
+        case 4: ok = yl_dwh_go<4>(p, grid, lds, st); break;
+        case 6: ok = yl_dwh_go<6>(p, grid, lds, st); break;
+        default: ok = yl_dwh_go<8>(p, grid, lds, st); break;
+      }
+      if (ok) return hipGetLastError();
+    }
+  }
   int MT = 2;
   const long tiles2 = ((long)p.M + 127) / 128;
   if (tile_hint == 1 || (tile_hint == 0 && tiles2 * gy < 2 * YL_NUM_CU)) MT = 1;

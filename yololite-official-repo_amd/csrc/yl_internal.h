@@ -56,6 +56,7 @@ struct YlConvP {
   const float* res;      // residual NHWC [B,OH,OW,N] or nullptr
   const float* up;       // NHWC [B,UH,UW,N] nearest-upsampled and added, or nullptr
   float* out;
+  const float* zeros;    // >= 64 zero bytes in HBM: out-of-range taps load from here (no select after the load)
   const float* dw_w;     // [dw_k*dw_k][Cin] tap-major
   const float* dw_b;     // [Cin] or nullptr
   int B, H, W, Cin;      // input tensor

@@ -291,7 +291,7 @@ class _Builder:
             doh, dpad = self.geom(h, dw["k"], dw["s"], same)
             dow, _ = self.geom(wd, dw["k"], dw["s"], same)
             dmacs = doh * dow * cin * dw["k"] ** 2
-            fuse = (dw["k"] == 3) if self.fuse_dw == "auto" else bool(self.fuse_dw)
+            fuse = (dw["k"] == 3) if self.fuse_dw == "dw3" else bool(self.fuse_dw)      # "auto" -> all
             # the prologue keeps the depthwise taps + bias of all Cin channels in LDS (yl_conv.hip)
             fuse = fuse and (dw["k"] ** 2 + 1) * cin * 4 <= DW_PROLOGUE_LDS_MAX
             if fuse and k == 1 and s == 1:
@@ -409,7 +409,7 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     """meta: the checkpoint's `meta` dict (tools/train.py:62-75); reads the keys
     build_model_from_meta reads (tools/infer.py:35-50).
     fuse_dw: True = every depthwise conv becomes the prologue of the following 1x1 conv, False = none,
-    "auto" = measured policy (3x3 fused; 5x5 run as their own bandwidth-bound launch)."""
+    "dw3" = only 3x3; "auto" = measured best policy (currently: all, LDS-halo kernel)."""
     cfg = meta.get("config", {}) or {}
     mcfg = cfg.get("model", {}) or {}
     tcfg = cfg.get("training", {}) or {}
