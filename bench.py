@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-dw", default="auto", help="auto | 1 | 0: fuse depthwise convs into the following 1x1 conv")
     ap.add_argument("--fuse-stem", type=int, default=1, help="fused stem+blocks.0 entry kernel")
+    ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
     args = ap.parse_args()
 
@@ -100,6 +101,8 @@ def main():
     model.load_state_dict(sd)
     model.to(dev)
     ctx, prog = model._ctx_for(S), model.program
+    if args.tile_m:
+        ctx.set_option("tile_m", args.tile_m)
     x = synth_images(B, S, seed=1234 + rank).to(dev)
     max_out = 300                                        # packed result rows per image
     dets = torch.empty((B, max_out, 6), device=dev, dtype=torch.float32)

@@ -185,12 +185,44 @@ __device__ __forceinline__ void yl_epi_generic(const YlConvP& p, f32x4 (&acc)[MT
   }
 }
 
-// scalar-store variant for N % 4 != 0 (the detection head: N = 5+C, rows of one anchor of one level,
-// image pitch p.out_bstride) -- one 64-bit row base per pixel, immediate offsets per element.
+// N % 4 != 0 (the detection head: N = 5+C).  The MT*16 pixels of a wave's tile are consecutive rows of
+// N floats, i.e. ONE contiguous, 16-byte aligned run of MT*16*N floats: the wave transposes its D
+// fragments through a private LDS region and writes the run with coalesced float4 stores (4x fewer store
+// instructions than per-element stores, full 128-B lines).  `stg` == nullptr or non-contiguous rows
+// (A > 1 anchors: image pitch != OH*OW*N) fall back to per-element stores.
 template <int NT, int MT>
 __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT], int nt0,
-                                              int kq, float lo, float hi) {
+                                              int kq, float lo, float hi, float* stg, size_t lin0, int lane) {
   const int ohw = p.OH * p.OW;
+  const bool contiguous = stg != nullptr && p.out_bstride == (long)ohw * p.N && gridDim.y == 1;
+  if (contiguous) {
+    const int pl = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nt0 + nt) * 16 + 4 * kq;
+        f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = fminf(fmaxf(v[r], lo), hi);
+          if (p.act == YL_ACT_SILU) e = yl_act1(v[r], YL_ACT_SILU);
+          if (n + r < p.N) stg[(mt * 16 + pl) * p.N + n + r] = e;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    long rows = (long)p.M - (long)lin0;                         // valid pixels of this tile
+    if (rows > MT * 16) rows = MT * 16;
+    const int total = (int)rows * p.N;                          // floats; the run starts 16-B aligned
+    float* dst = p.out + lin0 * p.N;
+    const int n4 = total >> 2;
+    for (int i = lane; i < n4; i += 64)
+      *reinterpret_cast<f32x4*>(dst + 4 * i) = *reinterpret_cast<const f32x4*>(stg + 4 * i);
+    for (int i = 4 * n4 + lane; i < total; i += 64) dst[i] = stg[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (!px[mt].valid) continue;
@@ -240,8 +272,16 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
     }
   };
   constexpr bool DWM = (MODE == YL_CM_DWPRO || MODE == YL_CM_DW3 || MODE == YL_CM_DW5);
-  // LDS carve: [CH*NT*64 float4 weight chunk][dw taps*Cin + Cin floats]
+  // LDS carve: [CH*NT*64 float4 weight chunk][dw taps*Cin + Cin floats][per-wave store staging (N%4 != 0)]
   float* dwl = yl_wlds + (size_t)CH * NT * 256;
+  float* stg = nullptr;
+  if (p.N & 3) {
+    const size_t dwf = DWM ? (size_t)(p.dw_k * p.dw_k + 1) * p.Cin : 0;
+    stg = dwl + ((dwf + 3) & ~(size_t)3) + (size_t)wave * (MT * 16 * p.N);
+  }
+  // residual / upsample-add without activation: the addends initialise the accumulators (loads issued
+  // with the first activation fetch instead of after the last MFMA)
+  const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE && !(p.N & 3);
   if (DWM) {
     const int nw = p.dw_k * p.dw_k * p.Cin;
     for (int i = tid; i < nw; i += 256) dwl[i] = p.dw_w[i];
@@ -269,6 +309,25 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pre_add) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const size_t obase = px[mt].lin * p.N;
+        size_t up_off = 0;
+        if (p.up) {
+          const int uy = (px[mt].oy * p.UH) / p.OH, ux = (px[mt].ox * p.UW) / p.OW;
+          up_off = (((size_t)px[mt].b * p.UH + uy) * p.UW + ux) * p.N;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = (nt0 + nt) * 16 + 4 * kq;
+          if (n < p.N) {
+            if (p.res) acc[mt][nt] = yl_ld4(p.res + obase + n);
+            if (p.up) acc[mt][nt] += yl_ld4(p.up + up_off + n);
+          }
+        }
+      }
+    }
 
     for (int c0 = 0; c0 < TK; c0 += CH) {
       const int c1 = (c0 + CH) < TK ? (c0 + CH) : TK;
@@ -323,8 +382,8 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
       }
     }
 
-    if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi);
-    else if (p.res || p.up || p.act == YL_ACT_SILU) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi, stg, ((size_t)tile * 4 + wave) * (MT * 16), lane);
+    else if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
   }
 }
@@ -476,7 +535,7 @@ __global__ __launch_bounds__(256) void yl_conv_dwh_kernel(YlConvP p) {
         stage_store(stg);
       }
     }
-    if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+    if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi, nullptr, 0, lane);
     else if (p.res || p.up || p.act == YL_ACT_SILU) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
   }
@@ -602,7 +661,7 @@ __global__ __launch_bounds__(256) void yl_dw_kernel(YlConvP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-#define YL_CONV_LDS_MAX (96 * 1024)
+#define YL_CONV_LDS_MAX (128 * 1024)
 
 template <int NT, int MT, int MODE>
 static hipError_t yl_conv_attr() {
@@ -733,10 +792,13 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
   p.ntiles = (int)(((long)p.M + 64 * MT - 1) / (64 * MT));
   // LDS weight chunk: whole K if it fits, else stream 48 KiB chunks
   const size_t step_bytes = (size_t)NT * 1024;
-  const size_t dw_bytes = p.dw_k > 0 ? (size_t)(p.dw_k * p.dw_k + 1) * p.Cin * sizeof(float) : 0;
-  if ((size_t)p.TK * step_bytes + dw_bytes <= YL_CONV_LDS_MAX) p.CH = p.TK;
-  else p.CH = (int)((48 * 1024) / step_bytes);
-  const size_t lds = (size_t)p.CH * step_bytes + dw_bytes;
+  size_t extra = p.dw_k > 0 ? (((size_t)(p.dw_k * p.dw_k + 1) * p.Cin * sizeof(float) + 15) & ~(size_t)15) : 0;
+  if (p.N & 3) extra += (size_t)4 * MT * 16 * p.N * sizeof(float);     // store staging (head rows)
+  if (extra + step_bytes > YL_CONV_LDS_MAX) return hipErrorInvalidValue;
+  const size_t budget = YL_CONV_LDS_MAX - extra;
+  if ((size_t)p.TK * step_bytes <= budget) p.CH = p.TK;                // whole K resident
+  else p.CH = (int)((budget < 48 * 1024 ? budget : 48 * 1024) / step_bytes);   // stream K in chunks
+  const size_t lds = (size_t)p.CH * step_bytes + extra;
   int gx = (4 * YL_NUM_CU) / gy;
   if (gx < 8) gx = 8;
   gx &= ~7;                         // multiple of 8: N-chunks of one M tile land on the same XCD/L2
