@@ -198,18 +198,40 @@ __device__ __forceinline__ u32 yl_desc_bits(float s) {
   return ~u;                                        // descending
 }
 
-__device__ __forceinline__ bool yl_suppress(const float4& bi, float ai, const float4& bj, float aj, float thr,
-                                            int impl) {
-  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-  const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-  const float inter = w * h;
+// exact reference predicate (one rounding per operation, IEEE division)
+__device__ __forceinline__ bool yl_suppress_exact(float inter, float ai, float aj, float thr, int impl) {
   if (impl == YL_NMS_TORCHVISION) {
     const float ovr = inter / (ai + aj - inter);
     return ovr > thr;                               // NaN (0/0) never suppresses
   }
   const float iou = inter / (ai + aj - inter + 1e-6f);
   return !(iou <= thr);                             // reference keeps iff iou <= thr
+}
+
+__device__ __forceinline__ float yl_inter(const float4& bi, const float4& bj) {
+  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+  const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+  return w * h;
+}
+
+// Same result as yl_suppress_exact for every input, but the IEEE division (~12 dependent VALU ops)
+// only runs when some relevant lane of the wave is within 1e-5 (relative) of the threshold: outside
+// that band  inter <> thr*den*(1 +- 1e-5)  decides identically (division / product rounding is 6e-8).
+__device__ __forceinline__ bool yl_suppress(const float4& bi, float ai, const float4& bj, float aj, float thr,
+                                            int impl, bool relevant) {
+  const float inter = yl_inter(bi, bj);
+  const float den = (impl == YL_NMS_TORCHVISION) ? (ai + aj - inter) : (ai + aj - inter + 1e-6f);
+  const float cmp = thr * den;
+  const bool sure_yes = den > 0.0f && inter > cmp * 1.00001f;
+  const bool sure_no = den > 0.0f && inter < cmp * 0.99999f && thr >= 0.0f;
+  bool r = sure_yes;
+  if (__ballot(relevant && !(sure_yes || sure_no)) != 0ull) r = yl_suppress_exact(inter, ai, aj, thr, impl);
+  return r;
+}
+
+__device__ __forceinline__ float yl_readlane_f(float v, int lane_uniform) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
 }
 
 __device__ __forceinline__ float4 yl_shfl4(const float4& v, int src) {
@@ -234,34 +256,38 @@ __device__ __forceinline__ void yl_bitonic_sort(KeyPtr keys, int P, int tid, int
   }
 }
 
-// greedy NMS of one class segment [s,e) of the sorted key array by ONE wave.
+// greedy NMS of one class segment [s,e) of the sorted key array by ONE wave.  SBOX: the survivors' boxes
+// were gathered into LDS in sorted order (sbox[pos]); every box access in the loops below is then an LDS
+// read -- the kept-box loop would otherwise be a chain of dependent global gathers (~1 us each).
 // k32 views the 64-bit keys as u32 pairs: [2*pos] = candidate index, [2*pos+1] = kept list of the
 // segment (entry s+k holds the sorted position of the k-th kept box).
-template <typename K32Ptr>
-__device__ __forceinline__ int yl_nms_segment(K32Ptr k32, int s, int e, const float4* __restrict__ boxes, float thr,
-                                              int impl, int cap, int lane) {
+template <bool SBOX, typename K32Ptr>
+__device__ __forceinline__ int yl_nms_segment(K32Ptr k32, int s, int e, const float4* __restrict__ boxes,
+                                              const float4* sbox, float thr, int impl, int cap, int lane) {
   int nk = 0;
   for (int cs = s; cs < e && nk < cap; cs += 64) {
     const int pos = cs + lane;
     const bool valid = pos < e;
-    const u32 idx = valid ? k32[2 * pos] : 0u;
     float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) bj = boxes[idx];
+    if (valid) bj = SBOX ? sbox[pos] : boxes[k32[2 * pos]];
     const float aj = (bj.z - bj.x) * (bj.w - bj.y);
     bool alive = valid;
     for (int k = 0; k < nk; ++k) {                          // boxes kept by earlier chunks
       const u32 q = k32[2 * (s + k) + 1];
-      const float4 bi = boxes[k32[2 * q]];
+      const float4 bi = SBOX ? sbox[q] : boxes[k32[2 * q]];
       const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-      if (alive && yl_suppress(bi, ai, bj, aj, thr, impl)) alive = false;
+      if (yl_suppress(bi, ai, bj, aj, thr, impl, alive) && alive) alive = false;
     }
     u64 rem = __ballot(alive);
     while (rem) {                                           // serial resolution inside the chunk
-      const int t = __ffsll((long long)rem) - 1;
+      const int t = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
       rem &= rem - 1;
-      const float4 bt = yl_shfl4(bj, t);
-      const float at = __shfl(aj, t);
-      if (alive && lane > t && yl_suppress(bt, at, bj, aj, thr, impl)) alive = false;
+      // box t broadcast through SGPRs (v_readlane), not through the LDS crossbar
+      const float4 bt = make_float4(yl_readlane_f(bj.x, t), yl_readlane_f(bj.y, t), yl_readlane_f(bj.z, t),
+                                    yl_readlane_f(bj.w, t));
+      const float at = yl_readlane_f(aj, t);
+      const bool rel = alive && lane > t;
+      if (yl_suppress(bt, at, bj, aj, thr, impl, rel) && rel) alive = false;
       rem &= __ballot(alive);
     }
     const u64 mask = __ballot(alive);
@@ -289,8 +315,9 @@ __device__ __forceinline__ void yl_write_det(const YlNmsP& p, int b, float* dst,
 
 // Body of the NMS kernel, instantiated once for LDS key storage and once for the global-memory
 // fallback so that each gets address-space-specific code after inlining.
-template <bool LDS_KEYS>
-__device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, int nsurv, int b, int* s_misc) {
+template <bool LDS_KEYS, bool SBOX>
+__device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, int nsurv, int b, int* s_misc,
+                                           float4* sbox) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int N = p.N, C = p.C;
   const float4* boxes = p.boxes + (size_t)b * N;
@@ -323,13 +350,17 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
     if (pos == nsurv - 1 || (int)(keys[pos + 1] >> 52) != c) ws_end[c] = pos + 1;
   }
   __syncthreads();
-  for (int pos = tid; pos < nsurv; pos += blockDim.x) keys[pos] = keys[pos] & 0xFFFFFull;
+  for (int pos = tid; pos < nsurv; pos += blockDim.x) {
+    const u64 idx = keys[pos] & 0xFFFFFull;
+    keys[pos] = idx;
+    if (SBOX) sbox[pos] = boxes[idx];                      // all gathers in flight at once
+  }
   __syncthreads();
 
   for (int c = wave; c < C; c += nwaves) {
     const int s = ws_start[c];
     if (s < 0) continue;
-    const int nk = yl_nms_segment(k32, s, ws_end[c], boxes, p.iou_thr, p.impl, p.cap, lane);
+    const int nk = yl_nms_segment<SBOX>(k32, s, ws_end[c], boxes, sbox, p.iou_thr, p.impl, p.cap, lane);
     if (lane == 0) ws_kept[c] = nk;
   }
   __syncthreads();
@@ -366,7 +397,7 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
       if (orow >= dst_rows) continue;
       const u32 pos = k32[2 * (s + k) + 1];
       const u32 idx = k32[2 * pos];
-      yl_write_det(p, b, dst, dst_idx, orow, boxes[idx], scores[idx], c, (int)idx, !do_topk);
+      yl_write_det(p, b, dst, dst_idx, orow, SBOX ? sbox[pos] : boxes[idx], scores[idx], c, (int)idx, !do_topk);
     }
   }
   if (!do_topk) {
@@ -413,8 +444,14 @@ __global__ __launch_bounds__(1024) void yl_nms_kernel(YlNmsP p) {
   }
   int P = 64;
   while (P < nsurv) P <<= 1;
-  if (P <= p.lds_cap) yl_nms_run<true>(p, lkeys, P, nsurv, b, s_misc);
-  else yl_nms_run<false>(p, p.gkeys + (size_t)b * p.gP, P, nsurv, b, s_misc);
+  // LDS: [lds_cap keys][4 ints]; the key slots beyond P are free -> survivors' boxes in sorted order
+  float4* sbox = reinterpret_cast<float4*>(lkeys + P);
+  if (P <= p.lds_cap) {
+    if ((size_t)P * 8 + (size_t)nsurv * 16 <= (size_t)p.lds_cap * 8) yl_nms_run<true, true>(p, lkeys, P, nsurv, b, s_misc, sbox);
+    else yl_nms_run<true, false>(p, lkeys, P, nsurv, b, s_misc, nullptr);
+  } else {
+    yl_nms_run<false, false>(p, p.gkeys + (size_t)b * p.gP, P, nsurv, b, s_misc, nullptr);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
