@@ -86,7 +86,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    force_coll = os.environ.get("YL_BENCH_FORCE_COLLECTIVE") == "1"      # test hook: collective path at world 1
+    if world > 1 or force_coll:
         dist.init_process_group("nccl", device_id=dev)
 
     import yololite_amd as ya
@@ -110,8 +111,8 @@ def main():
 
     def step():
         ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out, out=(dets, counts))
-        if world > 1:
-            return ydist.allgather_dets(dets, counts, B * world)
+        if world > 1 or force_coll:
+            return ydist.allgather_dets(dets, counts, B * world, force=force_coll)
         return dets, counts
 
     # ---- per-layer durations (HIP events on the launch stream), eager launches
@@ -198,7 +199,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(meta, sd, S, args.conf, args.iou)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 

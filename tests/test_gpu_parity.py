@@ -285,3 +285,31 @@ def test_predict_fused_equals_forward_plus_postprocess_and_graph():
         for b in range(4):
             assert torch.equal(d1[b, :int(c1[b])], d3[b, :int(c3[b])])
     ctx.set_option("graph", 0)
+
+
+def test_cli_infer_and_evaluate(tmp_path, golden_dir):
+    """tools/infer.py and tools/evaluate.py (reference CLI surface) end to end on the tiny golden checkpoint."""
+    import subprocess, sys
+    from PIL import Image
+    z = np.load(os.path.join(golden_dir, "infer_main.npz"))
+    with open(os.path.join(golden_dir, "infer_main_meta.json")) as f:
+        meta = json.load(f)
+    ck = str(tmp_path / "tiny.pt")
+    torch.save({"state_dict": {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, "meta": meta}, ck)
+    (tmp_path / "imgs").mkdir()
+    for name in ("sq", "wide"):
+        Image.fromarray(z[f"img_{name}"][..., ::-1]).save(str(tmp_path / "imgs" / f"{name}.png"))
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "infer.py"), "--weights", ck, "--img_dir",
+                        str(tmp_path / "imgs"), "--save_txt"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for name in ("sq", "wide"):
+        with open(tmp_path / "runs" / "infer" / "1" / "json" / f"{name}.json") as f:
+            dets = json.load(f)["detections"]
+        assert [d["class_id"] for d in dets] == z[f"{name}/class_id"].tolist()
+        np.testing.assert_array_equal(np.rint([d["bbox_xyxy"] for d in dets]), np.rint(z[f"{name}/bbox_xyxy"]))
+        assert (tmp_path / "runs" / "infer" / "1" / "labels" / f"{name}.txt").exists()
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "evaluate.py"), "--weights", ck, "--test_folder",
+                        str(tmp_path / "imgs"), "--batch_size", "2"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.splitlines()[0])["detections"] > 0

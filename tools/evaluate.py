@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""CLI with the reference's tools/evaluate.py surface (/root/reference/tools/evaluate.py:37-79) for
+the part of evaluate_model that is on the hot path (/root/reference/scripts/helpers/evaluate.py:421-429,
+253-303): batched forward -> _decode_batch_to_coco_dets(conf 0.001, iou 0.65) -> detections JSON, plus
+the forward-only latency bench (2 warm-up + 10 timed batches, ms/img = sum ms / sum images).
+COCOeval / curves / confusion matrix / summary image are unchanged CPU consumers of the detections
+list and are out of scope.
+
+    python tools/evaluate.py --weights W.pt --test_folder D [--img_size S] [--batch_size 8] [--device 0]
+D holds images/ (or the images directly); labels are not needed for this part."""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--weights", required=True)
+    ap.add_argument("--test_folder", required=True)
+    ap.add_argument("--img_size", type=int, default=0)
+    ap.add_argument("--device", default="0")
+    ap.add_argument("--batch_size", type=int, default=8)
+    ap.add_argument("--no_letterbox", action="store_true")
+    ap.add_argument("--out", default="runs/evaluate")
+    args = ap.parse_args()
+
+    import yololite_amd as ya
+    from yololite_amd.api import preprocess_bgr
+    from tools.infer import imread_bgr, next_run_dir
+    device = torch.device(f"cuda:{int(args.device)}")
+    model, names, meta_img_size = ya.load_model_names_imgsize_from_ckpt(args.weights, device)
+    S = int(args.img_size) if int(args.img_size) > 0 else int(meta_img_size)
+    root = Path(args.test_folder)
+    img_dir = root / "images" if (root / "images").exists() else root
+    paths = sorted(str(p) for p in img_dir.glob("*") if p.suffix.lower() in (".jpg", ".jpeg", ".png", ".bmp"))
+    if not paths:
+        raise ValueError(f"no images under {img_dir}")
+    run_dir = next_run_dir(args.out)
+    coco_dets, fwd_ms, fwd_imgs = [], [], 0
+    for i in range(0, len(paths), args.batch_size):
+        chunk = paths[i:i + args.batch_size]
+        xs = []
+        for p in chunk:
+            im = imread_bgr(p)
+            xs.append(preprocess_bgr(im, S)[0])
+        x = torch.from_numpy(np.stack(xs)).to(device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        preds = model(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if i // args.batch_size >= 2 and len(fwd_ms) < 10:          # evaluate.py:253-303 protocol
+            fwd_ms.append((t1 - t0) * 1e3); fwd_imgs += len(chunk)
+        dets = ya._decode_batch_to_coco_dets(preds, S, conf_th=0.001, iou_th=0.65, add_one=True)
+        for j, dl in enumerate(dets):
+            for d in dl:
+                coco_dets.append(dict(d, image_id=i + j, file_name=os.path.basename(chunk[j])))
+    with open(Path(run_dir) / "detections.json", "w") as f:
+        json.dump(coco_dets, f)
+    summary = {"images": len(paths), "detections": len(coco_dets), "img_size": S,
+               "gpu_forward_ms_per_img": (sum(fwd_ms) / fwd_imgs) if fwd_imgs else None}
+    with open(Path(run_dir) / "summary.json", "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps(summary))
+    print(f"saved to {run_dir}")
+
+
+if __name__ == "__main__":
+    main()

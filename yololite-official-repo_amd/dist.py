@@ -21,11 +21,12 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allgather_dets(dets: torch.Tensor, counts: torch.Tensor, total: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+def allgather_dets(dets: torch.Tensor, counts: torch.Tensor, total: int, group=None,
+                   force: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """dets [b_local,max_out,6], counts [b_local] of this rank's shard -> ([total,max_out,6], [total]) in image
     order on every rank.  Shards may differ by one image; they are padded to the largest shard for a single
     all_gather_into_tensor of a packed buffer (dets rows and the count travel together)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return dets, counts
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     max_out = dets.shape[1]
