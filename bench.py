@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-dw", default="auto", help="auto | 1 | 0: fuse depthwise convs into the following 1x1 conv")
     ap.add_argument("--fuse-stem", type=int, default=1, help="fused stem+blocks.0 entry kernel")
+    ap.add_argument("--streams", type=int, default=2, help="internal streams the batch is split over")
     ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
     args = ap.parse_args()
@@ -104,6 +105,7 @@ def main():
     ctx, prog = model._ctx_for(S), model.program
     if args.tile_m:
         ctx.set_option("tile_m", args.tile_m)
+    ctx.set_option("streams", args.streams)
     x = synth_images(B, S, seed=1234 + rank).to(dev)
     max_out = 300                                        # packed result rows per image
     dets = torch.empty((B, max_out, 6), device=dev, dtype=torch.float32)
@@ -184,7 +186,7 @@ def main():
                                    f"(conf {args.conf}, iou {args.iou}), input resident in HBM"
                                    + (", + RCCL all-gather of packed dets" if world > 1 else ""),
                        "global_batch": B * world, "img_size": S, "parallelism": f"dp{world} (batch sharded, weights replicated)",
-                       "hipgraph": bool(args.graph), "mean_dets_per_image": round(ndet, 1)},
+                       "hipgraph": bool(args.graph), "streams": args.streams, "mean_dets_per_image": round(ndet, 1)},
             "roofline": roof,
             "network": {"conv_gflop_per_image": round(2.0 * prog.macs / 1e9, 4), "launches": len(prog.layers),
                         "forward_ms_sum_of_layers": round(fwd_ms, 4),

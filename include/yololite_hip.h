@@ -153,7 +153,8 @@ yl_status yl_forward_timed(yl_ctx* ctx, const float* x_dev, int32_t batch, float
                            void* stream, float* layer_ms);
 /* Copies activation slot `slot` (NHWC fp32, [B,h,w,c]) of the last forward to dst_dev (testing aid). */
 yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev, void* stream);
-/* Options: "graph" (0/1: replay the forward from a captured hipGraph), "tile_m" (conv M-tile hint) */
+/* Options: "graph" (0/1: replay the whole call from a captured hipGraph), "streams" (1..4 internal
+ * streams the batch is split over; default 2), "tile_m" (conv M-tile hint) */
 yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
 
 /* ---- decode -----------------------------------------------------------------------------------

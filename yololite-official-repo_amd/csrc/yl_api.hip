@@ -4,6 +4,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
+#include <stddef.h>
 #include <string.h>
 
 #include <string>
@@ -58,12 +59,14 @@ struct yl_ctx {
   unsigned long long* ws_nms_gkeys = nullptr;
   int nms_gP = 0;
   // options
-  int opt_graph = 0, opt_tile_m = 0;
+  int opt_graph = 0, opt_tile_m = 0, opt_streams = 2;
+  // batch chunks run on `opt_streams` internal streams (fork/join around every call): the
+  // latency-bound low-resolution layers of one chunk overlap the bandwidth-bound layers of another
+  hipStream_t work[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  // single-entry hipGraph cache keyed on everything baked into the captured launches
   hipGraphExec_t graph_exec = nullptr;
-  int graph_batch = 0;
-  const float* graph_x = nullptr;
-  float* graph_out[YL_MAX_LEVELS] = {nullptr};
-  hipStream_t graph_stream = nullptr;
+  std::vector<unsigned char> graph_key;
   std::string err;
 };
 
@@ -147,7 +150,7 @@ void free_post_ws(yl_ctx* c) {
 void drop_graph(yl_ctx* c) {
   if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
   c->graph_exec = nullptr;
-  c->graph_batch = 0;
+  c->graph_key.clear();
 }
 
 void free_act(yl_ctx* c) {
@@ -203,7 +206,8 @@ void fill_levels(const yl_ctx* c, const float* const* ptrs, YlLevels& lv) {
 }
 
 // builds the kernel parameter block of layer i for batch B
-void layer_params(const yl_ctx* c, const DevLayer& L, int B, const float* x, float* const* level_out, YlConvP& p) {
+void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float* x, float* const* level_out,
+                  YlConvP& p) {
   memset(&p, 0, sizeof(p));
   const yl_layer& d = L.d;
   p.wp = L.wp; p.bias = L.bias; p.dw_w = L.dw_w; p.dw_b = L.dw_b;
@@ -217,7 +221,8 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int B, const float* x, flo
   p.TK = d.k * d.k * p.KB;
   p.NTtot = cdiv(d.cout, 16);
   p.M = B * L.out_h * L.out_w;
-  p.x = (d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? x : c->slots[d.in_slot].ptr;
+  auto slot_ptr = [&](int sl) { const Slot& t = c->slots[sl]; return t.ptr + (size_t)b0 * t.h * t.w * t.c; };
+  p.x = (d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? x + (size_t)b0 * 3 * L.in_h * L.in_w : slot_ptr(d.in_slot);
   if (d.op == YL_OP_STEMBLOCK) {
     p.w2p = L.w2p; p.b2 = L.b2; p.w3p = L.w3p; p.b3 = L.b3;
     p.C1 = d.cout; p.C2 = d.c2; p.C3 = d.c3; p.act2 = d.act2; p.act3 = d.act3;
@@ -226,28 +231,28 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int B, const float* x, flo
     p.ntiles = B * p.tiles_x * p.tiles_y;
     p.N = d.c3 > 0 ? d.c3 : d.c2;
   }
-  if (d.res_slot >= 0) p.res = c->slots[d.res_slot].ptr;
+  if (d.res_slot >= 0) p.res = slot_ptr(d.res_slot);
   if (d.up_slot >= 0) {
-    p.up = c->slots[d.up_slot].ptr;
+    p.up = slot_ptr(d.up_slot);
     p.UH = c->slots[d.up_slot].h; p.UW = c->slots[d.up_slot].w;
   }
   if (d.head_level >= 0) {
     const int l = d.head_level;
     const int ss = c->level_S[l] * c->level_S[l];
-    p.out = level_out[l] + (size_t)L.head_anchor * ss * c->E;
     p.out_bstride = (long)c->level_A[l] * ss * c->E;
+    p.out = level_out[l] + (size_t)b0 * p.out_bstride + (size_t)L.head_anchor * ss * c->E;
   } else {
-    p.out = c->slots[d.out_slot].ptr;
+    p.out = slot_ptr(d.out_slot);
     p.out_bstride = (long)L.out_h * L.out_w * d.cout;
   }
 }
 
-yl_status run_layers(yl_ctx* c, const float* x, int B, float* const* level_out, hipStream_t st,
+yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* level_out, hipStream_t st,
                      hipEvent_t* evs /*nullable: num_layers+1 events*/) {
   if (evs) HIPCHK(c, hipEventRecord(evs[0], st));
   for (size_t i = 0; i < c->layers.size(); ++i) {
     YlConvP p;
-    layer_params(c, c->layers[i], B, x, level_out, p);
+    layer_params(c, c->layers[i], b0, B, x, level_out, p);
     hipError_t e;
     switch (c->layers[i].d.op) {
       case YL_OP_STEM: e = yl_launch_stem(p, st); break;
@@ -274,31 +279,111 @@ yl_status check_cfg(yl_ctx* c, const yl_post_cfg* cfg) {
   return YL_OK;
 }
 
-yl_status do_post(yl_ctx* c, const float* const* levels, int B, const yl_post_cfg* cfg, float* dets, int* counts,
-                  int* keep_idx, hipStream_t st) {
-  yl_status s = ensure_post(c, B);
-  if (s != YL_OK) return s;
+// post-processing of images [b0, b0+B) of a batch (workspaces must already cover b0+B images)
+yl_status do_post(yl_ctx* c, const float* const* levels_all, int b0, int B, const yl_post_cfg* cfg, float* dets,
+                  int* counts, int* keep_idx, hipStream_t st) {
+  const float* levels[YL_MAX_LEVELS];
+  for (int l = 0; l < c->L; ++l)
+    levels[l] = levels_all[l] + (size_t)b0 * c->level_A[l] * c->level_S[l] * c->level_S[l] * c->E;
+  const size_t o = (size_t)b0 * c->N;
   YlLevels lv;
   fill_levels(c, levels, lv);
   YlDecodeP dp;
   dp.mode = cfg->mode; dp.center_mode = cfg->center_mode; dp.wh_mode = cfg->wh_mode;
-  dp.boxes = c->ws_boxes; dp.scores = c->ws_scores; dp.cls = c->ws_cls;
+  dp.boxes = c->ws_boxes + o; dp.scores = c->ws_scores + o; dp.cls = c->ws_cls + o;
   HIPCHK(c, yl_launch_decode_score(lv, B, dp, st));
   YlNmsP np;
   memset(&np, 0, sizeof(np));
-  np.boxes = c->ws_boxes; np.scores = c->ws_scores; np.cls = c->ws_cls;
+  np.boxes = c->ws_boxes + o; np.scores = c->ws_scores + o; np.cls = c->ws_cls + o;
   np.N = c->N; np.C = c->C > 0 ? c->C : 1;
   np.conf_thr = cfg->conf_thr; np.iou_thr = cfg->iou_thr;
   np.impl = (cfg->mode == YL_POST_FALLBACK) ? YL_NMS_GREEDY : YL_NMS_TORCHVISION;
   np.cap = (cfg->per_class_cap > 0) ? cfg->per_class_cap : INT_MAX;
   np.topk = (cfg->mode == YL_POST_FALLBACK && cfg->topk > 0) ? cfg->topk : 0;
   np.max_out = cfg->max_out;
-  np.cls_ws = c->ws_clsws;
-  np.gkeys = c->ws_gkeys; np.gP = c->gP;
+  np.cls_ws = c->ws_clsws + (size_t)b0 * 4 * np.C;
+  np.gkeys = c->ws_gkeys ? c->ws_gkeys + (size_t)b0 * c->gP : nullptr; np.gP = c->gP;
   np.lds_cap = c->gP < YL_LDS_KEYS_MAX ? c->gP : YL_LDS_KEYS_MAX;
-  np.dets = dets; np.counts = counts; np.keep_idx = keep_idx; np.backmap = cfg->backmap_dev;
-  np.tmp_dets = c->ws_tmp_dets; np.tmp_idx = c->ws_tmp_idx;
+  np.dets = dets + (size_t)b0 * cfg->max_out * 6; np.counts = counts + b0;
+  np.keep_idx = keep_idx ? keep_idx + (size_t)b0 * cfg->max_out : nullptr;
+  np.backmap = cfg->backmap_dev ? cfg->backmap_dev + (size_t)b0 * 5 : nullptr;
+  np.tmp_dets = c->ws_tmp_dets + o * 6; np.tmp_idx = c->ws_tmp_idx + o;
   HIPCHK(c, yl_launch_nms(np, B, st));
+  return YL_OK;
+}
+
+struct Job {
+  const float* x = nullptr;          // nullptr: no forward (post-processing of caller levels only)
+  int B = 0;
+  float* outs[YL_MAX_LEVELS] = {nullptr};
+  const yl_post_cfg* cfg = nullptr;  // nullptr: forward only
+  float* dets = nullptr;
+  int* counts = nullptr;
+  int* keep_idx = nullptr;
+};
+
+yl_status run_chunk(yl_ctx* c, const Job& j, int b0, int bn, hipStream_t st) {
+  yl_status s = YL_OK;
+  if (j.x) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr);
+  if (s == YL_OK && j.cfg) s = do_post(c, j.outs, b0, bn, j.cfg, j.dets, j.counts, j.keep_idx, st);
+  return s;
+}
+
+// enqueue a job on `st`, split into chunks over the internal worker streams (fork/join with events; the
+// same call sequence is legal inside a stream capture, where it becomes parallel graph branches)
+yl_status enqueue(yl_ctx* c, const Job& j, hipStream_t st) {
+  int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
+  if (j.B < 4 * n) n = 1;
+  if (n == 1) return run_chunk(c, j, 0, j.B, st);
+  if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  for (int i = 1; i < n; ++i) {
+    if (!c->work[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));
+    if (!c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+  }
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));
+  yl_status s = YL_OK;
+  const int base = j.B / n, rem = j.B % n;
+  int b0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const int bn = base + (i < rem ? 1 : 0);
+    hipStream_t ws = (i == 0) ? st : c->work[i];
+    if (i > 0) HIPCHK(c, hipStreamWaitEvent(ws, c->ev_fork, 0));
+    if (s == YL_OK) s = run_chunk(c, j, b0, bn, ws);
+    if (i > 0) {
+      HIPCHK(c, hipEventRecord(c->ev_join[i], ws));
+      HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
+    }
+    b0 += bn;
+  }
+  return s;
+}
+
+// run a job eagerly or by replaying a cached hipGraph of exactly this job
+yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
+  if (!c->opt_graph) return enqueue(c, j, st);
+  std::vector<unsigned char> key(sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), 0);
+  memcpy(key.data(), &j, sizeof(Job));
+  if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
+  memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &c->opt_streams, sizeof(int));
+  memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
+  // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
+  memset(key.data() + offsetof(Job, cfg), 0, sizeof(void*));
+  if (!c->graph_exec || key != c->graph_key) {
+    drop_graph(c);
+    hipStream_t cs;
+    HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipGraph_t g = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    yl_status s = enqueue(c, j, cs);
+    hipError_t e = hipStreamEndCapture(cs, &g);
+    if (s == YL_OK && e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+    if (g) hipGraphDestroy(g);
+    hipStreamDestroy(cs);
+    if (s != YL_OK) return s;
+    HIPCHK(c, e);
+    c->graph_key = key;
+  }
+  HIPCHK(c, hipGraphLaunch(c->graph_exec, st));
   return YL_OK;
 }
 
@@ -331,6 +416,11 @@ void yl_destroy(yl_ctx* c) {
   free_post_ws(c);
   hipFree(c->ws_nms_clsws);
   hipFree(c->zeros);
+  for (int i = 0; i < 4; ++i) {
+    if (c->work[i]) hipStreamDestroy(c->work[i]);
+    if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
   hipFree(c->ws_nms_gkeys);
   for (auto& L : c->layers) {
     hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b);
@@ -510,23 +600,26 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }
   return fail(c, YL_ERR_INVALID, std::string("unknown option ") + name);
 }
 
 static yl_status forward_impl(yl_ctx* c, const float* x, int B, float* const* level_out, hipStream_t st,
-                              float* layer_ms) {
+                              float* layer_ms, const yl_post_cfg* cfg, float* dets, int* counts) {
   if (!c) return YL_ERR_INVALID;
   if (c->layers.empty()) return fail(c, YL_ERR_STATE, "context was created without layers");
   if (!x || B < 1) return fail(c, YL_ERR_INVALID, "bad input");
   HIPCHK(c, hipSetDevice(c->device));
   yl_status s = ensure_act(c, B);
   if (s != YL_OK) return s;
-  float* outs[YL_MAX_LEVELS];
-  for (int l = 0; l < c->L; ++l) outs[l] = (level_out && level_out[l]) ? level_out[l] : c->level_buf[l];
-  if (layer_ms) {
+  if (cfg && (s = ensure_post(c, B)) != YL_OK) return s;
+  Job j;
+  j.x = x; j.B = B; j.cfg = cfg; j.dets = dets; j.counts = counts;
+  for (int l = 0; l < c->L; ++l) j.outs[l] = (level_out && level_out[l]) ? level_out[l] : c->level_buf[l];
+  if (layer_ms) {        // measurement path: one stream, one chunk, an event pair around every launch
     std::vector<hipEvent_t> ev(c->layers.size() + 1);
     for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
-    s = run_layers(c, x, B, outs, st, ev.data());
+    s = run_layers(c, x, 0, B, j.outs, st, ev.data());
     if (s == YL_OK) {
       HIPCHK(c, hipStreamSynchronize(st));
       for (size_t i = 0; i < c->layers.size(); ++i) hipEventElapsedTime(&layer_ms[i], ev[i], ev[i + 1]);
@@ -534,39 +627,17 @@ static yl_status forward_impl(yl_ctx* c, const float* x, int B, float* const* le
     for (auto& e : ev) hipEventDestroy(e);
     return s;
   }
-  if (c->opt_graph) {
-    bool same = c->graph_exec && c->graph_batch == B && c->graph_x == x;
-    for (int l = 0; same && l < c->L; ++l) same = (c->graph_out[l] == outs[l]);
-    if (!same) {
-      drop_graph(c);
-      hipStream_t cs;
-      HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-      hipGraph_t g = nullptr;
-      HIPCHK(c, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-      s = run_layers(c, x, B, outs, cs, nullptr);
-      hipError_t e = hipStreamEndCapture(cs, &g);
-      if (s == YL_OK && e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
-      if (g) hipGraphDestroy(g);
-      hipStreamDestroy(cs);
-      if (s != YL_OK) return s;
-      HIPCHK(c, e);
-      c->graph_batch = B; c->graph_x = x;
-      for (int l = 0; l < c->L; ++l) c->graph_out[l] = outs[l];
-    }
-    HIPCHK(c, hipGraphLaunch(c->graph_exec, st));
-    return YL_OK;
-  }
-  return run_layers(c, x, B, outs, st, nullptr);
+  return submit(c, j, st);
 }
 
 yl_status yl_forward(yl_ctx* c, const float* x, int32_t B, float* const* level_out, void* stream) {
-  return forward_impl(c, x, B, level_out, (hipStream_t)stream, nullptr);
+  return forward_impl(c, x, B, level_out, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 yl_status yl_forward_timed(yl_ctx* c, const float* x, int32_t B, float* const* level_out, void* stream,
                            float* layer_ms) {
   if (!layer_ms) return YL_ERR_INVALID;
-  return forward_impl(c, x, B, level_out, (hipStream_t)stream, layer_ms);
+  return forward_impl(c, x, B, level_out, (hipStream_t)stream, layer_ms, nullptr, nullptr, nullptr);
 }
 
 yl_status yl_read_slot(yl_ctx* c, int32_t slot, int32_t B, float* dst, void* stream) {
@@ -598,7 +669,11 @@ yl_status yl_postprocess(yl_ctx* c, const float* const* levels, int32_t B, const
   yl_status s = check_cfg(c, cfg);
   if (s != YL_OK) return s;
   HIPCHK(c, hipSetDevice(c->device));
-  return do_post(c, levels, B, cfg, dets, counts, keep_idx, (hipStream_t)stream);
+  if ((s = ensure_post(c, B)) != YL_OK) return s;
+  Job j;
+  j.B = B; j.cfg = cfg; j.dets = dets; j.counts = counts; j.keep_idx = keep_idx;
+  for (int l = 0; l < c->L; ++l) j.outs[l] = const_cast<float*>(levels[l]);
+  return enqueue(c, j, (hipStream_t)stream);
 }
 
 yl_status yl_predict(yl_ctx* c, const float* x, int32_t B, const yl_post_cfg* cfg, float* dets, int32_t* counts,
@@ -606,9 +681,7 @@ yl_status yl_predict(yl_ctx* c, const float* x, int32_t B, const yl_post_cfg* cf
   if (!c || !dets || !counts) return YL_ERR_INVALID;
   yl_status s = check_cfg(c, cfg);
   if (s != YL_OK) return s;
-  s = forward_impl(c, x, B, nullptr, (hipStream_t)stream, nullptr);
-  if (s != YL_OK) return s;
-  return do_post(c, c->level_buf, B, cfg, dets, counts, nullptr, (hipStream_t)stream);
+  return forward_impl(c, x, B, nullptr, (hipStream_t)stream, nullptr, cfg, dets, counts);
 }
 
 yl_status yl_nms(yl_ctx* c, const float* boxes, const float* scores, int32_t n, float iou_thr, int32_t impl,
