@@ -714,6 +714,14 @@ hipError_t yl_conv_init() {
 }
 
 template <int NT>
+static int yl_dwh_resident(const YlConvP& p, size_t lds) {
+  if (p.dw_k == 3 && p.dw_stride == 1) return yl_resident_blocks(yl_conv_dwh_kernel<NT, 3, 1>, lds);
+  if (p.dw_k == 3 && p.dw_stride == 2) return yl_resident_blocks(yl_conv_dwh_kernel<NT, 3, 2>, lds);
+  if (p.dw_k == 5 && p.dw_stride == 1) return yl_resident_blocks(yl_conv_dwh_kernel<NT, 5, 1>, lds);
+  return yl_resident_blocks(yl_conv_dwh_kernel<NT, 5, 2>, lds);
+}
+
+template <int NT>
 static bool yl_dwh_go(const YlConvP& p, dim3 grid, size_t lds, hipStream_t st) {
   if (p.dw_k == 3 && p.dw_stride == 1) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 3, 1>), grid, dim3(256), lds, st, p);
   else if (p.dw_k == 3 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 3, 2>), grid, dim3(256), lds, st, p);
@@ -721,6 +729,36 @@ static bool yl_dwh_go(const YlConvP& p, dim3 grid, size_t lds, hipStream_t st) {
   else if (p.dw_k == 5 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 5, 2>), grid, dim3(256), lds, st, p);
   else return false;
   return true;
+}
+
+// persistent grids are sized to what is co-resident (blocks/CU from the occupancy query x 256 CUs): a
+// block that has to queue behind another one re-stages the whole weight chunk into LDS for nothing
+template <typename K>
+static int yl_resident_blocks(K kernel, size_t lds) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, 256, lds) != hipSuccess || nb < 1) nb = 1;
+  if (nb > 4) nb = 4;
+  return nb * YL_NUM_CU;
+}
+
+template <int NT, int MT>
+static int yl_conv_resident(int mode, size_t lds) {
+  if (mode == YL_CM_PW) return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_PW>, lds);
+  if (mode == YL_CM_KXK) return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_KXK>, lds);
+  if (mode == YL_CM_DW3) return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_DW3>, lds);
+  if (mode == YL_CM_DW5) return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_DW5>, lds);
+  return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_DWPRO>, lds);
+}
+template <int MT>
+static int yl_conv_resident_nt(int NT, int mode, size_t lds) {
+  switch (NT) {
+    case 1: return yl_conv_resident<1, MT>(mode, lds);
+    case 2: return yl_conv_resident<2, MT>(mode, lds);
+    case 3: return yl_conv_resident<3, MT>(mode, lds);
+    case 4: return yl_conv_resident<4, MT>(mode, lds);
+    case 6: return yl_conv_resident<6, MT>(mode, lds);
+    default: return yl_conv_resident<8, MT>(mode, lds);
+  }
 }
 
 template <int NT, int MT>
@@ -768,7 +806,16 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
     const size_t lds = (size_t)p.KB * NT * 1024 + (size_t)(p.dw_k * p.dw_k + 1) * p.Cin * 4 + (size_t)4 * HP * PITCH * 64;
     if (lds <= YL_DWH_LDS_MAX) {
       const long wtiles = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
-      int gx = (4 * YL_NUM_CU) / gy;
+      int res = 0;
+      switch (NT) {
+        case 1: res = yl_dwh_resident<1>(p, lds); break;
+        case 2: res = yl_dwh_resident<2>(p, lds); break;
+        case 3: res = yl_dwh_resident<3>(p, lds); break;
+        case 4: res = yl_dwh_resident<4>(p, lds); break;
+        case 6: res = yl_dwh_resident<6>(p, lds); break;
+        default: res = yl_dwh_resident<8>(p, lds); break;
+      }
+      int gx = res / gy;
       if (gx < 8) gx = 8;
       gx &= ~7;
       if (gx > (wtiles + 3) / 4) gx = (int)((wtiles + 3) / 4);
@@ -799,12 +846,13 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
   if ((size_t)p.TK * step_bytes <= budget) p.CH = p.TK;                // whole K resident
   else p.CH = (int)((budget < 48 * 1024 ? budget : 48 * 1024) / step_bytes);   // stream K in chunks
   const size_t lds = (size_t)p.CH * step_bytes + extra;
-  int gx = (4 * YL_NUM_CU) / gy;
+  const int mode = p.dw_k == 3 ? YL_CM_DW3 : p.dw_k == 5 ? YL_CM_DW5 : p.dw_k > 0 ? YL_CM_DWPRO
+                   : ((p.k == 1 && p.stride == 1) ? YL_CM_PW : YL_CM_KXK);
+  const int res = (MT == 2) ? yl_conv_resident_nt<2>(NT, mode, lds) : yl_conv_resident_nt<1>(NT, mode, lds);
+  int gx = res / gy;
   if (gx < 8) gx = 8;
   gx &= ~7;                         // multiple of 8: N-chunks of one M tile land on the same XCD/L2
   if (gx > p.ntiles) gx = p.ntiles;
-  const int mode = p.dw_k == 3 ? YL_CM_DW3 : p.dw_k == 5 ? YL_CM_DW5 : p.dw_k > 0 ? YL_CM_DWPRO
-                   : ((p.k == 1 && p.stride == 1) ? YL_CM_PW : YL_CM_KXK);
   dim3 grid(gx, gy);
   if (MT == 2) yl_conv_go_nt<2>(p, NT, mode, grid, lds, st);
   else yl_conv_go_nt<1>(p, NT, mode, grid, lds, st);
