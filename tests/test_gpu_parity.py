@@ -313,3 +313,27 @@ def test_cli_infer_and_evaluate(tmp_path, golden_dir):
                         str(tmp_path / "imgs"), "--batch_size", "2"], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.splitlines()[0])["detections"] > 0
+
+
+def test_class_argmax_ties_match_torch_first_max():
+    """score/class selection on logits built to tie in the sigmoid domain: saturation (> 17 -> 1.0),
+    near-saturation neighbours, underflow (< -104 -> 0.0), subnormal range, exact duplicates."""
+    C = 12
+    rows = []
+    def row(cls, obj=3.0):
+        return [0.1, -0.2, 0.3, 0.2, obj] + list(cls)
+    rows.append(row([18.0, 25.0, 30.0] + [-5.0] * 9))                       # all 1.0f: first wins (index 0)
+    rows.append(row([-3.0, 14.2, 14.21, 14.2] + [0.0] * 8))                 # near saturation, may round equal
+    rows.append(row([-200.0] * 5 + [-150.0] + [-300.0] * 6))                # all exactly 0.0: index 0
+    rows.append(row([-103.9, -103.2, -103.5] + [-120.0] * 9))               # subnormal spacing
+    rows.append(row([1.25, 2.5, 2.5, 0.0, 2.5] + [-1.0] * 7))               # exact duplicates: first of them
+    rows.append(row([9.99, 10.0, 10.000001, 9.999999] + [3.0] * 8))
+    rng = np.random.RandomState(0)
+    for _ in range(58):
+        base = rng.randn(C).astype(np.float32) * 6
+        rows.append(row(base))
+    lv = torch.tensor(rows, dtype=torch.float32).reshape(1, 1, 8, 8, 5 + C)
+    exp = opost.pipeline_main([lv], 64, conf=-1.0, iou=1.0, per_class_cap=300)
+    got = ya.infer_main_postprocess([lv.to(DEV)], 64, conf=-1.0, iou=1.0, per_class_cap=300)
+    assert got["classes"][0].tolist() == exp["classes"][0].tolist()
+    np.testing.assert_allclose(got["scores"][0], exp["scores"][0], rtol=1e-6, atol=1e-7)

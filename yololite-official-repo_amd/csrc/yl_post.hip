@@ -133,10 +133,24 @@ __global__ __launch_bounds__(128) void yl_decode_score_kernel(YlLevels lv, int B
   int ci = 0;
   const int C = lv.C;
   if (C > 1) {
-    float best = yl_sigmoid(row[5]);
-    for (int c = 1; c < C; ++c) {                 // first maximum wins, like torch.max(dim)
-      const float s = yl_sigmoid(row[5 + c]);
-      if (s > best) { best = s; ci = c; }
+    // reference: (conf, idx) = sigmoid(cls).max(-1), first maximum wins.  sigmoid is monotonic, so
+    // conf = sigmoid(max logit); the index can only differ from the logit arg-max when an EARLIER class
+    // has a (slightly) smaller logit whose sigmoid rounds to the same float (saturation / <1 ulp):
+    // only those candidates get their own sigmoid.  1-2 expf per candidate instead of C.
+    float lmax = row[5];
+    for (int c = 1; c < C; ++c) {
+      const float l = row[5 + c];
+      if (l > lmax) { lmax = l; ci = c; }
+    }
+    const float best = yl_sigmoid(lmax);
+    // logits whose sigmoid can round to `best`: within 1e-3 relative of lmax; anything above 10 when the
+    // result is near saturation (float spacing below 1.0 is 6e-8 = e^-16.6); everything when `best` is
+    // subnormal or zero (coarse spacing / underflow of 1/(1+inf))
+    const float band = lmax - 1e-3f * (1.0f + fabsf(lmax));
+    const bool wide = best < 1.2e-38f;
+    for (int c = 0; c < ci; ++c) {
+      const float l = row[5 + c];
+      if ((wide || l >= band || l > 10.0f) && yl_sigmoid(l) == best) { ci = c; break; }
     }
     score = obj * best;
   } else if (C == 1 && p.mode == YL_POST_FALLBACK) {
