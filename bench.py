@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-dw", default="auto", help="auto | 1 | 0: fuse depthwise convs into the following 1x1 conv")
     ap.add_argument("--fuse-stem", type=int, default=1, help="fused stem+blocks.0 entry kernel")
+    ap.add_argument("--fuse-uib", type=int, default=0, help="whole inverted-residual blocks as one launch")
     ap.add_argument("--streams", type=int, default=2, help="internal streams the batch is split over")
     ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
@@ -102,7 +103,7 @@ def main():
     meta = zoo_meta(args.model, 80, S)
     sd = synth_state_dict(meta, seed=0, head_noise=2.0)
     model = ya.build_model_from_meta(meta, fuse_dw=(args.fuse_dw if args.fuse_dw in ("auto", "dw3") else bool(int(args.fuse_dw))),
-                                     fuse_stem=bool(args.fuse_stem))
+                                     fuse_stem=bool(args.fuse_stem), fuse_uib=bool(args.fuse_uib))
     model.load_state_dict(sd)
     model.to(dev)
     ctx, prog = model._ctx_for(S), model.program

@@ -80,8 +80,12 @@ typedef struct {
   const float* b;             /* [cout] or NULL                                                   */
   const float* dw_w;          /* [cin][1][dw_k][dw_k] or NULL                                     */
   const float* dw_b;          /* [cin] or NULL                                                    */
-  /* YL_OP_STEMBLOCK only (0 / NULL otherwise): second and optional third conv of the fused entry block */
-  int32_t c2, act2;           /* 3x3 stride-2 pad-1 conv: [c2][cout][3][3]                        */
+  /* YL_OP_STEMBLOCK: second and optional third conv of the fused entry block.
+   * YL_OP_CONV with c2 > 0: fused inverted-residual block -- in_slot has c2 channels, w2/b2/act2 is the 1x1
+   * EXPANSION [cin][c2][1][1] applied first, then the depthwise prologue (dw_*, stride 1) on the cin expanded
+   * channels, then the 1x1 projection (w,b,act,res_slot); the expanded tensor never reaches HBM.
+   * 0 / NULL otherwise. */
+  int32_t c2, act2;           /* STEMBLOCK: 3x3 stride-2 pad-1 conv [c2][cout][3][3]              */
   int32_t c3, act3;           /* 1x1 conv: [c3][c2][1][1]; c3 = 0 -> absent                       */
   const float* w2;
   const float* b2;

@@ -29,8 +29,8 @@ def _oracle_for(meta, sd):
     return m
 
 
-def _hip_for(meta, sd, fuse_dw="auto", fuse_stem=True):
-    m = ya.build_model_from_meta(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem)
+def _hip_for(meta, sd, fuse_dw="auto", fuse_stem=True, fuse_uib=False):
+    m = ya.build_model_from_meta(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib)
     m.load_state_dict(sd)
     return m.to(DEV)
 
@@ -74,7 +74,7 @@ def test_forward_tiny_models(idx, fuse):
     x = _x(3, 96, seed=idx)
     with torch.no_grad():
         ref = _oracle_for(meta, sd)(x)
-    m = _hip_for(meta, sd, fuse_dw=fuse, fuse_stem=(fuse != False))
+    m = _hip_for(meta, sd, fuse_dw=fuse, fuse_stem=(fuse != False), fuse_uib=(fuse != True))
     outs = m(x.to(DEV))
     _cmp_levels(outs, ref)
     assert m.get_strides() == _oracle_for(meta, sd).get_strides()
@@ -105,13 +105,16 @@ def test_forward_reference_fixture_weights(golden_dir):
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_n", 2, 640), ("edge_m", 1, 320), ("yololite_m", 1, 256)])
-def test_forward_zoo_models(name, B, S):
+@pytest.mark.parametrize("uib", [False, True])
+def test_forward_zoo_models(name, B, S, uib):
+    """BASELINE configs 2-4 backbones/necks/heads at reduced batch; uib=True also runs the inverted-residual
+    blocks as single fused launches (expand -> depthwise -> project)."""
     meta = zoo_meta(name, 80, S)
     sd = synth_state_dict(meta, seed=0)
     x = _x(B, S)
     with torch.no_grad():
         ref = _oracle_for(meta, sd)(x)
-    outs = _hip_for(meta, sd)(x.to(DEV))
+    outs = _hip_for(meta, sd, fuse_uib=uib)(x.to(DEV))
     _cmp_levels(outs, ref)
 
 

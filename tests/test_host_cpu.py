@@ -61,16 +61,18 @@ def test_product_never_imports_oracle():
 def test_program_edge_n_macs_and_layout():
     """edge_n C=80 640^2 = 0.7964 GMAC over 63 conv layers; fused into 42 launches."""
     meta = zoo_meta("edge_n", 80, 640)
-    p = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=False)
+    p = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=False, fuse_uib=False)
     assert abs(p.macs - 796.39e6) < 0.05e6
     assert p.level_size == [80, 40, 20] and p.level_anchors == [1, 1, 1] and p.strides == [8, 16, 32]
     assert [p.slots[p.feature_slots[k]] for k in ("c3", "c4", "c5")] == [(80, 80, 32), (40, 40, 48), (20, 20, 480)]
     nconv = sum(1 + (l.dw_k > 0) for l in p.layers)     # SURVEY App. A counts the head box/obj/cls convs as one row
     assert nconv == 63
-    p2 = build_program(meta, synth_state_dict(meta), fuse_dw=False, fuse_stem=False)
+    p2 = build_program(meta, synth_state_dict(meta), fuse_dw=False, fuse_stem=False, fuse_uib=False)
     assert len(p2.layers) > len(p.layers) and p2.macs == p.macs
-    p3 = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=True)     # 3 entry convs -> 1 launch
+    p3 = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=True, fuse_uib=False)   # 3 entry convs -> 1 launch
     assert len(p3.layers) == len(p.layers) - 2 and p3.macs == p.macs and p3.layers[0].op == 3
+    p4 = build_program(meta, synth_state_dict(meta), fuse_uib=True)     # + 8 inverted-residual blocks as one launch each
+    assert len(p4.layers) == len(p3.layers) - 8 and p4.macs == p.macs
 
 
 @pytest.mark.parametrize("name,feat", [("edge_m", [(80, 80, 64), (40, 40, 96), (20, 20, 960)]),

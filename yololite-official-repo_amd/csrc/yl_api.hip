@@ -223,6 +223,9 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   p.M = B * L.out_h * L.out_w;
   auto slot_ptr = [&](int sl) { const Slot& t = c->slots[sl]; return t.ptr + (size_t)b0 * t.h * t.w * t.c; };
   p.x = (d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? x + (size_t)b0 * 3 * L.in_h * L.in_w : slot_ptr(d.in_slot);
+  if (d.op == YL_OP_CONV && d.c2 > 0) {      // fused expand -> depthwise -> project
+    p.w2p = L.w2p; p.b2 = L.b2; p.C1 = d.c2; p.act2 = d.act2;
+  }
   if (d.op == YL_OP_STEMBLOCK) {
     p.w2p = L.w2p; p.b2 = L.b2; p.w3p = L.w3p; p.b3 = L.b3;
     p.C1 = d.cout; p.C2 = d.c2; p.C3 = d.c3; p.act2 = d.act2; p.act3 = d.act3;
@@ -496,7 +499,16 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     } else {
       if (l.in_slot < 0 || l.in_slot >= d->num_slots) return bad("bad in_slot");
       L.in_h = c->slots[l.in_slot].h; L.in_w = c->slots[l.in_slot].w;
-      if (c->slots[l.in_slot].c != l.cin) return bad("cin does not match the input slot");
+      const bool uib = (l.op == YL_OP_CONV && l.c2 > 0);
+      if (c->slots[l.in_slot].c != (uib ? l.c2 : l.cin)) return bad("cin does not match the input slot");
+      if (uib) {
+        if (!l.w2 || l.dw_k == 0 || l.dw_stride != 1 || l.k != 1 || l.head_level >= 0 || l.up_slot >= 0)
+          return bad("fused expand->depthwise->project block: needs w2, a stride-1 depthwise prologue, 1x1 projection");
+        if (!yl_uib_supported(l.c2, l.cin, l.cout, l.dw_k))
+          return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block: shape not instantiated / LDS budget exceeded");
+        if ((c->slots[l.in_slot].h & 3) || (c->slots[l.in_slot].w & 3))
+          return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block needs H,W multiples of 4");
+      }
     }
     // output geometry.  Sizes are declared by the host (slot / level dims); pad_t/pad_l are explicit
     // and the bottom/right padding is implied, so only reachability is checked here.
@@ -572,6 +584,13 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       pack_conv(l.w, l.cout, l.cin, l.k, wp);
       bias.assign((size_t)cdiv(l.cout, 16) * 16 + 128, 0.0f);
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
+      if (l.c2 > 0) {       // expansion conv of a fused inverted-residual block: [cin][c2][1][1]
+        std::vector<float> w2, b2v((size_t)cdiv(l.cin, 16) * 16, 0.0f);
+        pack_conv(l.w2, l.cin, l.c2, 1, w2);
+        if (l.b2) memcpy(b2v.data(), l.b2, l.cin * sizeof(float));
+        if ((s = upload(c, w2, &L.w2p)) != YL_OK) return s;
+        if ((s = upload(c, b2v, &L.b2)) != YL_OK) return s;
+      }
       if (l.dw_k > 0) {
         std::vector<float> dw, dwb;
         pack_dw(l.dw_w, l.cin, l.dw_k, dw);

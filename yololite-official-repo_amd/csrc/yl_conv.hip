@@ -542,6 +542,165 @@ __global__ __launch_bounds__(256) void yl_conv_dwh_kernel(YlConvP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole inverted-residual block in ONE launch:  1x1 expand (+BN+act)  ->  depthwise DKxDK s1 (+BN+act)
+// ->  1x1 project (+BN) (+residual).  The expanded tensor (2-6x the block's input) never exists in
+// HBM: per 16-channel slab it is produced by a mini-GEMM on the wave's halo pixels (HM m-tiles of 16
+// pixels: the 4x4 output tile grown by the depthwise reach), written to the wave's LDS patch in exactly
+// the layout the depthwise stage reads (MFMA D fragment = 4 channels of one pixel), consumed by the
+// tap FMAs, and fed to the projection GEMM.  Costs HM x the expansion FLOPs (2.25x for 3x3, 4x for 5x5)
+// in exchange for one launch instead of two and no expanded-tensor traffic -- these blocks live at
+// 40x40 / 20x20 where launches are latency-bound, not FLOP-bound.
+// Projection weights: LDS.  Expansion weights: A fragments straight from L2 (prefetched one slab ahead).
+template <int NT, int DK, int KBI /*ceil(C1/16)*/>
+__global__ __launch_bounds__(256) void yl_uib_kernel(YlConvP p) {
+  constexpr int HP = 3 + DK;                               // halo edge (stride 1)
+  constexpr int PITCH = (HP % 4 == 1 || HP % 4 == 3) ? HP : HP + 1;
+  constexpr int HM = (HP * HP + 15) / 16;                  // halo m-tiles (3 for 3x3, 4 for 5x5)
+  constexpr int MT = 1;
+  extern __shared__ __attribute__((aligned(16))) float yl_wlds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, pl = lane & 15;
+  const int nt0 = 0;
+  const int KB = p.KB;                                     // 16-channel slabs of the expanded tensor
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_wlds);           // projection weights [KB][NT][64] float4
+  float* dwl = yl_wlds + (size_t)KB * NT * 256;            // [DK*DK][Cmid] taps, [Cmid] dw bias, [KB*16] expansion bias
+  float* b2l = dwl + (size_t)(DK * DK + 1) * p.Cin;
+  float* halo = b2l + (size_t)KB * 16 + wave * (HP * PITCH * 16);
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
+  const f32x4* w2g = reinterpret_cast<const f32x4*>(p.w2p);  // [KBI][KB][64] float4
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float elo = (p.act2 == YL_ACT_RELU || p.act2 == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float ehi = (p.act2 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+
+  for (int t = wave; t < KB; t += 4) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (nt < p.NTtot) w = wg[((size_t)t * p.NTtot + nt) * 64 + lane];
+      wl[(t * NT + nt) * 64 + lane] = w;
+    }
+  }
+  {
+    const int nw = DK * DK * p.Cin;
+    for (int i = tid; i < nw; i += 256) dwl[i] = p.dw_w[i];
+    for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = p.dw_b ? p.dw_b[i] : 0.0f;
+    for (int i = tid; i < KB * 16; i += 256) b2l[i] = p.b2[i];
+  }
+  __syncthreads();
+
+  const int tw = p.OW >> 2, th = p.OH >> 2;
+  const int tiles_img = tw * th;
+  const int ntiles = p.B * tiles_img;
+  const int wstride = gridDim.x * 4;
+  // lane constants: halo pixel of this lane in every halo m-tile
+  int h_r[HM], h_c[HM], h_lo[HM];
+  bool h_ok[HM];
+#pragma unroll
+  for (int m = 0; m < HM; ++m) {
+    const int q = m * 16 + pl;
+    h_ok[m] = q < HP * HP;
+    const int qq = h_ok[m] ? q : 0;
+    h_r[m] = qq / HP;
+    h_c[m] = qq - h_r[m] * HP;
+    h_lo[m] = (h_r[m] * PITCH + h_c[m]) * 16 + 4 * kq;
+  }
+  const int rbase = ((pl >> 2) * PITCH + (pl & 3)) * 16 + 4 * kq;
+  const bool pre_add = p.res != nullptr && p.act == YL_ACT_NONE;
+
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tw, txi = trem - tyi * tw;
+    YlPix px[MT];
+    px[0].b = b;
+    px[0].oy = 4 * tyi + (pl >> 2);
+    px[0].ox = 4 * txi + (pl & 3);
+    px[0].valid = true;
+    px[0].lin = ((size_t)b * p.OH + px[0].oy) * p.OW + px[0].ox;
+    // block input at the lane's halo pixels: B fragments of the expansion GEMM, resident for the tile
+    const int iy0 = 4 * tyi - p.dw_pad_t, ix0 = 4 * txi - p.dw_pad_l;
+    f32x4 xin[HM][KBI];
+    bool h_in[HM];
+#pragma unroll
+    for (int m = 0; m < HM; ++m) {
+      const int iy = iy0 + h_r[m], ix = ix0 + h_c[m];
+      h_in[m] = h_ok[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const float* src = p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.C1 + 4 * kq;
+#pragma unroll
+      for (int kbi = 0; kbi < KBI; ++kbi) {
+        const bool ok = h_in[m] && (kbi * 16 + 4 * kq) < p.C1;
+        xin[m][kbi] = yl_ld4(ok ? src + kbi * 16 : p.zeros);
+      }
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int n = nt * 16 + 4 * kq;
+      if (pre_add && n < p.N) acc[0][nt] = yl_ld4(p.res + px[0].lin * p.N + n);
+    }
+    f32x4 we[KBI], wn[KBI];
+#pragma unroll
+    for (int kbi = 0; kbi < KBI; ++kbi) wn[kbi] = w2g[((size_t)kbi * KB + 0) * 64 + lane];
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int kbi = 0; kbi < KBI; ++kbi) we[kbi] = wn[kbi];
+      if (kb + 1 < KB) {
+#pragma unroll
+        for (int kbi = 0; kbi < KBI; ++kbi) wn[kbi] = w2g[((size_t)kbi * KB + kb + 1) * 64 + lane];
+      }
+      // expansion slab on the halo pixels
+      const f32x4 eb = yl_ld4(b2l + kb * 16 + 4 * kq);
+      f32x4 ex[HM];
+#pragma unroll
+      for (int m = 0; m < HM; ++m) {
+        f32x4 e = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kbi = 0; kbi < KBI; ++kbi)
+#pragma unroll
+          for (int ss = 0; ss < 4; ++ss)
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(we[kbi][ss], xin[m][kbi][ss], e, 0, 0, 0);
+        e = yl_actc(e + eb, p.act2, elo, ehi);
+        ex[m] = yl_sel4(h_in[m], e);                                  // the depthwise conv zero-pads the EXPANDED tensor
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // previous slab's tap reads are complete
+#pragma unroll
+      for (int m = 0; m < HM; ++m)
+        if (h_ok[m]) *reinterpret_cast<f32x4*>(halo + h_lo[m]) = ex[m];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // slab visible to all lanes
+      // depthwise on the slab
+      const int c = kb * 16 + 4 * kq;
+      const int cs = c < p.Cin ? c : p.Cin - 4;
+      f32x4 s = yl_ld4(dwl + DK * DK * p.Cin + cs);
+#pragma unroll
+      for (int dy = 0; dy < DK; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < DK; ++dx) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + (dy * PITCH + dx) * 16);
+          const f32x4 w = yl_ld4(dwl + (dy * DK + dx) * p.Cin + cs);
+          s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
+          s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
+        }
+      const f32x4 xq = yl_sel4(c < p.Cin, yl_actc(s, p.dw_act, dlo, dhi));
+      // projection
+      const f32x4* wrow = wl + (size_t)kb * NT * 64 + lane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 wq = wrow[nt * 64];
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[ss], xq[ss], acc[0][nt], 0, 0, 0);
+      }
+    }
+    if (!pre_add && (p.res || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stem: 3x3 conv on the NCHW network input (Cin = 3, K = 27 padded to 28 = 7 MFMA k-steps).
 // Same transposed GEMM as above: A = weights (7*NT floats per lane, resident in registers for the whole
 // kernel), B = one input scalar per lane per k-step gathered straight from the three input planes
@@ -688,6 +847,17 @@ static hipError_t yl_conv_attr_nt() {
   return yl_conv_attr_modes<8, MT>();
 }
 #define YL_DWH_LDS_MAX (144 * 1024)
+// persistent grids are sized to what is co-resident (blocks/CU from the occupancy query x 256 CUs): a
+// block that has to queue behind another one re-stages the whole weight chunk into LDS for nothing
+template <typename K>
+static int yl_resident_blocks(K kernel, size_t lds) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, 256, lds) != hipSuccess || nb < 1) nb = 1;
+  if (nb > 4) nb = 4;
+  return nb * YL_NUM_CU;
+}
+
+static hipError_t yl_uib_dispatch(const YlConvP& p, size_t lds, hipStream_t st, bool attr_only, int NT, int DK, int KBI);
 template <int NT, int DK, int DS>
 static hipError_t yl_dwh_attr() {
   return hipFuncSetAttribute((const void*)yl_conv_dwh_kernel<NT, DK, DS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -710,7 +880,58 @@ hipError_t yl_conv_init() {
   if ((e = yl_dwh_attr_all<3>()) != hipSuccess) return e;
   if ((e = yl_dwh_attr_all<4>()) != hipSuccess) return e;
   if ((e = yl_dwh_attr_all<6>()) != hipSuccess) return e;
-  return yl_dwh_attr_all<8>();
+  if ((e = yl_dwh_attr_all<8>()) != hipSuccess) return e;
+  YlConvP dummy{};
+  return yl_uib_dispatch(dummy, 0, nullptr, true, 0, 0, 0);
+}
+
+template <int NT, int DK, int KBI>
+static hipError_t yl_uib_one(const YlConvP& p, size_t lds, hipStream_t st, bool attr_only) {
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_uib_kernel<NT, DK, KBI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               YL_DWH_LDS_MAX);
+  const long wtiles = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
+  int gx = yl_resident_blocks(yl_uib_kernel<NT, DK, KBI>, lds);
+  if (gx > (wtiles + 3) / 4) gx = (int)((wtiles + 3) / 4);
+  hipLaunchKernelGGL((yl_uib_kernel<NT, DK, KBI>), dim3(gx), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+// instantiated shapes: NT (projection n-tiles) x DK x KBI (input k-blocks)
+static hipError_t yl_uib_dispatch(const YlConvP& p, size_t lds, hipStream_t st, bool attr_only, int NT, int DK, int KBI) {
+  hipError_t e = hipSuccess;
+  bool hit = false;
+#define UIB_CASE(A, B, C)                                                         \
+  if (attr_only || (NT == A && DK == B && KBI == C)) {                            \
+    hit = true;                                                                   \
+    if ((e = yl_uib_one<A, B, C>(p, lds, st, attr_only)) != hipSuccess) return e; \
+  }
+  UIB_CASE(1, 3, 1) UIB_CASE(2, 3, 1) UIB_CASE(1, 5, 1) UIB_CASE(2, 5, 2)          // tiny test nets
+  UIB_CASE(3, 3, 3) UIB_CASE(4, 3, 4) UIB_CASE(4, 5, 4) UIB_CASE(3, 5, 3)          // mobilenetv4_conv_small_050
+  UIB_CASE(6, 3, 6) UIB_CASE(8, 3, 8) UIB_CASE(8, 5, 8) UIB_CASE(6, 5, 6)          // mobilenetv4_conv_small
+  UIB_CASE(2, 3, 2) UIB_CASE(2, 5, 1)
+#undef UIB_CASE
+  return hit ? e : hipErrorInvalidValue;
+}
+
+size_t yl_uib_lds_bytes(int Cmid, int NT, int dk) {
+  const int KB = (Cmid + 15) / 16, HP = 3 + dk;
+  const int PITCH = (HP % 4 == 1 || HP % 4 == 3) ? HP : HP + 1;
+  return (size_t)KB * NT * 1024 + (size_t)(dk * dk + 1) * Cmid * 4 + (size_t)KB * 64 + (size_t)4 * HP * PITCH * 64;
+}
+
+bool yl_uib_supported(int c1, int cmid, int n, int dk) {
+  const int nts[6] = {1, 2, 3, 4, 6, 8};
+  const int ntt = (n + 15) / 16, kbi = (c1 + 15) / 16;
+  int NT = 0;
+  for (int i = 0; i < 6; ++i) if (nts[i] >= ntt) { NT = nts[i]; break; }
+  if (!NT || (dk != 3 && dk != 5)) return false;
+  if (yl_uib_lds_bytes(cmid, NT, dk) > YL_DWH_LDS_MAX) return false;
+  YlConvP p{};
+  // shape table of yl_uib_dispatch
+  const int T[][3] = {{1,3,1},{2,3,1},{1,5,1},{2,5,2},{3,3,3},{4,3,4},{4,5,4},{3,5,3},{6,3,6},{8,3,8},{8,5,8},{6,5,6},{2,3,2},{2,5,1}};
+  for (auto& t : T) if (t[0] == NT && t[1] == dk && t[2] == kbi) return true;
+  (void)p;
+  return false;
 }
 
 template <int NT>
@@ -729,16 +950,6 @@ static bool yl_dwh_go(const YlConvP& p, dim3 grid, size_t lds, hipStream_t st) {
   else if (p.dw_k == 5 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 5, 2>), grid, dim3(256), lds, st, p);
   else return false;
   return true;
-}
-
-// persistent grids are sized to what is co-resident (blocks/CU from the occupancy query x 256 CUs): a
-// block that has to queue behind another one re-stages the whole weight chunk into LDS for nothing
-template <typename K>
-static int yl_resident_blocks(K kernel, size_t lds) {
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, 256, lds) != hipSuccess || nb < 1) nb = 1;
-  if (nb > 4) nb = 4;
-  return nb * YL_NUM_CU;
 }
 
 template <int NT, int MT>
@@ -798,6 +1009,10 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
     NT = best;
   }
   const int gy = (p.NTtot + NT - 1) / NT;
+  if (p.C1 > 0) {          // fused inverted-residual block (expand -> depthwise -> project)
+    if (gy != 1 || (p.OH & 3) || (p.OW & 3) || p.dw_stride != 1) return hipErrorInvalidValue;
+    return yl_uib_dispatch(p, yl_uib_lds_bytes(p.Cin, NT, p.dw_k), st, false, NT, p.dw_k, (p.C1 + 15) / 16);
+  }
   // depthwise prologue with LDS-staged halo tiles (4x4 output pixels per wave)
   if (p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.OH & 3) == 0 &&
       (p.OW & 3) == 0 && tile_hint != 3) {

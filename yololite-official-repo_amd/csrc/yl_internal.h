@@ -97,3 +97,4 @@ hipError_t yl_launch_stemblock(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init();
 bool yl_stemblock_supported(int c1, int c2, int c3);
 hipError_t yl_conv_init();
+bool yl_uib_supported(int c1, int cmid, int n, int dk);

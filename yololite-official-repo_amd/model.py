@@ -227,9 +227,9 @@ class YOLOLiteHIP:
     checkpoint's meta, weights attached with load_state_dict(), moved with .to(device), called with
     a [B,3,S,S] float tensor, returns the list of level tensors."""
 
-    def __init__(self, meta: dict, fuse_dw="auto", fuse_stem: bool = True):
+    def __init__(self, meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False):
         self.meta = meta
-        self.fuse_dw, self.fuse_stem = fuse_dw, fuse_stem
+        self.fuse_dw, self.fuse_stem, self.fuse_uib = fuse_dw, fuse_stem, fuse_uib
         self.export_concat = False
         self.program: Optional[Program] = None
         self.ctx: Optional[HipContext] = None
@@ -247,7 +247,8 @@ class YOLOLiteHIP:
         Unlike the reference, a key the forward pass needs cannot be left at its random init:
         missing weights raise."""
         try:
-            self.program = build_program(self.meta, state_dict, fuse_dw=self.fuse_dw, fuse_stem=self.fuse_stem)
+            self.program = build_program(self.meta, state_dict, fuse_dw=self.fuse_dw, fuse_stem=self.fuse_stem,
+                                         fuse_uib=self.fuse_uib)
         except KeyError as e:
             raise RuntimeError(f"checkpoint lacks a weight the forward pass needs: {e.args[0]}") from None
         self._sd = state_dict
@@ -273,7 +274,8 @@ class YOLOLiteHIP:
         planned per size, so contexts are cached by input size."""
         if img_size not in self._ctxs:
             p = self.program if img_size == self.program.img_size else \
-                build_program(self.meta, self._sd, fuse_dw=self.fuse_dw, img_size=img_size, fuse_stem=self.fuse_stem)
+                build_program(self.meta, self._sd, fuse_dw=self.fuse_dw, img_size=img_size, fuse_stem=self.fuse_stem,
+                              fuse_uib=self.fuse_uib)
             self._ctxs[img_size] = (p, HipContext(p.img_size, p.num_classes, p.level_size, p.level_anchors, p,
                                                   self._device_index))
         return self._ctxs[img_size][1]
@@ -303,9 +305,9 @@ class YOLOLiteHIP:
     forward = __call__
 
 
-def build_model_from_meta(meta: dict, fuse_dw="auto", fuse_stem: bool = True) -> YOLOLiteHIP:
+def build_model_from_meta(meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False) -> YOLOLiteHIP:
     """tools/infer.py:34-77."""
-    return YOLOLiteHIP(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem)
+    return YOLOLiteHIP(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib)
 
 
 def load_model_names_imgsize_from_ckpt(weights: str, device):

@@ -202,8 +202,8 @@ DW_PROLOGUE_LDS_MAX = 32 * 1024      # bytes; mirrors YL_DW_LDS_MAX in csrc/yl_a
 
 
 class _Builder:
-    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw, fuse_stem=True):
-        self.sd, self.p, self.fuse_dw, self.fuse_stem = sd, prog, fuse_dw, fuse_stem
+    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw, fuse_stem=True, fuse_uib=True):
+        self.sd, self.p, self.fuse_dw, self.fuse_stem, self.fuse_uib = sd, prog, fuse_dw, fuse_stem, fuse_uib
 
     # ---- state-dict access
     def get(self, key: str, shape: Tuple[int, ...]) -> np.ndarray:
@@ -277,6 +277,38 @@ class _Builder:
                                    c2=c2, act2=_ACT[act], c3=c3, act3=_ACT[act], w2=w2, b2=b2, w3=w3, b3=b3,
                                    name=prefix + "conv_stem+blocks.0", macs=macs, bytes_in=4 * 3 * S * S,
                                    bytes_out=4 * oh * oh * cout))
+        return o
+
+    # shapes instantiated by yl_uib_dispatch (csrc/yl_conv.hip): (projection n-tiles, dw k, input k-blocks)
+    _UIB_SHAPES = {(1, 3, 1), (2, 3, 1), (1, 5, 1), (2, 5, 2), (3, 3, 3), (4, 3, 4), (4, 5, 4), (3, 5, 3),
+                   (6, 3, 6), (8, 3, 8), (8, 5, 8), (6, 5, 6), (2, 3, 2), (2, 5, 1)}
+
+    def uib_fusable(self, x, cmid, cout, dk):
+        h, w, c1 = self.dims(x)
+        if not self.fuse_uib or (h & 3) or (w & 3) or dk not in (3, 5):
+            return False
+        ntt = -(-cout // 16)
+        nt = next((v for v in (1, 2, 3, 4, 6, 8) if v >= ntt), 0)
+        if (nt, dk, -(-c1 // 16)) not in self._UIB_SHAPES:
+            return False
+        kb, hp = -(-cmid // 16), 3 + dk
+        pitch = hp if hp % 4 in (1, 3) else hp + 1
+        lds = kb * nt * 1024 + (dk * dk + 1) * cmid * 4 + kb * 64 + 4 * hp * pitch * 64
+        return lds <= 144 * 1024
+
+    def uib(self, x, pre, eps, act, cmid, cout, dk, res):
+        """pw_exp(+BN+act) -> dw_mid dk x dk s1 (+BN+act) -> pw_proj(+BN)(+res) as ONE launch."""
+        h, w, c1 = self.dims(x)
+        w2, b2 = self.fold(pre + "pw_exp.conv", pre + "pw_exp.bn", eps, False, (cmid, c1, 1, 1))
+        dww, dwb = self.fold(pre + "dw_mid.conv", pre + "dw_mid.bn", eps, False, (cmid, 1, dk, dk))
+        wp, bp = self.fold(pre + "pw_proj.conv", pre + "pw_proj.bn", eps, False, (cout, cmid, 1, 1))
+        o = self.slot(h, w, cout)
+        L = Layer(_OP_CONV, x, o, cmid, cout, 1, 1, 0, 0, _ACT["none"], wp, bp, res_slot=res,
+                  dw_k=dk, dw_stride=1, dw_pad_t=dk // 2, dw_pad_l=dk // 2, dw_act=_ACT[act], dw_w=dww, dw_b=dwb,
+                  c2=c1, act2=_ACT[act], w2=w2, b2=b2, name=pre + "uib",
+                  macs=h * w * (c1 * cmid + cmid * dk * dk + cmid * cout),
+                  bytes_in=4 * h * w * c1 * (2 if res >= 0 else 1), bytes_out=4 * h * w * cout)
+        self.p.layers.append(L)
         return o
 
     def conv(self, x, conv, bn, eps, act, cout, k=1, s=1, same=False, bias=False, res=-1, up=-1, head_level=-1,
@@ -371,6 +403,9 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
                 skip = (cin == cout and s == 1)
                 if d["type"] == "cn":
                     x = b.conv(x, pre + "conv", pre + "bn1", eps, act, cout, d["k"], s, same)
+                elif d["type"] == "uir" and not d["a"] and d["k"] and s == 1 and not same and \
+                        b.uib_fusable(x, _make_divisible(cin * d["e"], 8), cout, d["k"]):
+                    x = b.uib(x, pre, eps, act, _make_divisible(cin * d["e"], 8), cout, d["k"], x if skip else -1)
                 elif d["type"] == "uir":
                     mid = _make_divisible(cin * d["e"], 8)
                     dws = None
@@ -405,7 +440,7 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
 
 
 def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto",
-                  img_size: Optional[int] = None, fuse_stem: bool = True) -> Program:
+                  img_size: Optional[int] = None, fuse_stem: bool = True, fuse_uib: bool = False) -> Program:
     """meta: the checkpoint's `meta` dict (tools/train.py:62-75); reads the keys
     build_model_from_meta reads (tools/infer.py:35-50).
     fuse_dw: True = every depthwise conv becomes the prologue of the following 1x1 conv, False = none,
@@ -433,7 +468,7 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     else:
         sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
     prog = Program(img_size=S, num_classes=C, level_size=[], level_anchors=[], strides=[])
-    b = _Builder(sd, prog, fuse_dw, fuse_stem)
+    b = _Builder(sd, prog, fuse_dw, fuse_stem, fuse_uib and fuse_dw is not False)
 
     feats = _backbone(b, backbone)
     take = 4 if use_p2 else 3
