@@ -247,7 +247,7 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
 // LDS: weight chunk [CH][NT][64] float4 (n-tiles beyond the layer's last one are zero-filled so the
 // hot loop needs no tile predicate).
 template <int NT, int MT, int MODE>
-__global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
+__global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
   extern __shared__ __attribute__((aligned(16))) float yl_wlds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4, pl = lane & 15;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void yl_conv_mfma_kernel(YlConvP p) {
 // so the depthwise input is fetched from L2/HBM once per tile instead of DK*DK times and the hot loop
 // has no bounds logic.  Requires OH % 4 == 0 and OW % 4 == 0 (else the DW3/DW5 global-tap modes run).
 template <int NT, int DK, int DS>
-__global__ __launch_bounds__(256) void yl_conv_dwh_kernel(YlConvP p) {
+__global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
   constexpr int HP = 3 * DS + DK;                         // halo edge in pixels
   constexpr int PITCH = (HP % 4 == 1 || HP % 4 == 3) ? HP : HP + 1;   // row pitch (pixels): odd multiple of 64 B mod 256 B
   constexpr int HF4 = HP * HP * 4;                        // float4 elements of one halo patch (16 ch)
