@@ -161,6 +161,20 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * streams the batch is split over; default 2), "tile_m" (conv M-tile hint) */
 yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
 
+/* ---- pre-processing ----------------------------------------------------------------------------
+ * Replaces letterbox() + cv2.cvtColor + /255 + (x-mean)/std + transpose of tools/infer.py:121-131,446-453
+ * for a batch: `packed_u8_dev` holds the BGR uint8 HWC images back to back, `imgs_dev` one descriptor
+ * per image (the caller computes the letterbox geometry exactly like the reference: scale=min(S/h,S/w),
+ * nh,nw=int(round(.)), top=(S-nh)//2, left=(S-nw)//2).  x_dev receives [B,3,S,S] fp32.              */
+typedef struct {
+  int64_t offset;             /* byte offset of image b in packed_u8_dev                          */
+  int32_t h0, w0;             /* source size                                                      */
+  int32_t nh, nw;             /* resized size inside the letterbox                                */
+  int32_t top, left;          /* padding                                                          */
+} yl_pre_image;
+yl_status yl_preprocess(yl_ctx* ctx, const uint8_t* packed_u8_dev, const yl_pre_image* imgs_dev, int32_t batch,
+                        float* x_dev, void* stream);
+
 /* ---- decode -----------------------------------------------------------------------------------
  * Replaces decode_preds_anchorfree (scripts/helpers/utils_ms.py:26-123): levels -> box [B,N,4]
  * xyxy pixels clamped to [0,S-1], obj [B,N,1] logits, cls [B,N,C] logits; N = sum A_l*S_l^2.        */

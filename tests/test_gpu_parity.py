@@ -340,3 +340,27 @@ def test_class_argmax_ties_match_torch_first_max():
     got = ya.infer_main_postprocess([lv.to(DEV)], 64, conf=-1.0, iou=1.0, per_class_cap=300)
     assert got["classes"][0].tolist() == exp["classes"][0].tolist()
     np.testing.assert_allclose(got["scores"][0], exp["scores"][0], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("S", [96, 640])
+def test_preprocess_bit_exact_vs_oracle(S):
+    """GPU letterbox + normalise (yl_preprocess) against the CPU restatement of the reference's
+    pre-processing with OpenCV-style fixed-point bilinear (oracle/preproc.py): integer resize bit-exact,
+    fp32 normalisation evaluated op by op -> identical floats.  Up/down-scaling, odd sizes, portrait /
+    landscape / square, already-at-size images in one batch."""
+    from oracle import preproc as opre
+    rng = np.random.RandomState(7)
+    shapes = [(S, S), (S // 2, S), (S, S // 3 + 1), (37, 53), (S * 2 + 3, S + 11), (1080 // 4, 1920 // 4), (S - 1, S - 1)]
+    imgs = [rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for h, w in shapes]
+    ctx = ya.postprocess.context_for([torch.empty((1, 1, s, s, 6)) for s in (S // 8, S // 16, S // 32)], S)
+    x, bm = ya.preprocess_batch(ctx, imgs)
+    assert x.shape == (len(imgs), 3, S, S)
+    for i, im in enumerate(imgs):
+        ref, (padx, pady, scale, w0, h0) = opre.preprocess(im, S)
+        np.testing.assert_array_equal(x[i].cpu().numpy(), ref)
+        assert tuple(bm[i]) == (padx, pady, scale, w0, h0)
+    x2, bm2 = ya.preprocess_batch(ctx, imgs[:2], letterbox=False)
+    for i in range(2):
+        r = opre.resize_linear_u8(imgs[i], S, S)
+        ref = ((r[..., ::-1].astype(np.float32) / 255.0 - opre.MEAN) / opre.STD).transpose(2, 0, 1)
+        np.testing.assert_array_equal(x2[i].cpu().numpy(), ref)

@@ -175,3 +175,26 @@ def test_param_count_checksum():
     assert n == 552408
     n = sum(p.numel() for p in omodel.DetectorOracle(num_classes=3, **omodel.MODEL_ZOO["edge_m"]).parameters())
     assert abs(n - 2.950e6) < 0.002e6
+
+
+def test_preproc_oracle_matches_reference_flow_on_identity_resize(golden_dir):
+    """oracle/preproc.py letterbox + normalise equals the reference flow captured in the main() fixture for
+    the same-size images (the only resize the cv2 stub allowed); the bilinear path itself is unpinned."""
+    from oracle import preproc as opre
+    z = _load(golden_dir, "infer_main.npz")
+    for name in ("sq", "wide"):
+        img0 = z[f"img_{name}"]
+        x, (padx, pady, scale, w0, h0) = opre.preprocess(img0, 96)
+        S = 96
+        h, w = img0.shape[:2]
+        sc = min(S / h, S / w)
+        nh, nw = int(round(h * sc)), int(round(w * sc))
+        top, left = (S - nh) // 2, (S - nw) // 2
+        lb = np.full((S, S, 3), 114, np.uint8)
+        lb[top:top + nh, left:left + nw] = img0
+        im = (lb[..., ::-1].astype(np.float32) / 255.0 - opre.MEAN) / opre.STD
+        np.testing.assert_array_equal(x, im.transpose(2, 0, 1))
+        assert (padx, pady, scale, w0, h0) == (left, top, sc, w, h)
+    # fixed-point bilinear sanity: constant images stay constant, identity resize is exact
+    c = np.full((17, 29, 3), 200, np.uint8)
+    assert (opre.resize_linear_u8(c, 64, 40) == 200).all()

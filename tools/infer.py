@@ -6,7 +6,8 @@ NMS + back-map -> runs/infer/<n>/{labels/*.txt, json/*.json}.
     python tools/infer.py --weights W.pt --img I.png|--img_dir D [--img_size S] [--conf 0.4] [--iou 0.5]
                           [--max_det 300] [--save_txt] [--no_letterbox] [--device 0]
 
-Differences, all documented in DESIGN.md: images are read with PIL (cv2 is absent in this environment),
+Differences, all documented in DESIGN.md: images are decoded with PIL (cv2 is absent in this environment)
+and letterboxed/normalised on the GPU (yl_preprocess, OpenCV-style fixed-point bilinear),
 the annotated *_pred.jpg is not drawn (cosmetics, out of scope), --device cpu is refused (no CPU path).
 Like the reference's main path, --max_det is NOT forwarded to the per-class NMS (cap 300 per class)."""
 import argparse
@@ -60,7 +61,6 @@ def main():
     args = ap.parse_args()
 
     import yololite_amd as ya
-    from yololite_amd.api import preprocess_bgr, MEAN, STD, _resize_bilinear_u8
     if args.device == "cpu":
         raise SystemExit("this build has no CPU execution path; use --device <gpu index>")
     device = torch.device(f"cuda:{int(args.device)}")
@@ -78,24 +78,19 @@ def main():
     (Path(run_dir) / "labels").mkdir(parents=True, exist_ok=True)
     (Path(run_dir) / "json").mkdir(parents=True, exist_ok=True)
 
+    ctx = model._ctx_for(S)
     for i in range(0, len(paths), args.batch):
-        chunk, xs, bms, ok = paths[i:i + args.batch], [], [], []
+        chunk, imgs, ok = paths[i:i + args.batch], [], []
         for pth in chunk:
             img0 = imread_bgr(pth)
             if img0 is None:
                 print(f"Varnar: kunde inte läsa {pth}")
                 continue
-            if args.no_letterbox:
-                h0, w0 = img0.shape[:2]
-                r = _resize_bilinear_u8(img0, S, S)
-                im = (r[..., ::-1].astype(np.float32) / 255.0 - MEAN) / STD
-                x, bm = np.ascontiguousarray(im.transpose(2, 0, 1)), (0, 0, min(S / h0, S / w0), w0, h0)
-            else:
-                x, bm = preprocess_bgr(img0, S)
-            xs.append(x); bms.append(bm); ok.append((pth, img0.shape[:2]))
-        if not xs:
+            imgs.append(img0); ok.append((pth, img0.shape[:2]))
+        if not imgs:
             continue
-        outs = model(torch.from_numpy(np.stack(xs)).to(device))
+        x, bms = ya.preprocess_batch(ctx, imgs, letterbox=not args.no_letterbox)     # letterbox + normalise on the GPU
+        outs = model(x)
         res = ya.infer_main_postprocess(outs, S, args.conf, args.iou, backmap=bms)
         for j, (pth, (h, w)) in enumerate(ok):
             b, s, c = res["boxes"][j], res["scores"][j], res["classes"][j]

@@ -10,8 +10,10 @@ from .model import (HipContext, YOLOLiteHIP, build_model_from_meta,  # noqa: F40
                     load_model_names_imgsize_from_ckpt)
 from .postprocess import (_decode_batch_to_coco_dets, decode_anchorfree_like_train,  # noqa: F401
                           decode_preds_anchorfree, infer_main_postprocess, nms)
+from .preprocess import letterbox_geometry, preprocess_batch  # noqa: F401
 from .program import BACKBONES, Program, build_program  # noqa: F401
 
 __all__ = ["YoloLiteHipError", "load_library", "HipContext", "YOLOLiteHIP", "build_model_from_meta",
            "load_model_names_imgsize_from_ckpt", "decode_preds_anchorfree", "_decode_batch_to_coco_dets",
-           "decode_anchorfree_like_train", "infer_main_postprocess", "nms", "build_program", "Program", "BACKBONES"]
+           "decode_anchorfree_like_train", "infer_main_postprocess", "nms", "build_program", "Program", "BACKBONES",
+           "preprocess_batch", "letterbox_geometry"]

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("yl_forward_timed", C.c_int32, [_vp, _vp, C.c_int32, _vpp, _vp, _fp]),
     ("yl_read_slot", C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     ("yl_set_option", C.c_int32, [_vp, C.c_char_p, C.c_int32]),
+    ("yl_preprocess", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     ("yl_decode", C.c_int32, [_vp, _vpp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     ("yl_postprocess", C.c_int32, [_vp, _vpp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp, _vp]),
     ("yl_predict", C.c_int32, [_vp, _vp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp]),

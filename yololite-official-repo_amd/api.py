@@ -2,9 +2,9 @@
 (/root/reference/README.md:20-42, /root/reference/benchmark.py:73-129): one dict per image with
 `boxes` (xyxy), `scores`, `classes`, `masks` (None for detectors) and `speed`.
 
-Pre-processing (letterbox + normalise, tools/infer.py:121-131,442-453) runs on the host with numpy /
-PIL in this round (next); everything from the normalised tensor to the final
-detections runs in the HIP library."""
+Everything from the uint8 image bytes to the final detections runs in the HIP library: letterbox +
+normalise (yl_preprocess, tools/infer.py:121-131,442-453), forward, decode, NMS, back-map (yl_predict).
+`preprocess_bgr` below is the host (numpy/PIL) variant kept for tests and tools."""
 from __future__ import annotations
 
 import time
@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from .model import load_model_names_imgsize_from_ckpt
+from .preprocess import preprocess_batch
 
 MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
 STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
@@ -62,11 +63,12 @@ class YoloLite:
         tools/infer.py:460-516 (conf 0.4 / iou 0.5 defaults :403-404, 300 per class)."""
         imgs = [source] if isinstance(source, np.ndarray) else list(source)
         t0 = time.perf_counter()
-        pre = [preprocess_bgr(im, self.img_size) for im in imgs]
-        x = torch.from_numpy(np.stack([p[0] for p in pre])).to(self.device)
-        bm = np.asarray([[p[1][0], p[1][1], max(p[1][2], 1e-6), p[1][3], p[1][4]] for p in pre], np.float32)
-        t1 = time.perf_counter()
         ctx = self.model._ctx_for(self.img_size)
+        x, bmap = preprocess_batch(ctx, imgs)                   # letterbox + normalise on the GPU
+        bm = bmap.copy()
+        bm[:, 2] = np.maximum(bm[:, 2], 1e-6)
+        bm = bm.astype(np.float32)
+        t1 = time.perf_counter()
         dets, counts = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300, backmap=torch.from_numpy(bm))
         cn = counts.cpu().numpy()
         d = dets.cpu().numpy()

@@ -19,6 +19,7 @@ UNITS = [
     ("yl_stemblock.hip", []),
     # reference-exact fp32 arithmetic in decode/NMS: no fused multiply-add contraction
     ("yl_post.hip", ["-ffp-contract=off"]),
+    ("yl_pre.hip", ["-ffp-contract=off"]),
 ]
 DEPS = ["yl_internal.h", "yl_dev.h", os.path.join("..", "..", "include", "yololite_hip.h")]
 
@@ -53,7 +54,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=5) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src, _ in UNITS]
     if force or jobs or _stale(OUT, objs):

@@ -670,6 +670,14 @@ yl_status yl_read_slot(yl_ctx* c, int32_t slot, int32_t B, float* dst, void* str
   return YL_OK;
 }
 
+yl_status yl_preprocess(yl_ctx* c, const uint8_t* packed, const yl_pre_image* imgs, int32_t B, float* x, void* stream) {
+  if (!c || !packed || !imgs || !x || B < 1) return YL_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  static_assert(sizeof(yl_pre_image) == 32, "yl_pre_image layout");
+  HIPCHK(c, yl_launch_preprocess(packed, imgs, B, c->img_size, x, (hipStream_t)stream));
+  return YL_OK;
+}
+
 yl_status yl_decode(yl_ctx* c, const float* const* levels, int32_t B, int32_t center_mode, int32_t wh_mode,
                     float* box, float* obj, float* cls, void* stream) {
   if (!c || !levels || !box || !obj || B < 1) return YL_ERR_INVALID;

@@ -88,6 +88,7 @@ hipError_t yl_launch_decode_score(const YlLevels& lv, int B, const YlDecodeP& p,
 hipError_t yl_launch_decode_only(const YlLevels& lv, int B, int center_mode, int wh_mode, float* box,
                                  float* obj, float* cls, hipStream_t st);
 hipError_t yl_launch_nms(const YlNmsP& p, int B, hipStream_t st);
+hipError_t yl_launch_preprocess(const unsigned char* src, const void* imgs, int B, int S, float* out, hipStream_t st);
 hipError_t yl_post_init();   // one-time function attributes (large dynamic LDS)
 
 hipError_t yl_launch_stem(const YlConvP& p, hipStream_t st);
