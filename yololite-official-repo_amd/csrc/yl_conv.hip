@@ -401,7 +401,10 @@ __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
 template <int NT, int DK, int DS>
 __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
   constexpr int HP = 3 * DS + DK;                         // halo edge in pixels
-  constexpr int PITCH = (HP % 4 == 1 || HP % 4 == 3) ? HP : HP + 1;   // row pitch (pixels): odd multiple of 64 B mod 256 B
+  // row pitch in floats, == 56 (mod 64): consecutive patch rows start 32 B "earlier" modulo the 256-B LDS
+  // row, which makes the 16 lanes of every ds_read_b128 group (2 tile rows x 4 pixels x 2 channel quads)
+  // hit 16 distinct 16-B slots -- conflict-free tap reads for stride 1
+  constexpr int PITCHF = ((HP * 16 + 7) / 64) * 64 + 56;
   constexpr int HF4 = HP * HP * 4;                        // float4 elements of one halo patch (16 ch)
   constexpr int NSLOT = (HF4 + 63) / 64;                  // staging float4 per lane
   constexpr int MT = 1;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
   const int KB = p.KB;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_wlds);          // [KB][NT][64] float4 (whole K: checked by the launcher)
   float* dwl = yl_wlds + (size_t)KB * NT * 256;           // [DK*DK][Cin] taps, [Cin] bias
-  float* halo = dwl + (size_t)(DK * DK + 1) * p.Cin + wave * (HP * PITCH * 16);
+  float* halo = dwl + (size_t)(DK * DK + 1) * p.Cin + wave * (HP * PITCHF);
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
@@ -449,9 +452,9 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
     const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
     s_hr[j] = hp / HP;
     s_hc[j] = hp - s_hr[j] * HP;
-    s_lo[j] = (s_hr[j] * PITCH + s_hc[j]) * 16 + quad * 4;
+    s_lo[j] = s_hr[j] * PITCHF + s_hc[j] * 16 + quad * 4;
   }
-  const int rbase = (((pl >> 2) * DS) * PITCH + (pl & 3) * DS) * 16 + 4 * kq;
+  const int rbase = ((pl >> 2) * DS) * PITCHF + ((pl & 3) * DS) * 16 + 4 * kq;
 
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
     const int b = tile / tiles_img;
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
         for (int dy = 0; dy < DK; ++dy)
 #pragma unroll
           for (int dx = 0; dx < DK; ++dx) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + (dy * PITCH + dx) * 16);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + dx * 16);
             const f32x4 w = yl_ld4(dwl + (dy * DK + dx) * p.Cin + cs);
             s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
             s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
         for (int dy = 0; dy < DK; ++dy) {                 // one tap row at a time bounds the register footprint
 #pragma unroll
           for (int dx = 0; dx < DK; ++dx) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + (dy * PITCH + dx) * 16);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + dx * 16);
             const f32x4 w = yl_ld4(dwl + (dy * DK + dx) * p.Cin + cs);
             s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
             s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
@@ -1017,8 +1020,8 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
   if (p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.OH & 3) == 0 &&
       (p.OW & 3) == 0 && tile_hint != 3) {
     const int HP = 3 * p.dw_stride + p.dw_k;
-    const int PITCH = (HP % 4 == 1 || HP % 4 == 3) ? HP : HP + 1;
-    const size_t lds = (size_t)p.KB * NT * 1024 + (size_t)(p.dw_k * p.dw_k + 1) * p.Cin * 4 + (size_t)4 * HP * PITCH * 64;
+    const int PITCHF = ((HP * 16 + 7) / 64) * 64 + 56;
+    const size_t lds = (size_t)p.KB * NT * 1024 + (size_t)(p.dw_k * p.dw_k + 1) * p.Cin * 4 + (size_t)4 * HP * PITCHF * 4;
     if (lds <= YL_DWH_LDS_MAX) {
       const long wtiles = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
       int res = 0;
