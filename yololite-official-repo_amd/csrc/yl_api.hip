@@ -490,6 +490,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       L.in_h = L.in_w = d->img_size;
       if (l.cin != 3 || l.k != 3) return fail(c, YL_ERR_UNSUPPORTED, "stem must be 3x3 with 3 input channels");
       if (!l.w2 || l.c2 < 1 || l.c3 < 0 || (l.c3 > 0 && !l.w3)) return bad("stem block needs w2 (and w3 when c3 > 0)");
+      if (l.act == YL_ACT_SILU || l.act2 == YL_ACT_SILU || l.act3 == YL_ACT_SILU)
+        return fail(c, YL_ERR_UNSUPPORTED, "stem block: ReLU-family activations only");
       if (!yl_stemblock_supported(l.cout, l.c2, l.c3))
         return fail(c, YL_ERR_UNSUPPORTED, "stem block: c1 in {16,32}, c2,c3 <= 32 and multiples of 4");
     } else if (l.op == YL_OP_STEM) {

@@ -82,6 +82,15 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   for (int nt = 0; nt < NT1; ++nt) bias1[nt] = yl_ld4(p.bias + nt * 16 + 4 * kq);
 #pragma unroll
   for (int nt = 0; nt < NT2; ++nt) bias2[nt] = yl_ld4(p.b2 + nt * 16 + 4 * kq);
+  // ReLU-family activations as branch-free clamps (SiLU is rejected for this op at yl_create)
+  const float lo1 = (p.act == YL_ACT_NONE) ? -INFINITY : 0.0f, hi1 = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float lo2 = (p.act2 == YL_ACT_NONE) ? -INFINITY : 0.0f, hi2 = (p.act2 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float lo3 = (p.act3 == YL_ACT_NONE) ? -INFINITY : 0.0f, hi3 = (p.act3 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  auto clamp4 = [](f32x4 v, float lo, float hi) {
+    v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
+    v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
+    return v;
+  };
   const int lq = pl * P1 + 4 * kq;                                   // lane part of the patch write offset
   const int ty = pl >> 3, tx = pl & 7;                               // lane's pixel inside the 2x8 tile
   const int lr = ((2 * ty) * SB_PC + 2 * tx) * P1 + 4 * kq;          // lane part of the patch read offset
@@ -91,19 +100,20 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   const int ntiles = p.B * tiles_img;
   const int wstride = gridDim.x * 4;
 
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
+  // gather of the 42 input scalars this lane feeds to the stem MFMAs of `tile` (7 k-slots x 6 patch
+  // m-tiles).  Issued for tile t+1 right after tile t's stem phase has consumed the registers, so the
+  // global-load latency hides behind tile t's 3x3 / 1x1 MFMAs.
+  float xv[SB_MT1][KS];
+  auto gather = [&](int tile) {
     const int b = tile / tiles_img;
     const int trem = tile - b * tiles_img;
     const int tyi = trem / tpr, txi = trem - tyi * tpr;
-    const int oy0 = tyi * SB_TR, ox0 = txi * SB_TC;                  // tile origin on the conv2 output grid
-    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;                  // patch origin on the stem grid
-    const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;   // input coords of patch(0,0) tap(0,0)
+    const int sy0 = 2 * tyi * SB_TR - 1, sx0 = 2 * txi * SB_TC - 1;
+    const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;
     const float* xb = p.x + (size_t)b * 3 * plane;
-    // interior tiles (the common case) need no bounds logic at all: wave-uniform branch
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW && iy0 >= 0 && ix0 >= 0 &&
                           iy0 + (SB_PR - 1) * p.stride + 3 <= p.H && ix0 + (SB_PC - 1) * p.stride + 3 <= p.W;
-    float xv[SB_MT1][KS];
-    if (interior) {
+    if (interior) {                                   // the common case: no bounds logic (wave-uniform branch)
       const float* xo = xb + (size_t)iy0 * p.W + ix0;
 #pragma unroll
       for (int m = 0; m < SB_MT1; ++m)
@@ -116,11 +126,20 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
         for (int s = 0; s < KS; ++s) {
           const int iy = iy0 + ppi[m] * p.stride + tky[s], ix = ix0 + ppj[m] * p.stride + tkx[s];
           const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-          const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-          const float t = xb[tc[s] * plane + (size_t)iyc * p.W + ixc];
-          xv[m][s] = in ? t : 0.0f;
+          xv[m][s] = *(in ? xb + tc[s] * plane + (size_t)iy * p.W + ix : p.zeros);
         }
     }
+  };
+  const int tile0 = blockIdx.x * 4 + wave;
+  if (tile0 < ntiles) gather(tile0);
+
+  for (int tile = tile0; tile < ntiles; tile += wstride) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tpr, txi = trem - tyi * tpr;
+    const int oy0 = tyi * SB_TR, ox0 = txi * SB_TC;                  // tile origin on the conv2 output grid
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;                  // patch origin on the stem grid
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW;
     // ---- phase 1: stem on the patch -> wave-private LDS
 #pragma unroll
     for (int m = 0; m < SB_MT1; ++m) {
@@ -139,36 +158,48 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
       }
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
-        f32x4 v = yl_act4(a1[nt] + bias1[nt], p.act);
+        f32x4 v = clamp4(a1[nt] + bias1[nt], lo1, hi1);
         if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(patch + m * 16 * P1 + lq + nt * 16) = v;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // LDS writes of other lanes -> reads below
     __builtin_amdgcn_wave_barrier();
+    if (tile + wstride < ntiles) gather(tile + wstride);             // next tile's inputs: in flight during phases 2-3
 
-    // ---- phase 2: 3x3 stride-2 conv on the wave's 2x8 tile
-    f32x4 a2[NT2];
+    // ---- phase 2: 3x3 stride-2 conv on the wave's 2x8 tile.  LDS operands of step i+1 are requested
+    //      before the MFMAs of step i (explicit double buffer, order pinned with sched_group_barrier), and
+    //      each n-tile accumulates in two chains (the 16x16x4 f32 MFMA has a 40-cycle dependent latency
+    //      against a 32-cycle issue interval).
+    f32x4 a2[NT2], a2b[NT2];
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) a2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT2; ++nt) { a2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; a2b[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    constexpr int NSTEP = 9 * KB1;
+    f32x4 xq[2], wq[2][NT2];
+    auto lds_step = [&](int i, int buf) {              // i = tap * KB1 + kb  (all compile-time after unrolling)
+      const int tap = i / KB1, kb = i - tap * KB1;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      xq[buf] = *reinterpret_cast<const f32x4*>(patch + lr + (ky * SB_PC + kx) * P1 + kb * 16);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+      for (int nt = 0; nt < NT2; ++nt) wq[buf][nt] = w2l[(i * NT2 + nt) * 64 + lane];
+    };
+    lds_step(0, 0);
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
+    for (int i = 0; i < NSTEP; ++i) {
+      if (i + 1 < NSTEP) lds_step(i + 1, (i + 1) & 1);
 #pragma unroll
-        for (int kb = 0; kb < KB1; ++kb) {
-          const f32x4 xq = *reinterpret_cast<const f32x4*>(patch + lr + (ky * SB_PC + kx) * P1 + kb * 16);
-          const f32x4* wrow = w2l + (((ky * 3 + kx) * KB1 + kb) * NT2) * 64 + lane;
+      for (int nt = 0; nt < NT2; ++nt) {
+        const f32x4 w = wq[i & 1][nt], x = xq[i & 1];
+        a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], a2[nt], 0, 0, 0);
+        a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], a2b[nt], 0, 0, 0);
+        a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], a2[nt], 0, 0, 0);
+        a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[3], a2b[nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT2, 0);       // DS reads of step i+1
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT2, 0);       // MFMAs of step i
+    }
 #pragma unroll
-          for (int nt = 0; nt < NT2; ++nt) {
-            const f32x4 wq = wrow[nt * 64];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-              a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s], xq[s], a2[nt], 0, 0, 0);
-          }
-        }
-#pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) a2[nt] = yl_act4(a2[nt] + bias2[nt], p.act2);
+    for (int nt = 0; nt < NT2; ++nt) a2[nt] = clamp4((a2[nt] + a2b[nt]) + bias2[nt], lo2, hi2);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // patch reads done before the next tile's writes
     __builtin_amdgcn_wave_barrier();
 
@@ -192,7 +223,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
       for (int nt = 0; nt < NT3; ++nt) {
         const int n = nt * 16 + 4 * kq;
-        const f32x4 v = yl_act4(a3[nt] + yl_ld4(p.b3 + n), p.act3);
+        const f32x4 v = clamp4(a3[nt] + yl_ld4(p.b3 + n), lo3, hi3);
         if (valid && n < Nout) *reinterpret_cast<f32x4*>(orow + n) = v;
       }
     } else {

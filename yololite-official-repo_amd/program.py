@@ -371,7 +371,7 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
     ns = len(arch)
     s0 = [_parse(t) for t in arch[0]]
     c_s0 = [_make_divisible(d["c"] * spec["cmult"], 8) for d in s0]
-    fused_entry = (b.fuse_stem and not same and spec["stem"] in (16, 32) and len(s0) in (1, 2)
+    fused_entry = (b.fuse_stem and not same and act in ("relu", "relu6") and spec["stem"] in (16, 32) and len(s0) in (1, 2)
                    and s0[0]["type"] == "cn" and s0[0]["k"] == 3 and s0[0]["s"] == 2 and s0[0]["r"] == 1
                    and (len(s0) == 1 or (s0[1]["type"] == "cn" and s0[1]["k"] == 1 and s0[1]["s"] == 1 and s0[1]["r"] == 1))
                    and all(c <= 32 and c % 4 == 0 for c in c_s0))
