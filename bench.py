@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--fuse-dw", default="auto", help="auto | 1 | 0: fuse depthwise convs into the following 1x1 conv")
     ap.add_argument("--fuse-stem", type=int, default=1, help="fused stem+blocks.0 entry kernel")
     ap.add_argument("--fuse-uib", type=int, default=0, help="whole inverted-residual blocks as one launch")
+    ap.add_argument("--seg", type=int, default=0, help="add the build-defined instance-seg branch (BASELINE config 4)")
     ap.add_argument("--streams", type=int, default=2, help="internal streams the batch is split over")
     ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
@@ -100,7 +101,7 @@ def main():
     from yololite_amd.program import synth_state_dict, zoo_meta
 
     B, S = args.batch, args.img
-    meta = zoo_meta(args.model, 80, S)
+    meta = zoo_meta(args.model, 80, S, seg=bool(args.seg))
     sd = synth_state_dict(meta, seed=0, head_noise=2.0)
     model = ya.build_model_from_meta(meta, fuse_dw=(args.fuse_dw if args.fuse_dw in ("auto", "dw3") else bool(int(args.fuse_dw))),
                                      fuse_stem=bool(args.fuse_stem), fuse_uib=bool(args.fuse_uib))
@@ -116,6 +117,11 @@ def main():
     counts = torch.empty((B,), device=dev, dtype=torch.int32)
 
     def step():
+        if args.seg:
+            _, _, idx = ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
+                                    out=(dets, counts), want_idx=True)
+            ctx.masks(counts, idx, max_out)
+            return dets, counts
         ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out, out=(dets, counts))
         if world > 1 or force_coll:
             return ydist.allgather_dets(dets, counts, B * world, force=force_coll)
@@ -186,7 +192,7 @@ def main():
             "p50_ms_per_frame": round(float(np.median(step_ms)) / B, 5),
             "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} detector 640x640 C=80 batch={B}/GPU, forward+decode+per-class NMS "
+            "config": {"workload": f"{args.model} {'detector+instance-seg head' if args.seg else 'detector'} 640x640 C=80 batch={B}/GPU, forward+decode+per-class NMS{'+masks' if args.seg else ''} "
                                    f"(conf {args.conf}, iou {args.iou}), input resident in HBM"
                                    + (", + RCCL all-gather of packed dets" if world > 1 else ""),
                        "global_batch": B * world, "img_size": S, "parallelism": f"dp{world} (batch sharded, weights replicated)",

@@ -74,6 +74,8 @@ typedef struct {
   int32_t cin, cout;
   int32_t k, stride, pad_t, pad_l;
   int32_t act;                /* YL_ACT_* applied after bias                                      */
+  int32_t in_shift;           /* YL_OP_CONV, k>1, no prologue: the conv reads its input nearest-upsampled by
+                                 2^in_shift (F.interpolate(scale_factor=2) folded into the tap addressing)   */
   int32_t dw_k;               /* YL_OP_CONV only: 0 = none, else depthwise kxk prologue on input  */
   int32_t dw_stride, dw_pad_t, dw_pad_l, dw_act;
   const float* w;             /* CONV/STEM: [cout][cin][k][k]; DW: [cout][1][k][k]                */
@@ -104,6 +106,9 @@ typedef struct {
   int32_t img_size;           /* square network input S (x is [B,3,S,S] NCHW fp32)                */
   int32_t in_channels;        /* 3                                                                */
   int32_t num_classes;        /* C                                                                */
+  int32_t num_masks;          /* NM: mask coefficients appended to every level row (0 = detector);
+                                 level rows are [tx,ty,tw,th,tobj, cls_0..C-1, mc_0..NM-1]                */
+  int32_t proto_slot;         /* activation slot holding the mask prototypes [B,PH,PW,NM] (-1 = none)   */
   int32_t num_levels;         /* L <= YL_MAX_LEVELS                                               */
   int32_t level_size[YL_MAX_LEVELS];
   int32_t level_anchors[YL_MAX_LEVELS];
@@ -191,9 +196,19 @@ yl_status yl_decode(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, 
 yl_status yl_postprocess(yl_ctx* ctx, const float* const* levels_dev, int32_t batch,
                          const yl_post_cfg* cfg, float* dets_dev, int32_t* counts_dev,
                          int32_t* keep_idx_dev, void* stream);
-/* forward + postprocess on the context's own level buffers (YoloLite.predict hot loop).            */
+/* forward + postprocess on the context's own level buffers (YoloLite.predict hot loop).
+ * keep_idx_dev: optional [B][max_out] candidate indices (needed by yl_masks), NULL to skip.          */
 yl_status yl_predict(yl_ctx* ctx, const float* x_dev, int32_t batch, const yl_post_cfg* cfg,
-                     float* dets_dev, int32_t* counts_dev, void* stream);
+                     float* dets_dev, int32_t* counts_dev, int32_t* keep_idx_dev, void* stream);
+
+/* ---- instance masks (BUILD-DEFINED: the reference repository contains no mask code; parity unpinned) --
+ * For detection i of image b (candidate keep_idx[b][i] of the levels of the last yl_forward/yl_predict on
+ * this context, box = its decoded box in network-input pixels):
+ *     m(y,x) = sigmoid( sum_k mc_k * proto[b][y][x][k] )          proto = slot `proto_slot`, [PH,PW,NM]
+ *     mask(y,x) = m(y,x) > thr  and  x1*PW/S <= x < x2*PW/S  and  y1*PH/S <= y < y2*PH/S
+ * masks_dev: uint8 [B][max_out][PH][PW] (rows >= counts[b] are left untouched).                       */
+yl_status yl_masks(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, const int32_t* counts_dev,
+                   const int32_t* keep_idx_dev, int32_t max_out, float thr, uint8_t* masks_dev, void* stream);
 /* Replaces nms(boxes, scores, iou_th, max_det) (tools/infer.py:134-152): keep_dev[max_det] receives
  * the kept indices in score-descending order, count_dev[0] their number (<= max_det).              */
 yl_status yl_nms(yl_ctx* ctx, const float* boxes_dev, const float* scores_dev, int32_t n, float iou_thr,

@@ -49,10 +49,28 @@ class DWSmooth(nn.Module):
         return self.block(x)
 
 
-def build_head(A: int, head_depth: int, C: int, F_: int) -> nn.ModuleDict:
-    """model_v2.py:42-53 + bias init :7-14."""
+class ProtoNet(nn.Module):
+    """BUILD-DEFINED mask prototype head (the reference has no mask code; SURVEY 8a row a15, parity unpinned):
+    conv3x3(F->Cp)+BN+SiLU -> nearest x2 -> conv3x3(Cp->Cp)+BN+SiLU -> conv1x1(Cp->NM)+BN+SiLU on P3."""
+
+    def __init__(self, F_: int, Cp: int, NM: int):
+        super().__init__()
+        def cba(ci, co, k):
+            return nn.Sequential(nn.Conv2d(ci, co, k, padding=k // 2, bias=False), nn.BatchNorm2d(co), nn.SiLU())
+        self.cv1, self.cv2, self.cv3 = cba(F_, Cp, 3), cba(Cp, Cp, 3), cba(Cp, NM, 1)
+
+    def forward(self, p3):
+        y = self.cv1(p3)
+        y = F.interpolate(y, scale_factor=2, mode="nearest")
+        return self.cv3(self.cv2(y))
+
+
+def build_head(A: int, head_depth: int, C: int, F_: int, NM: int = 0) -> nn.ModuleDict:
+    """model_v2.py:42-53 + bias init :7-14 (+ build-defined mask-coefficient conv `mc` when NM > 0)."""
     trunk = nn.Sequential(*[DWSmooth(F_, 1) for _ in range(head_depth)])
     out = nn.ModuleDict(dict(box=nn.Conv2d(F_, 4 * A, 1), obj=nn.Conv2d(F_, A, 1), cls=nn.Conv2d(F_, A * C, 1)))
+    if NM > 0:
+        out["mc"] = nn.Conv2d(F_, A * NM, 1)
     with torch.no_grad():
         out["obj"].bias.fill_(-math.log((1 - 0.01) / 0.01))
         out["cls"].bias.fill_(-math.log(C) if C > 1 else 0.0)
@@ -67,7 +85,8 @@ class DetectorOracle(nn.Module):
                  num_classes: int = 3, fpn_channels: int = 96,
                  num_anchors_per_level: Sequence[int] = (1, 1, 1),
                  depth_multiple: float = 1.0, width_multiple: float = 1.0, head_depth: int = 1,
-                 use_p6: bool = False, use_p2: bool = False, backbone_module: nn.Module = None):
+                 use_p6: bool = False, use_p2: bool = False, backbone_module: nn.Module = None,
+                 seg: bool = False, num_masks: int = 32, proto_channels: int = 64):
         super().__init__()
         arch_l = arch.lower()
         if arch_l not in ("yololitems", "yololitems_cpu"):
@@ -108,8 +127,11 @@ class DetectorOracle(nn.Module):
         self.num_anchors_per_level = tuple(amap[l] for l in self.levels)
         self.num_classes = int(num_classes)
         self.export_concat = False
+        self.num_masks = int(num_masks) if seg else 0
         for l in self.levels:
-            setattr(self, f"head{l[1]}", build_head(amap[l], head_depth, self.num_classes, Fc))
+            setattr(self, f"head{l[1]}", build_head(amap[l], head_depth, self.num_classes, Fc, self.num_masks))
+        if seg:
+            self.proto = ProtoNet(Fc, int(proto_channels), self.num_masks)
         self.fpn_strides = list(self.reductions) + ([self.reductions[-1] * 2] if use_p6 else [])
 
     # -- pieces ---------------------------------------------------------------------------
@@ -119,6 +141,8 @@ class DetectorOracle(nn.Module):
         parts = [hd["out"]["box"](t).view(B, A, 4, S, S),
                  hd["out"]["obj"](t).view(B, A, 1, S, S),
                  hd["out"]["cls"](t).view(B, A, self.num_classes, S, S)]
+        if self.num_masks:
+            parts.append(hd["out"]["mc"](t).view(B, A, self.num_masks, S, S))
         return torch.cat(parts, dim=2).permute(0, 1, 3, 4, 2).contiguous()
 
     def neck(self, feats: List[torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -142,6 +166,8 @@ class DetectorOracle(nn.Module):
         p = self.neck(feats)
         outs = [self._head(p[l], getattr(self, f"head{l[1]}"), A)
                 for l, A in zip(self.levels, self.num_anchors_per_level)]
+        if self.num_masks:                                              # build-defined: (levels, prototypes [B,NM,PH,PW])
+            return outs, self.proto(p["p3"])
         if self.export_concat:                                          # :57-64
             return torch.cat([o.reshape(o.shape[0], -1, o.shape[-1]) for o in outs], dim=1)
         return outs
@@ -167,7 +193,9 @@ def build_from_meta(meta: dict) -> DetectorOracle:
         depth_multiple=float(mcfg.get("depth_multiple", 1.0)),
         width_multiple=float(mcfg.get("width_multiple", 1.0)),
         head_depth=int(mcfg.get("head_depth", 1)),
-        use_p6=cfg["training"]["use_p6"], use_p2=cfg["training"]["use_p2"])
+        use_p6=cfg["training"]["use_p6"], use_p2=cfg["training"]["use_p2"],
+        seg=bool(mcfg.get("seg", False)), num_masks=int(mcfg.get("num_masks", 32)),
+        proto_channels=int(mcfg.get("proto_channels", 64)))
 
 
 # ------------------------------------------------------------------ synthetic weights

@@ -287,3 +287,36 @@ def backmap(boxes: np.ndarray, padx: float, pady: float, scale: float, w0: int, 
     b[:, [0, 2]] = np.clip(b[:, [0, 2]], 0, w0 - 1)
     b[:, [1, 3]] = np.clip(b[:, [1, 3]], 0, h0 - 1)
     return b
+
+
+# ------------------------------------------------------------------------------ instance masks (build-defined)
+@torch.no_grad()
+def split_mask_levels(levels, num_classes: int):
+    """rows [.., 5+C+NM] -> (detection levels [.., 5+C], coefficient levels [.., NM])."""
+    return [t[..., :5 + num_classes] for t in levels], [t[..., 5 + num_classes:] for t in levels]
+
+
+@torch.no_grad()
+def masks_for(levels, protos: torch.Tensor, num_classes: int, img_size: int, keep_idx, boxes_letterbox, thr: float = 0.5):
+    """BUILD-DEFINED (no reference code exists; parity unpinned).  For image b and its kept candidates
+    keep_idx[b] (indices into the concatenated candidate axis) with decoded boxes in network-input pixels:
+        m = sigmoid(coef . proto[b])  (proto [NM,PH,PW]);  mask = (m > thr) inside the box scaled to the
+    prototype grid (x1*PW/S <= x < x2*PW/S, same for y), 0 outside.  Returns list of uint8 [Ni,PH,PW]."""
+    _, coef_lv = split_mask_levels(levels, num_classes)
+    B, NM, PH, PW = protos.shape
+    coefs = torch.cat([c.reshape(B, -1, NM) for c in coef_lv], 1)
+    out = []
+    xs = torch.arange(PW, dtype=torch.float32)[None, None, :]
+    ys = torch.arange(PH, dtype=torch.float32)[None, :, None]
+    for b in range(B):
+        idx = torch.as_tensor(np.asarray(keep_idx[b], dtype=np.int64))
+        if idx.numel() == 0:
+            out.append(np.zeros((0, PH, PW), np.uint8))
+            continue
+        m = torch.sigmoid(torch.einsum("nk,kyx->nyx", coefs[b][idx], protos[b]))
+        bx = torch.as_tensor(np.asarray(boxes_letterbox[b], dtype=np.float32)).reshape(-1, 4)
+        x1, y1 = bx[:, 0] * (PW / img_size), bx[:, 1] * (PH / img_size)
+        x2, y2 = bx[:, 2] * (PW / img_size), bx[:, 3] * (PH / img_size)
+        inside = (xs >= x1[:, None, None]) & (xs < x2[:, None, None]) & (ys >= y1[:, None, None]) & (ys < y2[:, None, None])
+        out.append(((m > thr) & inside).numpy().astype(np.uint8))
+    return out

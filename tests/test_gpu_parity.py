@@ -364,3 +364,42 @@ def test_preprocess_bit_exact_vs_oracle(S):
         r = opre.resize_linear_u8(imgs[i], S, S)
         ref = ((r[..., ::-1].astype(np.float32) / 255.0 - opre.MEAN) / opre.STD).transpose(2, 0, 1)
         np.testing.assert_array_equal(x2[i].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("name,B,S", [("edge_n", 2, 128), ("edge_m", 2, 320)])
+def test_seg_model_forward_and_masks(name, B, S):
+    """BASELINE config 4 family (edge_m + instance-seg head; build-defined branch, parity unpinned -- the
+    reference has no mask code): levels incl. mask coefficients and prototypes vs the oracle's own
+    restatement, then masks for the HIP detections vs the oracle's mask assembly (mask IoU >= 0.999)."""
+    from yololite_amd.program import MODEL_ZOO
+    meta = make_meta(num_classes=80, img_size=S, seg=True, **MODEL_ZOO[name])
+    sd = synth_state_dict(meta, seed=3, head_noise=2.0)
+    x = _x(B, S, seed=5)
+    orc = _oracle_for(meta, sd)
+    with torch.no_grad():
+        ref_lv, ref_pr = orc(x)
+    m = _hip_for(meta, sd)
+    lv, pr = m(x.to(DEV))
+    _cmp_levels(lv, ref_lv)
+    assert pr.shape == ref_pr.shape == (B, 32, S // 4, S // 4)
+    assert (pr.cpu() - ref_pr).abs().max().item() <= 1e-4 + 1e-4 * ref_pr.abs().max().item()
+    ctx = m._ctx_for(S)
+    dets, counts, idx = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.02, 0.5, per_class_cap=300, want_idx=True)
+    masks = ctx.masks(counts, idx, dets.shape[1]).cpu().numpy()
+    cn = counts.cpu().numpy()
+    assert cn.min() > 3
+    lv_cpu = [t.cpu() for t in lv]
+    dec = opost.decode_levels([t[..., :85] for t in lv_cpu], S)
+    keep = [idx[b, :cn[b]].cpu().numpy() for b in range(B)]
+    boxes = [dec["box"][b][torch.as_tensor(keep[b], dtype=torch.long)].numpy() for b in range(B)]
+    exp = opost.masks_for(lv_cpu, pr.cpu(), 80, S, keep, boxes, thr=0.5)
+    for b in range(B):
+        got = masks[b, :cn[b]].astype(bool)
+        ref = exp[b].astype(bool)
+        inter, union = (got & ref).sum(), (got | ref).sum()
+        assert union > 0 and inter / union >= 0.999, (b, inter, union)
+    # detections themselves: same as the detector-only pipeline run on the detection part of the rows
+    exp_det = opost.pipeline_main([t[..., :85] for t in lv_cpu], S, 0.02, 0.5, 300)
+    for b in range(B):
+        d = dets[b, :cn[b]].cpu().numpy()
+        _match(d[:, :4], d[:, 4], d[:, 5].astype(np.int64), exp_det["boxes"][b], exp_det["scores"][b], exp_det["classes"][b])

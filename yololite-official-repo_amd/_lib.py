@@ -26,7 +26,7 @@ _ip = C.POINTER(C.c_int32)
 class yl_layer(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "op", "in_slot", "out_slot", "res_slot", "up_slot", "head_level", "cin", "cout",
-        "k", "stride", "pad_t", "pad_l", "act", "dw_k", "dw_stride", "dw_pad_t", "dw_pad_l", "dw_act")] + [
+        "k", "stride", "pad_t", "pad_l", "act", "in_shift", "dw_k", "dw_stride", "dw_pad_t", "dw_pad_l", "dw_act")] + [
         ("w", _fp), ("b", _fp), ("dw_w", _fp), ("dw_b", _fp),
         ("c2", C.c_int32), ("act2", C.c_int32), ("c3", C.c_int32), ("act3", C.c_int32),
         ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp)]
@@ -34,7 +34,8 @@ class yl_layer(C.Structure):
 
 class yl_model_desc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("img_size", C.c_int32), ("in_channels", C.c_int32),
-                ("num_classes", C.c_int32), ("num_levels", C.c_int32),
+                ("num_classes", C.c_int32), ("num_masks", C.c_int32), ("proto_slot", C.c_int32),
+                ("num_levels", C.c_int32),
                 ("level_size", C.c_int32 * YL_MAX_LEVELS), ("level_anchors", C.c_int32 * YL_MAX_LEVELS),
                 ("num_slots", C.c_int32), ("slot_h", _ip), ("slot_w", _ip), ("slot_c", _ip),
                 ("num_layers", C.c_int32), ("layers", C.POINTER(yl_layer))]
@@ -62,7 +63,8 @@ SYMBOLS = [
     ("yl_preprocess", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     ("yl_decode", C.c_int32, [_vp, _vpp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     ("yl_postprocess", C.c_int32, [_vp, _vpp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp, _vp]),
-    ("yl_predict", C.c_int32, [_vp, _vp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp]),
+    ("yl_predict", C.c_int32, [_vp, _vp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp, _vp]),
+    ("yl_masks", C.c_int32, [_vp, _vpp, C.c_int32, _vp, _vp, C.c_int32, C.c_float, _vp, _vp]),
     ("yl_nms", C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp]),
 ]
 

@@ -69,7 +69,13 @@ class YoloLite:
         bm[:, 2] = np.maximum(bm[:, 2], 1e-6)
         bm = bm.astype(np.float32)
         t1 = time.perf_counter()
-        dets, counts = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300, backmap=torch.from_numpy(bm))
+        masks = None
+        if ctx.NM:                                              # build-defined seg model: masks at prototype resolution
+            dets, counts, idx = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300,
+                                            backmap=torch.from_numpy(bm), want_idx=True)
+            masks = ctx.masks(counts, idx, dets.shape[1]).cpu().numpy()
+        else:
+            dets, counts = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300, backmap=torch.from_numpy(bm))
         cn = counts.cpu().numpy()
         d = dets.cpu().numpy()
         t2 = time.perf_counter()
@@ -77,7 +83,7 @@ class YoloLite:
         for b in range(len(imgs)):
             r = d[b, :min(int(cn[b]), d.shape[1])]
             out.append({"boxes": r[:, :4].copy(), "scores": r[:, 4].copy(), "classes": r[:, 5].astype(np.int64),
-                        "masks": None,
+                        "masks": (masks[b, :len(r)].copy() if masks is not None else None),
                         "speed": {"pre_ms": (t1 - t0) * 1e3 / len(imgs), "infer_post_ms": (t2 - t1) * 1e3 / len(imgs),
                                   "total_ms": (t2 - t0) * 1e3 / len(imgs)}})
         return out

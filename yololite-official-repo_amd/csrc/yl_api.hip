@@ -37,7 +37,7 @@ struct Slot {
 
 struct yl_ctx {
   int device = 0;
-  int img_size = 0, in_ch = 3, C = 0, L = 0, N = 0, E = 0;
+  int img_size = 0, in_ch = 3, C = 0, L = 0, N = 0, E = 0, NM = 0, proto_slot = -1;
   int level_S[YL_MAX_LEVELS] = {0}, level_A[YL_MAX_LEVELS] = {0}, level_off[YL_MAX_LEVELS + 1] = {0};
   std::vector<Slot> slots;
   std::vector<DevLayer> layers;
@@ -215,6 +215,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   p.B = B; p.H = L.in_h; p.W = L.in_w; p.Cin = d.cin;
   p.OH = L.out_h; p.OW = L.out_w; p.N = d.cout;
   p.k = d.k; p.stride = d.stride; p.pad_t = d.pad_t; p.pad_l = d.pad_l; p.act = d.act;
+  p.in_shift = d.in_shift;
   p.dw_k = d.dw_k; p.dw_stride = d.dw_stride; p.dw_pad_t = d.dw_pad_t; p.dw_pad_l = d.dw_pad_l; p.dw_act = d.dw_act;
   p.MH = L.out_h; p.MW = L.out_w;
   p.KB = cdiv(d.cin, 16);
@@ -451,7 +452,9 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   *out = c;   // handed out even on failure so that yl_last_error() can be read; caller destroys it
   c->device = device_id;
   c->img_size = d->img_size; c->in_ch = d->in_channels; c->C = d->num_classes; c->L = d->num_levels;
-  c->E = 5 + c->C;
+  c->NM = d->num_masks; c->proto_slot = d->proto_slot;
+  if (c->NM < 0 || c->NM > 64) return fail(c, YL_ERR_UNSUPPORTED, "num_masks must be in [0,64]");
+  c->E = 5 + c->C + c->NM;
   int off = 0;
   for (int l = 0; l < c->L; ++l) {
     c->level_S[l] = d->level_size[l]; c->level_A[l] = d->level_anchors[l];
@@ -501,6 +504,11 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     } else {
       if (l.in_slot < 0 || l.in_slot >= d->num_slots) return bad("bad in_slot");
       L.in_h = c->slots[l.in_slot].h; L.in_w = c->slots[l.in_slot].w;
+      if (l.in_shift != 0) {
+        if (l.op != YL_OP_CONV || l.k < 2 || l.dw_k != 0 || l.in_shift < 0 || l.in_shift > 3)
+          return bad("in_shift needs a kxk (k>1) conv without depthwise prologue");
+        L.in_h <<= l.in_shift; L.in_w <<= l.in_shift;          // dims of the virtually upsampled input
+      }
       const bool uib = (l.op == YL_OP_CONV && l.c2 > 0);
       if (c->slots[l.in_slot].c != (uib ? l.c2 : l.cin)) return bad("cin does not match the input slot");
       if (uib) {
@@ -524,7 +532,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     if (l.head_level >= 0) {
       if (l.op != YL_OP_CONV || l.head_level >= c->L) return bad("bad head_level");
       L.out_h = L.out_w = c->level_S[l.head_level];
-      if (l.cout != c->E) return bad("head layers must have cout = 5+C (one layer per anchor)");
+      if (l.cout != c->E) return bad("head layers must have cout = 5+C+NM (one layer per anchor)");
       L.head_anchor = head_seen[l.head_level]++;
       if (L.head_anchor >= c->level_A[l.head_level]) return bad("more head layers than anchors for this level");
       if (l.res_slot >= 0 || l.up_slot >= 0) return bad("head layers take no residual/upsample input");
@@ -614,6 +622,10 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   }
   for (int l = 0; l < c->L; ++l)
     if (head_seen[l] != c->level_A[l]) return fail(c, YL_ERR_INVALID, "every level needs one head layer per anchor");
+  if (c->NM > 0) {
+    if (c->proto_slot < 0 || c->proto_slot >= d->num_slots || c->slots[c->proto_slot].c != c->NM)
+      return fail(c, YL_ERR_INVALID, "num_masks > 0 needs proto_slot with num_masks channels");
+  }
   return YL_OK;
 }
 
@@ -626,7 +638,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
 }
 
 static yl_status forward_impl(yl_ctx* c, const float* x, int B, float* const* level_out, hipStream_t st,
-                              float* layer_ms, const yl_post_cfg* cfg, float* dets, int* counts) {
+                              float* layer_ms, const yl_post_cfg* cfg, float* dets, int* counts, int* keep_idx = nullptr) {
   if (!c) return YL_ERR_INVALID;
   if (c->layers.empty()) return fail(c, YL_ERR_STATE, "context was created without layers");
   if (!x || B < 1) return fail(c, YL_ERR_INVALID, "bad input");
@@ -635,7 +647,7 @@ static yl_status forward_impl(yl_ctx* c, const float* x, int B, float* const* le
   if (s != YL_OK) return s;
   if (cfg && (s = ensure_post(c, B)) != YL_OK) return s;
   Job j;
-  j.x = x; j.B = B; j.cfg = cfg; j.dets = dets; j.counts = counts;
+  j.x = x; j.B = B; j.cfg = cfg; j.dets = dets; j.counts = counts; j.keep_idx = keep_idx;
   for (int l = 0; l < c->L; ++l) j.outs[l] = (level_out && level_out[l]) ? level_out[l] : c->level_buf[l];
   if (layer_ms) {        // measurement path: one stream, one chunk, an event pair around every launch
     std::vector<hipEvent_t> ev(c->layers.size() + 1);
@@ -706,11 +718,28 @@ yl_status yl_postprocess(yl_ctx* c, const float* const* levels, int32_t B, const
 }
 
 yl_status yl_predict(yl_ctx* c, const float* x, int32_t B, const yl_post_cfg* cfg, float* dets, int32_t* counts,
-                     void* stream) {
+                     int32_t* keep_idx, void* stream) {
   if (!c || !dets || !counts) return YL_ERR_INVALID;
   yl_status s = check_cfg(c, cfg);
   if (s != YL_OK) return s;
-  return forward_impl(c, x, B, nullptr, (hipStream_t)stream, nullptr, cfg, dets, counts);
+  return forward_impl(c, x, B, nullptr, (hipStream_t)stream, nullptr, cfg, dets, counts, keep_idx);
+}
+
+yl_status yl_masks(yl_ctx* c, const float* const* levels, int32_t B, const int32_t* counts, const int32_t* keep_idx,
+                   int32_t max_out, float thr, uint8_t* masks, void* stream) {
+  if (!c || !counts || !keep_idx || !masks || B < 1 || max_out < 1) return YL_ERR_INVALID;
+  if (c->NM <= 0 || c->proto_slot < 0) return fail(c, YL_ERR_STATE, "context has no mask branch");
+  if (B > c->cap_batch || B > c->post_cap_batch || !c->slots[c->proto_slot].ptr)
+    return fail(c, YL_ERR_STATE, "yl_masks needs a preceding yl_predict / yl_forward+yl_postprocess of this batch");
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* lp[YL_MAX_LEVELS];
+  for (int l = 0; l < c->L; ++l) lp[l] = (levels && levels[l]) ? levels[l] : c->level_buf[l];
+  YlLevels lv;
+  fill_levels(c, lp, lv);
+  const Slot& ps = c->slots[c->proto_slot];
+  HIPCHK(c, yl_launch_masks(lv, B, ps.ptr, ps.h, ps.w, c->NM, c->img_size, c->ws_boxes, counts, keep_idx, max_out, thr,
+                            masks, (hipStream_t)stream));
+  return YL_OK;
 }
 
 yl_status yl_nms(yl_ctx* c, const float* boxes, const float* scores, int32_t n, float iou_thr, int32_t impl,

@@ -61,10 +61,14 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
   if (MODE == YL_CM_PW) {
     return yl_ld4(cin_ok ? p.x + px.lin * p.Cin + cs : p.zeros);
   } else if (MODE == YL_CM_KXK) {
+    // p.H/p.W are the dims of the (virtually upsampled) tensor the conv sees; the stored tensor is
+    // (H >> in_shift) x (W >> in_shift): nearest-neighbour upsampling folded into the addressing
     const int iy = px.oy * p.stride - p.pad_t + ky;
     const int ix = px.ox * p.stride - p.pad_l + kx;
     const bool in = cin_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    return yl_ld4(in ? p.x + (((size_t)px.b * p.H + iy) * p.W + ix) * p.Cin + cs : p.zeros);
+    const int sh = p.in_shift;
+    return yl_ld4(in ? p.x + (((size_t)px.b * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * p.Cin + cs
+                     : p.zeros);
   } else {  // depthwise prologue feeding a 1x1 conv: value of the dw output at (oy,ox)
     // depthwise taps and bias come from LDS (staged once per block): the vector-memory pipe only
     // carries the activation taps

@@ -63,6 +63,7 @@ struct YlConvP {
   int OH, OW, N;         // output tensor (N = Cout)
   int k, stride, pad_t, pad_l;
   int act;
+  int in_shift;          // KXK: input coordinates are shifted right by this (nearest 2^n upsample of x)
   int dw_k, dw_stride, dw_pad_t, dw_pad_l, dw_act;
   int MH, MW;            // grid the main conv reads (== H,W without prologue; dw output grid with it)
   int KB;                // ceil(Cin/16): 16-wide k blocks per tap
@@ -89,6 +90,9 @@ hipError_t yl_launch_decode_only(const YlLevels& lv, int B, int center_mode, int
                                  float* obj, float* cls, hipStream_t st);
 hipError_t yl_launch_nms(const YlNmsP& p, int B, hipStream_t st);
 hipError_t yl_launch_preprocess(const unsigned char* src, const void* imgs, int B, int S, float* out, hipStream_t st);
+hipError_t yl_launch_masks(const YlLevels& lv, int B, const float* proto, int PH, int PW, int NM, int img_size,
+                           const float4* boxes, const int* counts, const int* keep_idx, int max_out, float thr,
+                           unsigned char* masks, hipStream_t st);
 hipError_t yl_post_init();   // one-time function attributes (large dynamic LDS)
 
 hipError_t yl_launch_stem(const YlConvP& p, hipStream_t st);

@@ -469,6 +469,49 @@ __global__ __launch_bounds__(1024) void yl_nms_kernel(YlNmsP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// instance masks (build-defined, see include/yololite_hip.h): one block = 256 prototype pixels of one
+// detection; coefficients staged in LDS; pixels outside the box never touch the prototypes.
+__global__ __launch_bounds__(256) void yl_masks_kernel(YlLevels lv, const float* __restrict__ proto, int PH, int PW,
+                                                       int NM, float scale_x, float scale_y,
+                                                       const float4* __restrict__ boxes, const int* __restrict__ counts,
+                                                       const int* __restrict__ keep_idx, int max_out, float thr,
+                                                       unsigned char* __restrict__ masks) {
+  __shared__ float coef[64];
+  const int b = blockIdx.z, d = blockIdx.y;
+  if (d >= counts[b] || d >= max_out) return;
+  const int n = keep_idx[(size_t)b * max_out + d];
+  if (threadIdx.x < NM) {
+    const int l = yl_level_of(lv, n);
+    const int nl = lv.A[l] * lv.S[l] * lv.S[l];
+    coef[threadIdx.x] = lv.ptr[l][((size_t)b * nl + (n - lv.off[l])) * lv.E + 5 + lv.C + threadIdx.x];
+  }
+  __syncthreads();
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= PH * PW) return;
+  const int y = pix / PW, x = pix - y * PW;
+  const float4 bx = boxes[(size_t)b * lv.N + n];
+  const float x1 = bx.x * scale_x, y1 = bx.y * scale_y, x2 = bx.z * scale_x, y2 = bx.w * scale_y;
+  unsigned char out = 0;
+  if ((float)x >= x1 && (float)x < x2 && (float)y >= y1 && (float)y < y2) {
+    const float* pp = proto + (((size_t)b * PH + y) * PW + x) * NM;
+    float acc = 0.0f;
+    for (int k = 0; k < NM; ++k) acc = fmaf(coef[k], pp[k], acc);
+    out = (yl_sigmoid(acc) > thr) ? 1 : 0;
+  }
+  masks[(((size_t)b * max_out + d) * PH + y) * PW + x] = out;
+}
+
+hipError_t yl_launch_masks(const YlLevels& lv, int B, const float* proto, int PH, int PW, int NM, int img_size,
+                           const float4* boxes, const int* counts, const int* keep_idx, int max_out, float thr,
+                           unsigned char* masks, hipStream_t st) {
+  if (NM > 64) return hipErrorInvalidValue;
+  dim3 grid((PH * PW + 255) / 256, max_out, B);
+  hipLaunchKernelGGL(yl_masks_kernel, grid, dim3(256), 0, st, lv, proto, PH, PW, NM, (float)PW / (float)img_size,
+                     (float)PH / (float)img_size, boxes, counts, keep_idx, max_out, thr, masks);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 static int g_nms_lds_max = 0;
 
 hipError_t yl_post_init() {

@@ -28,7 +28,7 @@ class HipContext:
     """Owns one yl_ctx.  Post-processing-only contexts are created with no layers."""
 
     def __init__(self, img_size: int, num_classes: int, level_size: Sequence[int], level_anchors: Sequence[int],
-                 program: Optional[Program] = None, device: int = 0):
+                 program: Optional[Program] = None, device: int = 0, num_masks: int = 0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.YoloLiteHipError("no HIP device visible (torch.cuda.is_available() is False); "
@@ -38,10 +38,13 @@ class HipContext:
         self.level_size, self.level_anchors = [int(s) for s in level_size], [int(a) for a in level_anchors]
         self.L = len(self.level_size)
         self.N = sum(a * s * s for a, s in zip(self.level_anchors, self.level_size))
-        self.E = 5 + self.C
         d = _lib.yl_model_desc()
+        self.NM = int(program.num_masks) if program is not None else int(num_masks)
+        self.proto_slot = int(program.proto_slot) if program is not None else -1
+        self.E = 5 + self.C + self.NM
         d.abi_version, d.img_size, d.in_channels = _lib.YL_ABI_VERSION, self.img_size, 3
         d.num_classes, d.num_levels = self.C, self.L
+        d.num_masks, d.proto_slot = self.NM, self.proto_slot
         for i in range(self.L):
             d.level_size[i], d.level_anchors[i] = self.level_size[i], self.level_anchors[i]
         keep = []                                        # host arrays must outlive yl_create
@@ -67,7 +70,7 @@ class HipContext:
                 y = arr[i]
                 y.op, y.in_slot, y.out_slot, y.res_slot, y.up_slot = l.op, l.in_slot, l.out_slot, l.res_slot, l.up_slot
                 y.head_level, y.cin, y.cout = l.head_level, l.cin, l.cout
-                y.k, y.stride, y.pad_t, y.pad_l, y.act = l.k, l.stride, l.pad_t, l.pad_l, l.act
+                y.k, y.stride, y.pad_t, y.pad_l, y.act, y.in_shift = l.k, l.stride, l.pad_t, l.pad_l, l.act, l.in_shift
                 y.dw_k, y.dw_stride, y.dw_pad_t, y.dw_pad_l, y.dw_act = l.dw_k, l.dw_stride, l.dw_pad_t, l.dw_pad_l, l.dw_act
                 y.w, y.b, y.dw_w, y.dw_b = fp(l.w), fp(l.b), fp(l.dw_w), fp(l.dw_b)
                 y.c2, y.act2, y.c3, y.act3 = l.c2, l.act2, l.c3, l.act3
@@ -76,6 +79,7 @@ class HipContext:
             d.layers = arr
             keep.append(arr)
         self.num_layers = int(d.num_layers)
+        self.proto_shape = tuple(program.slots[self.proto_slot]) if self.proto_slot >= 0 else None
         h = C.c_void_p()
         st = self.lib.yl_create(C.byref(d), device, C.byref(h))
         self.handle = h
@@ -191,8 +195,28 @@ class HipContext:
                                            _stream_ptr(self.device)), self.handle, "yl_postprocess")
         return (dets, counts, idx) if want_idx else (dets, counts)
 
+    def prototypes(self, B: int) -> torch.Tensor:
+        """mask prototypes of the last forward/predict as [B,NM,PH,PW] (the device tensor is NHWC)."""
+        if self.proto_slot < 0:
+            raise _lib.YoloLiteHipError("model has no mask branch")
+        return self.read_slot(self.proto_slot, B, self.proto_shape).permute(0, 3, 1, 2)
+
+    def masks(self, counts: torch.Tensor, keep_idx: torch.Tensor, max_out: int, thr: float = 0.5,
+              levels: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        """uint8 [B,max_out,PH,PW] instance masks of the detections of the last predict()/postprocess()
+        (build-defined semantics, see include/yololite_hip.h: yl_masks)."""
+        B = counts.shape[0]
+        ph, pw, _ = self.proto_shape
+        out = torch.zeros((B, max_out, ph, pw), device=self.device, dtype=torch.uint8)
+        arr = None
+        if levels is not None:
+            arr = self._ptr_array(self._check_levels(levels))
+        _lib.check(self.lib.yl_masks(self.handle, arr, B, counts.data_ptr(), keep_idx.data_ptr(), int(max_out),
+                                     float(thr), out.data_ptr(), _stream_ptr(self.device)), self.handle, "yl_masks")
+        return out
+
     def predict(self, x: torch.Tensor, mode, conf, iou, per_class_cap=300, topk=0, max_out=None, backmap=None,
-                out: Optional[tuple] = None):
+                out: Optional[tuple] = None, want_idx: bool = False):
         """Fused forward + post-processing on the context's own level buffers (no raw output copy)."""
         B = x.shape[0]
         if max_out is None:
@@ -205,9 +229,11 @@ class HipContext:
             counts = torch.empty((B,), device=self.device, dtype=torch.int32)
         else:
             dets, counts = out
+        idx = torch.empty((B, max_out), device=self.device, dtype=torch.int32) if want_idx else None
         _lib.check(self.lib.yl_predict(self.handle, x.data_ptr(), B, C.byref(cfg), dets.data_ptr(), counts.data_ptr(),
-                                       _stream_ptr(self.device)), self.handle, "yl_predict")
-        return dets, counts
+                                       idx.data_ptr() if want_idx else None, _stream_ptr(self.device)),
+                   self.handle, "yl_predict")
+        return (dets, counts, idx) if want_idx else (dets, counts)
 
     def nms(self, boxes: torch.Tensor, scores: torch.Tensor, iou_thr: float, max_det: int = 300,
             impl: int = _lib.NMS_TORCHVISION) -> torch.Tensor:
@@ -296,7 +322,10 @@ class YOLOLiteHIP:
     def __call__(self, x: torch.Tensor):
         if self.ctx is None:
             raise RuntimeError("model.to('cuda') first")
-        outs = self._ctx_for(int(x.shape[-1])).forward(x)
+        ctx = self._ctx_for(int(x.shape[-1]))
+        outs = ctx.forward(x)
+        if ctx.NM:                                  # build-defined seg model: (levels, prototypes [B,NM,PH,PW])
+            return outs, ctx.prototypes(x.shape[0])
         if self.export_concat:                      # model_v2.py:57-64
             B = outs[0].shape[0]
             return torch.cat([o.view(B, -1, o.shape[-1]) for o in outs], dim=1)

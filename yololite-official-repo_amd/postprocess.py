@@ -28,15 +28,16 @@ def _levels_list(preds):
     return [t if t.dim() == 5 else t.unsqueeze(1) for t in lv]
 
 
-def context_for(levels: Sequence[torch.Tensor], img_size: int) -> HipContext:
-    """A (cached) post-processing-only context matching the level geometry."""
+def context_for(levels: Sequence[torch.Tensor], img_size: int, num_masks: int = 0) -> HipContext:
+    """A (cached) post-processing-only context matching the level geometry (num_masks: trailing mask
+    coefficients per row of a build-defined seg model)."""
     lv = _levels_list(levels)
     dev = lv[0].device if lv[0].is_cuda else torch.device("cuda", torch.cuda.current_device()
                                                            if torch.cuda.is_available() else 0)
-    key = (int(img_size), int(lv[0].shape[-1]) - 5, tuple(int(t.shape[2]) for t in lv),
-           tuple(int(t.shape[1]) for t in lv), dev.index or 0)
+    key = (int(img_size), int(lv[0].shape[-1]) - 5 - int(num_masks), tuple(int(t.shape[2]) for t in lv),
+           tuple(int(t.shape[1]) for t in lv), dev.index or 0, int(num_masks))
     if key not in _CTX_CACHE:
-        _CTX_CACHE[key] = HipContext(key[0], key[1], key[2], key[3], None, key[4])
+        _CTX_CACHE[key] = HipContext(key[0], key[1], key[2], key[3], None, key[4], num_masks=key[5])
     return _CTX_CACHE[key]
 
 
@@ -98,13 +99,13 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_th: float = 0.5, max_det:
 
 @torch.no_grad()
 def infer_main_postprocess(preds, img_size: int, conf: float = 0.4, iou: float = 0.5, per_class_cap: int = 300,
-                           backmap: Optional[Sequence[Sequence[float]]] = None):
+                           backmap: Optional[Sequence[Sequence[float]]] = None, num_masks: int = 0):
     """The main-path block of tools/infer.py:460-516 for a whole batch: decode, score, `> conf`,
     per-class NMS (cap 300/class, the nms() default -- the CLI's --max_det is not forwarded there),
     optional back-map to the original image (padx, pady, scale, w0, h0 per image).
     Returns {"boxes","scores","classes"} lists of numpy arrays (classes int64)."""
     lv = _levels_list(preds)
-    ctx = context_for(lv, img_size)
+    ctx = context_for(lv, img_size, num_masks)
     bm = None
     if backmap is not None:
         arr = np.asarray(backmap, dtype=np.float64).reshape(len(backmap), 5).copy()

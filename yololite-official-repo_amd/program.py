@@ -80,6 +80,7 @@ class Layer:
     act: int
     w: np.ndarray
     b: Optional[np.ndarray]
+    in_shift: int = 0           # conv reads its input nearest-upsampled by 2**in_shift
     res_slot: int = -1
     up_slot: int = -1
     head_level: int = -1
@@ -116,6 +117,8 @@ class Program:
     used_keys: set = field(default_factory=set)
     known_keys: set = field(default_factory=set)
     feature_slots: Dict[str, int] = field(default_factory=dict)           # c3/c4/c5/p3/... for tests
+    num_masks: int = 0          # build-defined instance-mask branch (0 = detector)
+    proto_slot: int = -1
 
     @property
     def macs(self):
@@ -142,7 +145,7 @@ class SynthStateDict(dict):
             if key.endswith(".weight"):
                 v = r.randn(*shape) * (math.sqrt(1.0 / shape[1]) * (1.0 + self.head_noise))
             else:
-                base = {"obj": -math.log(99.0), "cls": (-math.log(self.C) if self.C > 1 else 0.0), "box": 0.0}
+                base = {"obj": -math.log(99.0), "cls": (-math.log(self.C) if self.C > 1 else 0.0), "box": 0.0, "mc": 0.0}
                 v = base[key.split(".")[-2]] + r.randn(*shape) * self.head_noise
         elif key.endswith("running_var"):
             v = r.rand(*shape) + 0.5
@@ -166,14 +169,16 @@ def synth_state_dict(meta: dict, seed: int = 0, head_noise: float = 0.5) -> Dict
 
 def make_meta(arch: str, backbone: str, num_classes: int = 80, img_size: int = 640, fpn_channels: int = 128,
               depth_multiple: float = 1.0, width_multiple: float = 1.0, head_depth: int = 1, use_p6: bool = False,
-              use_p2: bool = False, anchors: int = 1, names=None) -> dict:
+              use_p2: bool = False, anchors: int = 1, names=None, seg: bool = False, num_masks: int = 32,
+              proto_channels: int = 64) -> dict:
     """A `meta` dict shaped like the one the reference stores in checkpoints (tools/train.py:62-75)."""
     nl = 3 + int(use_p6) + int(use_p2)
     return dict(metric_key="map50", metric_value=-1.0, names=names, num_classes=num_classes, img_size=img_size,
                 arch=arch, backbone=backbone, num_anchors_per_level=(anchors,) * nl,
                 config=dict(model=dict(arch=arch, backbone=backbone, num_classes=num_classes, fpn_channels=fpn_channels,
                                        depth_multiple=depth_multiple, width_multiple=width_multiple,
-                                       head_depth=head_depth),
+                                       head_depth=head_depth, **(dict(seg=True, num_masks=num_masks,
+                                                                      proto_channels=proto_channels) if seg else {})),
                             training=dict(img_size=img_size, use_p6=use_p6, use_p2=use_p2)))
 
 
@@ -193,6 +198,7 @@ MODEL_ZOO = {
 
 
 def zoo_meta(name: str, num_classes: int = 80, img_size: int = 640, **kw) -> dict:
+    """meta for one of the reference's configs/models/*.yaml (kw: use_p6, use_p2, anchors, seg, ...)."""
     return make_meta(num_classes=num_classes, img_size=img_size, **MODEL_ZOO[name], **kw)
 
 
@@ -312,10 +318,11 @@ class _Builder:
         return o
 
     def conv(self, x, conv, bn, eps, act, cout, k=1, s=1, same=False, bias=False, res=-1, up=-1, head_level=-1,
-             dw=None, out_hw=None, wb=None, name=None):
+             dw=None, out_hw=None, wb=None, name=None, in_shift=0):
         """dense conv; dw = dict(conv=..., bn=..., eps=..., act=..., k=..., s=..., bias=False) is a depthwise
         conv applied to x first (fused as a prologue when enabled, otherwise emitted as its own layer)."""
         h, wd, cin = self.dims(x)
+        h, wd = h << in_shift, wd << in_shift           # the conv sees the nearest-upsampled tensor
         pro = None
         if dw is not None:
             dww, dwb = self.fold(dw["conv"], dw.get("bn"), dw.get("eps", 1e-5), dw.get("bias", False),
@@ -349,7 +356,7 @@ class _Builder:
             o = -1
         else:
             o = self.slot(oh, ow, cout)
-        L = Layer(_OP_CONV, x, o, cin, cout, k, s, pad, pad, _ACT[act], w, b, res_slot=res, up_slot=up,
+        L = Layer(_OP_CONV, x, o, cin, cout, k, s, pad, pad, _ACT[act], w, b, in_shift=in_shift, res_slot=res, up_slot=up,
                   head_level=head_level, name=name or conv, macs=oh * ow * cout * cin * k * k,
                   bytes_in=4 * h * wd * cin, bytes_out=4 * oh * ow * cout)
         if res >= 0 or up >= 0:
@@ -462,6 +469,10 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     if arch not in ("yololitems", "yololitems_cpu"):
         raise ValueError(f"Okänd arch i meta/config: {arch}")
     cpu_arch = arch == "yololitems_cpu"
+    # build-defined instance-segmentation branch (the reference has no mask code): config.model.seg
+    seg = bool(mcfg.get("seg", False))
+    NM = int(mcfg.get("num_masks", 32)) if seg else 0
+    Cp = int(mcfg.get("proto_channels", 64))
 
     if isinstance(state_dict, SynthStateDict):
         sd = state_dict
@@ -522,6 +533,12 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
                                                     ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")])
     for n_ in levels:
         prog.feature_slots[n_] = P[n_]
+    if seg:
+        # prototypes on P3: conv3x3+BN+SiLU -> nearest x2 (folded into the next conv's addressing) -> conv3x3 -> conv1x1
+        y = b.conv(P["p3"], "proto.cv1.0", "proto.cv1.1", 1e-5, "silu", Cp, k=3)
+        y = b.conv(y, "proto.cv2.0", "proto.cv2.1", 1e-5, "silu", Cp, k=3, in_shift=1)
+        prog.proto_slot = b.conv(y, "proto.cv3.0", "proto.cv3.1", 1e-5, "silu", NM, k=1)
+        prog.num_masks = NM
 
     # heads (model_v2.py:42-53,340-350): trunk, then box/obj/cls 1x1 convs fused into ONE GEMM per anchor
     for li, n_ in enumerate(levels):
@@ -535,10 +552,15 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
         wbox, bbox_ = b.get(f"head{k}.out.box.weight", (4 * A, F_, 1, 1)), b.get(f"head{k}.out.box.bias", (4 * A,))
         wobj, bobj = b.get(f"head{k}.out.obj.weight", (A, F_, 1, 1)), b.get(f"head{k}.out.obj.bias", (A,))
         wcls, bcls = b.get(f"head{k}.out.cls.weight", (A * C, F_, 1, 1)), b.get(f"head{k}.out.cls.bias", (A * C,))
+        if seg:
+            wmc, bmc = b.get(f"head{k}.out.mc.weight", (A * NM, F_, 1, 1)), b.get(f"head{k}.out.mc.bias", (A * NM,))
         for a in range(A):                                  # conv channels are anchor-major (view(B,A,4,S,S))
             w = np.concatenate([wbox[4 * a:4 * a + 4], wobj[a:a + 1], wcls[C * a:C * (a + 1)]], 0)
             bb = np.concatenate([bbox_[4 * a:4 * a + 4], bobj[a:a + 1], bcls[C * a:C * (a + 1)]], 0)
-            b.conv(x, None, None, 0.0, "none", 5 + C, head_level=li,
+            if seg:
+                w = np.concatenate([w, wmc[NM * a:NM * (a + 1)]], 0)
+                bb = np.concatenate([bb, bmc[NM * a:NM * (a + 1)]], 0)
+            b.conv(x, None, None, 0.0, "none", 5 + C + NM, head_level=li,
                    wb=(np.ascontiguousarray(w, np.float32), np.ascontiguousarray(bb, np.float32)),
                    name=f"head{k}.out[a={a}]")
         prog.level_size.append(hs)
