@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B helper: build a variant of libyololite_hip.so with extra -D flags for ONE translation unit.
+#   tools/build_variant.sh NAME UNIT.hip -DFOO=1 ...   ->  _variants/libyololite_hip_NAME.so
+# Run with  YOLOLITE_HIP_LIB=_variants/libyololite_hip_NAME.so python bench.py ...
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+CS=$ROOT/yololite-official-repo_amd/csrc
+NAME=$1; UNIT=$2; shift 2
+mkdir -p $ROOT/_variants/obj_$NAME
+EXTRA=""
+case $UNIT in yl_post.hip|yl_pre.hip) EXTRA="-ffp-contract=off";; esac
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value $EXTRA "$@" \
+  -c $CS/$UNIT -o $ROOT/_variants/obj_$NAME/${UNIT%.hip}.o
+OBJS=""
+for u in yl_api yl_conv yl_stemblock yl_post yl_pre; do
+  if [ "$u.hip" == "$UNIT" ]; then OBJS="$OBJS $ROOT/_variants/obj_$NAME/$u.o"; else OBJS="$OBJS $CS/_obj/$u.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/_variants/libyololite_hip_$NAME.so $OBJS
+echo $ROOT/_variants/libyololite_hip_$NAME.so

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyololite_hip.so")
+# YOLOLITE_HIP_LIB selects another build of the same ABI (kernel A/B runs); default: the in-tree library
+LIB_PATH = os.environ.get("YOLOLITE_HIP_LIB") or os.path.join(_HERE, "libyololite_hip.so")
 
 YL_ABI_VERSION = 1
 YL_MAX_LEVELS = 8

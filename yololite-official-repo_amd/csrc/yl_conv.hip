@@ -402,6 +402,19 @@ __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
 //   3. feeds 4 MFMA k-steps per n-tile,
 // so the depthwise input is fetched from L2/HBM once per tile instead of DK*DK times and the hot loop
 // has no bounds logic.  Requires OH % 4 == 0 and OW % 4 == 0 (else the DW3/DW5 global-tap modes run).
+// A/B switches (tools/build_variant.sh; measured on edge_n B=64, profiles/README.md):
+//   YL_DWH_XTILE  software-pipeline the halo staging across tile boundaries      (+0.5 %, within noise: off)
+//   YL_DWH_BUF    raw buffer loads (hardware range check) instead of address select (-3.7 %: off)
+//   YL_DWH_PREADD residual initialises the accumulators                            (-1.7 us per residual layer: on)
+#ifndef YL_DWH_XTILE
+#define YL_DWH_XTILE 0
+#endif
+#ifndef YL_DWH_BUF
+#define YL_DWH_BUF 0
+#endif
+#ifndef YL_DWH_PREADD
+#define YL_DWH_PREADD 1
+#endif
 template <int NT, int DK, int DS>
 __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
   constexpr int HP = 3 * DS + DK;                         // halo edge in pixels
@@ -427,6 +440,74 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
   const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
 
+
+  const int tw = p.OW >> 2, th = p.OH >> 2;
+  const int tiles_img = tw * th;
+  const int ntiles = p.B * tiles_img;
+  const int wstride = gridDim.x * 4;
+  // lane constants: LDS offsets of the staging slots (halo pixel / channel quad) and the read base of the
+  // lane's output pixel
+  int s_lo[NSLOT];
+  bool s_ok[NSLOT];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int e = j * 64 + lane;
+    s_ok[j] = e < HF4;
+    const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
+    const int hr = hp / HP, hc = hp - hr * HP;
+    s_lo[j] = hr * PITCHF + hc * 16 + quad * 4;
+  }
+  const int rbase = ((pl >> 2) * DS) * PITCHF + ((pl & 3) * DS) * 16 + 4 * kq;
+
+  // residual add without activation: the addend initialises the accumulators (loads issued at tile start)
+  const bool pre_add = YL_DWH_PREADD && p.res != nullptr && p.up == nullptr && p.act == YL_ACT_NONE;
+  // The depthwise input is read through a raw buffer descriptor: 32-bit byte offsets, and an offset at or
+  // beyond num_records (image border, channel tail) returns 0 from the hardware range check -- no bounds
+  // selects, no 64-bit address arithmetic in the loop.  The launcher guarantees the tensor is < 2 GiB.
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)((long)p.B * p.H * p.W * p.Cin * 4), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned goff[NSLOT];        // byte offsets of the lane's staging slots (channel block 0) for one tile
+  auto tile_geom = [&](int tile) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tw, txi = trem - tyi * tw;
+    const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * txi * DS - p.dw_pad_l;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int e = j * 64 + lane;
+      const int hp = (e < HF4 ? e : 0) >> 2;
+      const int hr = hp / HP, hc = hp - hr * HP;
+      const int iy = iy0 + hr, ix = ix0 + hc;
+      const bool in = e < HF4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      goff[j] = in ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.Cin + (lane & 3) * 4) * 4) : OOB;
+    }
+  };
+  auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
+    const bool cok = kb * 16 + (lane & 3) * 4 < p.Cin;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const unsigned off = cok ? goff[j] + (unsigned)kb * 64u : OOB;
+#if YL_DWH_BUF
+      r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+#else
+      r[j] = yl_ld4(off < OOB ? p.x + (off >> 2) : p.zeros);
+#endif
+    }
+  };
+  auto stage_store = [&](const f32x4 (&r)[NSLOT]) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+      if (s_ok[j]) *reinterpret_cast<f32x4*>(halo + s_lo[j]) = r[j];
+  };
+  f32x4 stg[NSLOT];
+  int tile = blockIdx.x * 4 + wave;
+#if YL_DWH_XTILE
+  if (tile < ntiles) {                  // software pipeline over (tile, channel block): prime with (tile0, 0);
+    tile_geom(tile);                    // its loads fly under the weight fill below
+    stage_load(0, stg);
+  }
+#endif
   for (int t = wave; t < KB; t += 4) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -441,66 +522,43 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
     for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = p.dw_b ? p.dw_b[i] : 0.0f;
   }
   __syncthreads();
-
-  const int tw = p.OW >> 2, th = p.OH >> 2;
-  const int tiles_img = tw * th;
-  const int ntiles = p.B * tiles_img;
-  const int wstride = gridDim.x * 4;
-  // lane constants: staging slots (halo pixel / channel quad) and the read base of the lane's output pixel
-  int s_hr[NSLOT], s_hc[NSLOT], s_lo[NSLOT];
-  bool s_ok[NSLOT];
-#pragma unroll
-  for (int j = 0; j < NSLOT; ++j) {
-    const int e = j * 64 + lane;
-    s_ok[j] = e < HF4;
-    const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
-    s_hr[j] = hp / HP;
-    s_hc[j] = hp - s_hr[j] * HP;
-    s_lo[j] = s_hr[j] * PITCHF + s_hc[j] * 16 + quad * 4;
-  }
-  const int rbase = ((pl >> 2) * DS) * PITCHF + ((pl & 3) * DS) * 16 + 4 * kq;
-
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += wstride) {
+#if YL_DWH_XTILE
+  if (tile < ntiles) stage_store(stg);
+#endif
+  for (; tile < ntiles; tile += wstride) {
     const int b = tile / tiles_img;
     const int trem = tile - b * tiles_img;
     const int tyi = trem / tw, txi = trem - tyi * tw;
+    const int ntile = tile + wstride;
     YlPix px[MT];
     px[0].b = b;
     px[0].oy = 4 * tyi + (pl >> 2);
     px[0].ox = 4 * txi + (pl & 3);
     px[0].valid = true;
     px[0].lin = ((size_t)b * p.OH + px[0].oy) * p.OW + px[0].ox;
-    // global element offsets of the lane's staging slots (channel block 0), -1 = outside the image
-    const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * txi * DS - p.dw_pad_l;
-    long goff[NSLOT];
-#pragma unroll
-    for (int j = 0; j < NSLOT; ++j) {
-      const int iy = iy0 + s_hr[j], ix = ix0 + s_hc[j];
-      const bool in = s_ok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      goff[j] = in ? ((((long)b * p.H + iy) * p.W + ix) * p.Cin + (lane & 3) * 4) : -1;
-    }
-    auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
-#pragma unroll
-      for (int j = 0; j < NSLOT; ++j) {
-        const int c = kb * 16 + (lane & 3) * 4;
-        const bool ok = goff[j] >= 0 && c < p.Cin;
-        r[j] = yl_ld4(ok ? p.x + goff[j] + kb * 16 : p.zeros);
-      }
-    };
-    auto stage_store = [&](const f32x4 (&r)[NSLOT]) {
-#pragma unroll
-      for (int j = 0; j < NSLOT; ++j)
-        if (s_ok[j]) *reinterpret_cast<f32x4*>(halo + s_lo[j]) = r[j];
-    };
     f32x4 acc[MT][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 stg[NSLOT];
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int n = (nt0 + nt) * 16 + 4 * kq;
+      if (pre_add && n < p.N) acc[0][nt] = yl_ld4(p.res + px[0].lin * p.N + n);
+    }
+#if !YL_DWH_XTILE
+    tile_geom(tile);
     stage_load(0, stg);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // previous tile's halo reads are complete
     stage_store(stg);
+#endif
     for (int kb = 0; kb < KB; ++kb) {
-      if (kb + 1 < KB) stage_load(kb + 1, stg);                       // next channel block: loads in flight
+      // next (tile, channel block) of the pipeline: loads in flight under this step's taps and MFMAs
+#if YL_DWH_XTILE
+      const bool more = kb + 1 < KB || ntile < ntiles;
+      if (kb + 1 < KB) stage_load(kb + 1, stg);
+      else if (ntile < ntiles) { tile_geom(ntile); stage_load(0, stg); }
+#else
+      const bool more = kb + 1 < KB;
+      if (more) stage_load(kb + 1, stg);
+#endif
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // halo writes (all lanes) -> tap reads
       const int c = kb * 16 + 4 * kq;
       const int cs = c < p.Cin ? c : p.Cin - 4;
@@ -537,13 +595,12 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[nt][ss], xq[ss], acc[0][nt], 0, 0, 0);
-      if (kb + 1 < KB) {
+      if (more) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // this step's tap reads are complete
         stage_store(stg);
       }
     }
-    if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi, nullptr, 0, lane);
-    else if (p.res || p.up || p.act == YL_ACT_SILU) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
   }
 }
@@ -1022,11 +1079,11 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
   }
   // depthwise prologue with LDS-staged halo tiles (4x4 output pixels per wave)
   if (p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.OH & 3) == 0 &&
-      (p.OW & 3) == 0 && tile_hint != 3) {
+      (p.OW & 3) == 0 && (p.N & 3) == 0 && tile_hint != 3) {
     const int HP = 3 * p.dw_stride + p.dw_k;
     const int PITCHF = ((HP * 16 + 7) / 64) * 64 + 56;
     const size_t lds = (size_t)p.KB * NT * 1024 + (size_t)(p.dw_k * p.dw_k + 1) * p.Cin * 4 + (size_t)4 * HP * PITCHF * 4;
-    if (lds <= YL_DWH_LDS_MAX) {
+    if (lds <= YL_DWH_LDS_MAX && (size_t)p.B * p.H * p.W * p.Cin * 4 < ((size_t)1 << 31)) {
       const long wtiles = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
       int res = 0;
       switch (NT) {
