@@ -64,6 +64,69 @@ def cpu_baseline(meta, sd, S, conf, iou, budget_s=12.0, bs=8):
                       f"{el:.1f} s wall, torch {n} threads of {os.cpu_count()} logical CPUs"}
 
 
+def synth_coco(n_img, n_cls=80, gt_per_img=8, det_per_img=100, seed=5):
+    """COCO-style annotation / detection lists of an evaluation pass (conf 0.001 keeps ~100 dets/img)."""
+    r = np.random.RandomState(seed)
+    anns, dets = [], []
+    for img in range(1, n_img + 1):
+        g = np.c_[r.uniform(0, 500, (gt_per_img, 2)), r.uniform(10, 140, (gt_per_img, 2))]
+        gc = r.randint(1, n_cls + 1, gt_per_img)
+        for k in range(gt_per_img):
+            anns.append({"image_id": img, "category_id": int(gc[k]), "bbox": [float(v) for v in g[k]]})
+        j = r.randint(gt_per_img, size=det_per_img)
+        near = r.rand(det_per_img) < 0.5
+        b = np.where(near[:, None], g[j] * (1 + r.normal(0, 0.08, (det_per_img, 4))),
+                     np.c_[r.uniform(0, 500, (det_per_img, 2)), r.uniform(10, 140, (det_per_img, 2))]).astype(np.float32)
+        c = np.where(near, gc[j], r.randint(1, n_cls + 1, det_per_img))
+        sc = r.rand(det_per_img).astype(np.float32)
+        for k in range(det_per_img):
+            dets.append({"image_id": img, "category_id": int(c[k]), "bbox": [float(v) for v in b[k]],
+                         "score": float(sc[k])})
+    return anns, dets
+
+
+def bench_eval_consumers(args):
+    """--workload eval: the evaluate-path consumers -- P/R/F1 curves (201 steps) and the
+    detection confusion matrix over one validation pass of N images x 100 detections.  Separate JSON line;
+    the headline workload is unaffected."""
+    from yololite_amd import evalops
+    n_img = args.batch * 32                               # 2048 images at the default batch
+    anns, dets = synth_coco(n_img)
+    names = [f"c{i}" for i in range(80)]
+
+    def step():
+        s = evalops.build_curves_from_coco([], anns, dets, None, iou=0.5, steps=201)
+        cm = evalops.confusion_matrix_counts(anns, dets, 80, 0.5, s["best_conf"])
+        return s, cm
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / args.steps
+    out = {"metric": "eval detections/sec (P/R/F1 sweep + confusion matrix)", "value": round(len(dets) / el, 1),
+           "unit": "detections/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(el * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64/f32", "data": "synthetic",
+           "config": {"workload": f"{n_img} images x 100 detections x 8 ground truths, 80 classes, host list "
+                                  f"-> array conversion included"}}
+    if not args.no_cpu_baseline:
+        from oracle import evalcons as oeval              # checker code, used only as the timed baseline
+        m = n_img                                         # the whole pass: ~10 s of python loops
+        a2 = [a for a in anns if a["image_id"] <= m]
+        d2 = [d for d in dets if d["image_id"] <= m]
+        t0 = time.perf_counter()
+        s = oeval.build_curves_from_coco([], a2, d2, None, iou=0.5, steps=201)
+        oeval.confusion_matrix_counts(a2, d2, 80, 0.5, s["best_conf"])
+        cel = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(len(d2) / cel, 1), "unit": "detections/sec", "cores": 1, "kind": "port",
+                               "sample": f"{m} images ({len(d2)} detections) of the same lists, {cel:.1f} s wall, "
+                                         f"python loops as in the reference"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +146,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="internal streams the batch is split over")
     ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
+    ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -90,6 +154,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback exists)"
     torch.cuda.set_device(local)
+    if args.workload == "eval":
+        import yololite_amd  # noqa: F401
+        if rank == 0:
+            bench_eval_consumers(args)
+        return
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     force_coll = os.environ.get("YL_BENCH_FORCE_COLLECTIVE") == "1"      # test hook: collective path at world 1

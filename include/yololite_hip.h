@@ -214,6 +214,48 @@ yl_status yl_masks(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, c
 yl_status yl_nms(yl_ctx* ctx, const float* boxes_dev, const float* scores_dev, int32_t n, float iou_thr,
                  int32_t nms_impl, int32_t max_det, int32_t* keep_dev, int32_t* count_dev, void* stream);
 
+/* ---- evaluate-path consumers ----------------------------------------------
+ * The two O(detections x ground truths) matching loops of the reference's evaluation, as device
+ * kernels.  They take no context (stateless; current HIP device); all pointers are device pointers.
+ *
+ * yl_eval_match replaces the greedy per-(image, category) matching of build_curves_from_coco
+ * (scripts/data/p_r_f1.py:31-78 and :100-118).  Keys k = 0..num_keys-1 are the distinct
+ * (image_id, category_id) pairs; detections of key k are rows det_off[k]..det_off[k+1]-1 of det_xywh,
+ * ALREADY in score-descending stable order; ground truths likewise through gt_off.  Boxes are
+ * [x,y,w,h] float64 exactly as the reference's python floats; IoU is evaluated in float64 with the
+ * reference's operation order (iou_xywh, p_r_f1.py:31-41).  For every detection, in order: the
+ * not-yet-matched ground truth with the largest IoU > 0 (first index on ties) is taken; if that IoU
+ * >= iou_thr the detection is a true positive and the ground truth becomes matched.
+ *   tp_dev[Nd]     1 = true positive, 0 = false positive
+ *   match_dev[Nd]  index (within the key) of the matched ground truth, -1 if none   (may be NULL)
+ *   gt_matched_dev[Ng]  scratch AND output: zeroed by the call, 1 where a ground truth was matched */
+yl_status yl_eval_match(const double* det_xywh_dev, const int32_t* det_off_dev, const double* gt_xywh_dev,
+                        const int32_t* gt_off_dev, int32_t num_keys, int32_t num_gt, double iou_thr,
+                        uint8_t* tp_dev, int32_t* match_dev, uint8_t* gt_matched_dev, void* stream);
+/* The 0..1 confidence sweep of build_curves_from_coco (p_r_f1.py:96-124): for every threshold
+ * thr[s] (ascending float64, the reference uses np.linspace(0,1,steps)) the number of true / false
+ * positives among the counted detections with score >= thr[s].  Because the greedy matching of a
+ * score-descending list is prefix-stable, these are suffix sums of a histogram of the tp flags of ONE
+ * matching pass (yl_eval_match) -- the reference re-runs the matching per threshold.
+ *   counted_dev[n] 1 = detection takes part in the sweep (its key has ground truth), may be NULL = all
+ *   tp_ge_dev[steps], fp_ge_dev[steps]  int32 outputs                                                   */
+yl_status yl_eval_sweep(const double* score_dev, const uint8_t* tp_dev, const uint8_t* counted_dev, int32_t n,
+                        const double* thr_dev, int32_t steps, int32_t* tp_ge_dev, int32_t* fp_ge_dev,
+                        void* stream);
+/* Replaces the matching loops of create_confusion_matrix (scripts/helpers/evaluate.py:96-153).
+ * Images i = 0..num_images-1 are the images that HAVE ground truth; their detections (already
+ * filtered by score >= score_thresh and in score-descending stable order) are rows
+ * det_off[i]..det_off[i+1]-1; boxes are float32 [x1,y1,x2,y2] as produced by the reference's
+ * xywh_to_xyxy (:23-25); IoU in float32 with iou_matrix's operation order (:27-57, union clipped at
+ * 1e-6).  Class-agnostic: the best ground truth is the FIRST argmax over all ground truths of the
+ * image; true positive iff its IoU >= iou_thr and it is unmatched (:128-140).
+ *   cm_dev[(C+1)*(C+1)] int32, row = true class, column = predicted class, index C = background;
+ *   zeroed by the call.                                                                               */
+yl_status yl_eval_confusion(const float* det_xyxy_dev, const int32_t* det_cls_dev, const int32_t* det_off_dev,
+                            const float* gt_xyxy_dev, const int32_t* gt_cls_dev, const int32_t* gt_off_dev,
+                            int32_t num_images, int32_t num_gt, int32_t num_classes, float iou_thr,
+                            int32_t* cm_dev, uint8_t* gt_matched_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,6 +316,20 @@ def test_cli_infer_and_evaluate(tmp_path, golden_dir):
                         str(tmp_path / "imgs"), "--batch_size", "2"], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.splitlines()[0])["detections"] > 0
+    # dataset layout with YOLO labels: images/ + labels/ -> device P/R/F1 curves + confusion matrix stats
+    ds = tmp_path / "ds"
+    (ds / "images").mkdir(parents=True); (ds / "labels").mkdir()
+    for name in ("sq", "wide"):
+        Image.fromarray(z[f"img_{name}"][..., ::-1]).save(str(ds / "images" / f"{name}.png"))
+        (ds / "labels" / f"{name}.txt").write_text("0 0.5 0.5 0.4 0.4\n1 0.25 0.3 0.2 0.2\n")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "evaluate.py"), "--weights", ck, "--test_folder",
+                        str(ds), "--batch_size", "2"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.splitlines()[0])
+    assert 0.0 <= out["best_f1"] <= 1.0 and 0.0 <= out["best_conf"] <= 1.0
+    run = tmp_path / "runs" / "evaluate" / "2"
+    assert (run / "curves.json").exists()
+    assert "Total FP:" in (run / "confusion_matrices" / "confusion_matrix_stats.txt").read_text()
 
 
 def test_class_argmax_ties_match_torch_first_max():

@@ -198,3 +198,37 @@ def test_preproc_oracle_matches_reference_flow_on_identity_resize(golden_dir):
     # fixed-point bilinear sanity: constant images stay constant, identity resize is exact
     c = np.full((17, 29, 3), 200, np.uint8)
     assert (opre.resize_linear_u8(c, 64, 40) == 200).all()
+
+
+# --------------------------------------------------------------------------- evaluate-path consumers (f3)
+from oracle import evalcons as oeval   # noqa: E402
+
+
+def _eval_fix(golden_dir):
+    with open(os.path.join(golden_dir, "eval_consumers.json")) as f:
+        return json.load(f)
+
+
+from _evalcheck import assert_curves_equal   # noqa: E402
+
+
+@pytest.mark.parametrize("case", ["mixed", "ties", "crowded", "no_dets"])
+def test_eval_curves_oracle_matches_reference(golden_dir, case):
+    fx = _eval_fix(golden_dir)[case]
+    for tag, want in fx["curves"].items():
+        iou, steps = tag.split("_")
+        got = oeval.build_curves_from_coco(fx["images"], fx["anns"], fx["dets"], None, iou=float(iou),
+                                           steps=int(steps))
+        assert_curves_equal(got, want)
+
+
+@pytest.mark.parametrize("case", ["mixed", "ties", "crowded", "no_dets"])
+def test_eval_confusion_oracle_matches_reference(golden_dir, case):
+    fx = _eval_fix(golden_dir)[case]
+    for rec in fx["confusion"].values():
+        cm = oeval.confusion_matrix_counts(fx["anns"], fx["dets"], fx["num_classes"], rec["iou_thresh"],
+                                           rec["score_thresh"])
+        assert np.array_equal(cm, np.asarray(rec["cm"]))
+        st = oeval.confusion_stats(cm)
+        assert f"Total FP: {st['total_fp']}\n" in rec["stats_txt"]
+        assert f"Total FN: {st['total_fn']}\n" in rec["stats_txt"]

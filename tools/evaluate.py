@@ -46,13 +46,26 @@ def main():
     if not paths:
         raise ValueError(f"no images under {img_dir}")
     run_dir = next_run_dir(args.out)
-    coco_dets, fwd_ms, fwd_imgs = [], [], 0
+    lab_dir = root / "labels"
+    coco_dets, coco_anns, fwd_ms, fwd_imgs = [], [], [], 0
     for i in range(0, len(paths), args.batch_size):
         chunk = paths[i:i + args.batch_size]
         xs = []
-        for p in chunk:
+        for j, p in enumerate(chunk):
             im = imread_bgr(p)
-            xs.append(preprocess_bgr(im, S)[0])
+            xc, (padx, pady, scale, w0, h0) = preprocess_bgr(im, S)
+            xs.append(xc)
+            lab = lab_dir / (Path(p).stem + ".txt")
+            if lab.exists():
+                # YOLO rows "cls xc yc w h" (normalised, scripts/data/dataset.py:94-112) -> letterbox pixels ->
+                # the reference's "[cx,cy,w,h]" rows of _xyxy_to_xywh (helpers.py:58-83), category_id = cls+1
+                rows = np.loadtxt(str(lab), ndmin=2, dtype=np.float64)
+                for r in rows.reshape(-1, 5) if rows.size else []:
+                    x1 = (r[1] - r[3] / 2) * w0 * scale + padx; x2 = (r[1] + r[3] / 2) * w0 * scale + padx
+                    y1 = (r[2] - r[4] / 2) * h0 * scale + pady; y2 = (r[2] + r[4] / 2) * h0 * scale + pady
+                    bb = [float(np.float32(v)) for v in ((x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1)]
+                    coco_anns.append({"id": len(coco_anns) + 1, "image_id": i + j, "category_id": int(r[0]) + 1,
+                                      "bbox": bb, "area": float(max(0.0, bb[2] * bb[3])), "iscrowd": 0})
         x = torch.from_numpy(np.stack(xs)).to(device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -69,6 +82,17 @@ def main():
         json.dump(coco_dets, f)
     summary = {"images": len(paths), "detections": len(coco_dets), "img_size": S,
                "gpu_forward_ms_per_img": (sum(fwd_ms) / fwd_imgs) if fwd_imgs else None}
+    if coco_anns:
+        # evaluate.py:480-489: P/R/F1 curves, then the confusion matrix at the best-F1 confidence -- on the device
+        from yololite_amd import evalops
+        cur = evalops.build_curves_from_coco([], coco_anns, coco_dets, Path(run_dir) / "curves", iou=0.50, steps=201)
+        evalops.create_confusion_matrix(coco_anns, coco_dets, list(names), SAVE_PATH=str(run_dir),
+                                        score_thresh=cur["best_conf"], device=device)
+        summary.update({k: cur[k] for k in ("best_f1", "best_conf", "precision_at_best", "recall_at_best",
+                                            "precision_at_fixed_conf", "recall_at_fixed_conf", "f1_at_fixed_conf")
+                        if k in cur})
+        with open(Path(run_dir) / "curves.json", "w") as f:
+            json.dump({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in cur.items()}, f)
     with open(Path(run_dir) / "summary.json", "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary))

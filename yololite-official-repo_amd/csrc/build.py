@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build libyololite_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
-three translation units, one shared library with a plain C ABI (include/yololite_hip.h).
+six translation units, one shared library with a plain C ABI (include/yololite_hip.h).
 
     python yololite-official-repo_amd/csrc/build.py [--force]
 """
@@ -20,6 +20,8 @@ UNITS = [
     # reference-exact fp32 arithmetic in decode/NMS: no fused multiply-add contraction
     ("yl_post.hip", ["-ffp-contract=off"]),
     ("yl_pre.hip", ["-ffp-contract=off"]),
+    # evaluation consumers: python-float / numpy-float32 exact IoU arithmetic
+    ("yl_eval.hip", ["-ffp-contract=off"]),
 ]
 DEPS = ["yl_internal.h", "yl_dev.h", os.path.join("..", "..", "include", "yololite_hip.h")]
 
@@ -54,7 +56,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src, _ in UNITS]
     if force or jobs or _stale(OUT, objs):
