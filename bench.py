@@ -127,6 +127,57 @@ def bench_eval_consumers(args):
     print(json.dumps(out))
 
 
+def bench_tracker(args):
+    """--workload track: Kalman-SORT tracker bank, S = batch streams x 48 objects,
+    one yl_track_update launch per frame on detections resident on the device.  Separate JSON line."""
+    from yololite_amd.tracker import TrackerBank
+    S, n_obj, F, max_out = args.batch, 48, 60, 64
+    r = np.random.RandomState(3)
+    pos = r.uniform(40, 600, (S, n_obj, 2)); vel = r.uniform(-4, 4, (S, n_obj, 2)); wh = r.uniform(20, 60, (S, n_obj, 2))
+    cls = r.randint(0, 8, (S, n_obj)).astype(np.float32)
+    frames = []
+    for f in range(F):
+        c = pos + vel * f + r.normal(0, 0.6, (S, n_obj, 2))
+        d = np.zeros((S, max_out, 6), np.float32)
+        d[:, :n_obj, :4] = np.concatenate([c - wh / 2, c + wh / 2], -1)
+        d[:, :n_obj, 4] = r.uniform(0.4, 0.99, (S, n_obj)); d[:, :n_obj, 5] = cls
+        frames.append(d)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    fr_dev = [torch.from_numpy(d).to(dev) for d in frames]
+    cnt = torch.full((S,), n_obj, dtype=torch.int32, device=dev)
+    bank = TrackerBank(S, max_tracks=256, device=dev)
+
+    def run():
+        bank.reset(-1)
+        for d in fr_dev:
+            bank.update(d, cnt)
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / (args.steps * F)
+    out = {"metric": "tracker stream-frames/sec", "value": round(S / el, 1), "unit": "stream-frames/sec", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{S} streams x {n_obj} objects x {F} frames, detections resident in HBM, "
+                                  f"one launch per frame (ms_per_step = one frame of all streams)"}}
+    if not args.no_cpu_baseline:
+        from oracle import tracker as otrack              # checker code, used only as the timed baseline
+        ns = S
+        t0 = time.perf_counter()
+        for s in range(ns):
+            trk = otrack.SortOracle()
+            for d in frames:
+                trk.update(d[s, :n_obj, :4], d[s, :n_obj, 4], d[s, :n_obj, 5].astype(np.int32))
+        cel = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(ns * F / cel, 1), "unit": "stream-frames/sec", "cores": 1, "kind": "port",
+                               "sample": f"{ns} of the {S} streams x {F} frames, {cel:.1f} s wall, numpy as in the reference"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,7 +197,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="internal streams the batch is split over")
     ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
-    ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3)")
+    ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3) | track (tracker bank, f4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -154,10 +205,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback exists)"
     torch.cuda.set_device(local)
-    if args.workload == "eval":
+    if args.workload in ("eval", "track"):
         import yololite_amd  # noqa: F401
         if rank == 0:
-            bench_eval_consumers(args)
+            (bench_eval_consumers if args.workload == "eval" else bench_tracker)(args)
         return
     dev = torch.device("cuda", local)
     import torch.distributed as dist

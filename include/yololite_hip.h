@@ -256,6 +256,33 @@ yl_status yl_eval_confusion(const float* det_xyxy_dev, const int32_t* det_cls_de
                             int32_t num_images, int32_t num_gt, int32_t num_classes, float iou_thr,
                             int32_t* cm_dev, uint8_t* gt_matched_dev, void* stream);
 
+/* ---- Kalman-SORT tracker bank (reference tools/tracker.py:9-326) -------------
+ * The reference's KalmanSortTracker follows ONE stream on the host.  A yl_tracker holds `num_streams`
+ * independent trackers on the device (capacity `max_tracks` tracks each); yl_track_update advances all of
+ * them by one frame from the packed detections of yl_predict / yl_postprocess without a host round trip:
+ *   dets_dev   [S][max_out][6] = x1,y1,x2,y2,score,class      counts_dev [S] (clamped to max_out)
+ * Semantics per stream = KalmanSortTracker.update(boxes, scores, classes) (tools/tracker.py:211-326):
+ * predict, greedy IoU assignment (descending IoU, optional same-class mask, stop below iou_threshold),
+ * Kalman update, new tracks for unmatched detections (ids from 1, detection order), drop tracks unseen
+ * for more than max_age frames, report tracks updated this frame with hits >= min_hits, in list order.
+ * Constructor defaults of the reference: iou_threshold 0.3, max_age 15, min_hits 2, match_by_class 1.
+ * Outputs (device): out_id/out_cls [S][max_tracks] int32, out_box [S][max_tracks][4] xyxy,
+ * out_score [S][max_tracks], out_count [S].  fp32 like the reference; the 7x7 / 4x4 products are not
+ * summed in BLAS order, so boxes agree to rounding (tests: 1e-3 px), ids / classes / counts exactly.
+ * Equal IoUs are taken in flat-index order (numpy's argsort leaves ties unspecified).
+ * Tracks beyond max_tracks are not created; yl_track_stats reports how many were lost.                */
+typedef struct yl_tracker yl_tracker;
+yl_status yl_track_create(int32_t device, int32_t num_streams, int32_t max_tracks, float iou_threshold,
+                          int32_t max_age, int32_t min_hits, int32_t match_by_class, yl_tracker** out);
+void yl_track_destroy(yl_tracker* t);
+/* reset() of the reference (tools/tracker.py:191-193) for one stream, or all with stream_index = -1 */
+yl_status yl_track_reset(yl_tracker* t, int32_t stream_index, void* stream);
+yl_status yl_track_update(yl_tracker* t, const float* dets_dev, const int32_t* counts_dev, int32_t max_out,
+                          int32_t* out_id_dev, float* out_box_dev, int32_t* out_cls_dev, float* out_score_dev,
+                          int32_t* out_count_dev, void* stream);
+/* synchronises the device; host arrays [num_streams] (either may be NULL) */
+yl_status yl_track_stats(yl_tracker* t, int32_t* ntracks_host, int32_t* overflow_host);
+
 #ifdef __cplusplus
 }
 #endif

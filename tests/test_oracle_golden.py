@@ -232,3 +232,15 @@ def test_eval_confusion_oracle_matches_reference(golden_dir, case):
         st = oeval.confusion_stats(cm)
         assert f"Total FP: {st['total_fp']}\n" in rec["stats_txt"]
         assert f"Total FN: {st['total_fn']}\n" in rec["stats_txt"]
+
+
+# --------------------------------------------------------------------------- Kalman-SORT tracker (f4)
+from oracle import tracker as otrack   # noqa: E402
+from _evalcheck import check_tracker_sequence   # noqa: E402
+
+
+@pytest.mark.parametrize("case", ["default", "crowd", "anyclass", "gaps"])
+def test_tracker_oracle_matches_reference(golden_dir, case):
+    with open(os.path.join(golden_dir, "tracker.json")) as f:
+        rec = json.load(f)[case]
+    check_tracker_sequence(otrack.SortOracle, rec, box_tol=0.0)       # same numpy calls: bit-exact here

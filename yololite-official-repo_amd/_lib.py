@@ -71,6 +71,12 @@ SYMBOLS = [
     ("yl_eval_sweep", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp]),
     ("yl_eval_confusion", C.c_int32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                       _vp, _vp, _vp]),
+    ("yl_track_create", C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int32,
+                                    C.POINTER(_vp)]),
+    ("yl_track_destroy", None, [_vp]),
+    ("yl_track_reset", C.c_int32, [_vp, C.c_int32, _vp]),
+    ("yl_track_update", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("yl_track_stats", C.c_int32, [_vp, _ip, _ip]),
 ]
 
 _lib = None

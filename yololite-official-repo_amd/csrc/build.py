@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build libyololite_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
-six translation units, one shared library with a plain C ABI (include/yololite_hip.h).
+seven translation units, one shared library with a plain C ABI (include/yololite_hip.h).
 
     python yololite-official-repo_amd/csrc/build.py [--force]
 """
@@ -22,6 +22,8 @@ UNITS = [
     ("yl_pre.hip", ["-ffp-contract=off"]),
     # evaluation consumers: python-float / numpy-float32 exact IoU arithmetic
     ("yl_eval.hip", ["-ffp-contract=off"]),
+    # tracker: float32 scalar arithmetic of the reference's bbox conversions / IoU, op by op
+    ("yl_track.hip", ["-ffp-contract=off"]),
 ]
 DEPS = ["yl_internal.h", "yl_dev.h", os.path.join("..", "..", "include", "yololite_hip.h")]
 
@@ -56,7 +58,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=7) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src, _ in UNITS]
     if force or jobs or _stale(OUT, objs):
