@@ -254,6 +254,85 @@ __device__ __forceinline__ float4 yl_shfl4(const float4& v, int src) {
   return r;
 }
 
+#ifdef YL_NMS_STAMP
+// profiling aid (variant builds only, tools/build_variant.sh ... -DYL_NMS_STAMP): wall-clock ticks (100 MHz) at the
+// phase boundaries of block 0
+__device__ unsigned long long yl_nms_stamps[16];
+__device__ unsigned long long yl_nms_tstamps[128];
+__device__ int yl_nms_tcount;
+#define YL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) yl_nms_stamps[i] = wall_clock64(); } while (0)
+extern "C" int yl_debug_nms_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_nms_stamps), sizeof(unsigned long long) * 16);
+}
+extern "C" int yl_debug_nms_tstamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_nms_tstamps), sizeof(unsigned long long) * 128);
+}
+#define YL_TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 128 && yl_nms_tstamps[i] == 0) yl_nms_tstamps[i] = wall_clock64(); } while (0)
+#else
+#define YL_STAMP(i) do {} while (0)
+#define YL_TSTAMP(i) do {} while (0)
+#endif
+// Scalar pass of the in-tile resolution: candidate i (alive mask `am`, ascending = score order) is kept iff
+// none of its suppressors (per-lane mask M, bits < lane only) is kept.  Candidates nobody can suppress
+// (M == 0) are kept unconditionally, so only the "suspects" are walked -- usually a handful.
+__device__ __forceinline__ u64 yl_tile_scan(u64 am, u64 M) {
+  const u64 sus = __ballot(M != 0ull) & am;
+  u64 kept = am & ~sus;
+  const u32 mlo = (u32)M, mhi = (u32)(M >> 32);
+  for (u64 rem = sus; rem; rem &= rem - 1) {
+    const int i = __ffsll((long long)rem) - 1;
+    const u64 mi = ((u64)(u32)__builtin_amdgcn_readlane((int)mhi, i) << 32) |
+                   (u64)(u32)__builtin_amdgcn_readlane((int)mlo, i);
+    if ((mi & kept) == 0ull) kept |= 1ull << i;
+  }
+  return kept;
+}
+
+// Greedy resolution INSIDE one 64-candidate tile (lane = candidate in score order, `alive` = not yet
+// suppressed by boxes kept earlier).  Pass 1 (vector, no scalar round trips): for every alive candidate i,
+// broadcast its box through SGPRs and let every later lane j record "i would suppress me" in a 64-bit
+// per-lane mask M.  Pass 2 (scalar): walk the alive candidates in order; i is kept iff none of its
+// suppressors is kept: (M_i & kept) == 0.  Identical keep set to the serial "take first alive, strike the
+// rest" loop it replaces, whose every step paid a VALU->SALU->VALU round trip (~770 clk per kept box).
+// Pairs inside the 1e-5 band around the threshold are re-decided with the exact IEEE division.
+__device__ __forceinline__ bool yl_tile_resolve(const float4& bj, float aj, bool alive, float thr, int impl, int lane) {
+  const u64 am = __ballot(alive);
+  u64 M = 0ull, U = 0ull;
+  for (u64 rem = am; rem; rem &= rem - 1) {
+    const int i = __ffsll((long long)rem) - 1;
+    const u64 bit = 1ull << i;
+    const float4 bt = make_float4(yl_readlane_f(bj.x, i), yl_readlane_f(bj.y, i), yl_readlane_f(bj.z, i),
+                                  yl_readlane_f(bj.w, i));
+    const float at = yl_readlane_f(aj, i);
+    const float inter = yl_inter(bt, bj);
+    const float den = (impl == YL_NMS_TORCHVISION) ? (at + aj - inter) : (at + aj - inter + 1e-6f);
+    const float cmp = thr * den;
+    const bool sure_yes = den > 0.0f && inter > cmp * 1.00001f;
+    const bool sure_no = den > 0.0f && inter < cmp * 0.99999f && thr >= 0.0f;
+    const bool rel = lane > i;
+    if (rel && sure_yes) M |= bit;
+    if (rel && !(sure_yes || sure_no)) U |= bit;
+  }
+  if (__ballot(U != 0ull) != 0ull) {                          // rare: exact predicate for the undecided pairs
+    for (u64 rem = U; rem; rem &= rem - 1) {
+      const int i = __ffsll((long long)rem) - 1;
+      const float4 bt = yl_shfl4(bj, i);
+      const float at = __shfl(aj, i);
+      if (yl_suppress_exact(yl_inter(bt, bj), at, aj, thr, impl)) M |= 1ull << i;
+    }
+  }
+  const u64 kept = yl_tile_scan(am, M);
+  return ((kept >> lane) & 1ull) != 0ull;
+}
+
+// class segments above YL_NMS_BIG survivors are handled by the whole workgroup (yl_nms_segment_block)
+#ifndef YL_NMS_BIG
+#define YL_NMS_BIG 64
+#endif
+#define YL_NMS_BIGQ 200
+#define YL_NMS_SCRATCH 2304          // bytes of LDS behind the keys: ints [0..3] counters, [8..209] big-class queue,
+                                     // byte 1024..2063: 2 x 65 u64 OR scratch of the cooperative pass
+
 template <typename KeyPtr>
 __device__ __forceinline__ void yl_bitonic_sort(KeyPtr keys, int P, int tid, int nthreads) {
   for (int k = 2; k <= P; k <<= 1) {
@@ -286,29 +365,140 @@ __device__ __forceinline__ int yl_nms_segment(K32Ptr k32, int s, int e, const fl
     if (valid) bj = SBOX ? sbox[pos] : boxes[k32[2 * pos]];
     const float aj = (bj.z - bj.x) * (bj.w - bj.y);
     bool alive = valid;
-    for (int k = 0; k < nk; ++k) {                          // boxes kept by earlier chunks
-      const u32 q = k32[2 * (s + k) + 1];
-      const float4 bi = SBOX ? sbox[q] : boxes[k32[2 * q]];
-      const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-      if (yl_suppress(bi, ai, bj, aj, thr, impl, alive) && alive) alive = false;
+    // boxes kept by earlier chunks: fetched 64 at a time (lane k holds kept box k0+k: two LDS reads, all in
+    // flight together) and broadcast through SGPRs -- no dependent LDS read in the per-box loop
+    for (int k0 = 0; k0 < nk && __ballot(alive) != 0ull; k0 += 64) {
+      const int kk = (nk - k0) < 64 ? (nk - k0) : 64;
+      float4 kb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < kk) {
+        const u32 q = k32[2 * (s + k0 + lane) + 1];
+        kb = SBOX ? sbox[q] : boxes[k32[2 * q]];
+      }
+      const float ka = (kb.z - kb.x) * (kb.w - kb.y);
+      for (int k = 0; k < kk; ++k) {
+        const int ku = __builtin_amdgcn_readfirstlane(k);
+        const float4 bi = make_float4(yl_readlane_f(kb.x, ku), yl_readlane_f(kb.y, ku), yl_readlane_f(kb.z, ku),
+                                      yl_readlane_f(kb.w, ku));
+        const float ai = yl_readlane_f(ka, ku);
+        if (yl_suppress(bi, ai, bj, aj, thr, impl, alive) && alive) alive = false;
+      }
     }
-    u64 rem = __ballot(alive);
-    while (rem) {                                           // serial resolution inside the chunk
-      const int t = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
-      rem &= rem - 1;
-      // box t broadcast through SGPRs (v_readlane), not through the LDS crossbar
-      const float4 bt = make_float4(yl_readlane_f(bj.x, t), yl_readlane_f(bj.y, t), yl_readlane_f(bj.z, t),
-                                    yl_readlane_f(bj.w, t));
-      const float at = yl_readlane_f(aj, t);
-      const bool rel = alive && lane > t;
-      if (yl_suppress(bt, at, bj, aj, thr, impl, rel) && rel) alive = false;
-      rem &= __ballot(alive);
-    }
+    alive = yl_tile_resolve(bj, aj, alive, thr, impl, lane);
     const u64 mask = __ballot(alive);
     const int rank = __popcll(mask & ((1ull << lane) - 1ull));
     if (alive && nk + rank < cap) k32[2 * (s + nk + rank) + 1] = (u32)pos;
     nk += __popcll(mask);
   }
+  return nk < cap ? nk : cap;
+}
+
+// greedy NMS of ONE LARGE class segment [s,e) by the WHOLE workgroup.  Every pair test costs a wave ~400
+// clocks (a ~35-deep dependent VALU chain behind an SGPR broadcast; one wave per SIMD, nothing to overlap
+// with), and the per-wave routine above runs nk + 64 of them back to back for every 64-candidate chunk:
+// measured 130 of 160 us per image on the B=64 benchmark, spent by ONE wave on a 1178-survivor class while
+// 15 waves idled.  Here all waves work on the same chunk (lane = candidate) and split the SOURCE boxes:
+//   phase A  kept boxes k = wave, wave+nwaves, ...  -> "dead" ballots OR-ed in LDS        (nk/nwaves tests)
+//   phase B  in-chunk suppressor rows i = wave*(64/nwaves).. -> partial masks M_j OR-ed in LDS (4 tests)
+//   then every wave runs the same scalar scan (kept iff (M_i & kept) == 0) -- no result to publish.
+// Two barriers per chunk; the LDS scratch is double-buffered by chunk parity.  Same keep set and order
+// as yl_nms_segment.  s_or: 2 x (1 + 64) u64 of LDS, zero on entry and on exit.
+template <bool SBOX, typename K32Ptr>
+__device__ __forceinline__ int yl_nms_segment_block(K32Ptr k32, int s, int e, const float4* __restrict__ boxes,
+                                                    const float4* sbox, float thr, int impl, int cap, u64* s_or) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int rows = (64 + nwaves - 1) / nwaves;              // phase-B rows per wave
+  int nk = 0, par = 0;
+  for (int cs = s; cs < e && nk < cap; cs += 64, par ^= 1) {
+    const int ci = (cs - s) >> 6;
+    YL_TSTAMP(6 * ci);
+    u64* s_dead = s_or + par * 65;
+    u64* s_M = s_dead + 1;
+    const int pos = cs + lane;
+    const bool valid = pos < e;
+    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) bj = SBOX ? sbox[pos] : boxes[k32[2 * pos]];
+    const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+    // ---- phase A: my share of the kept boxes
+    bool alive = valid;
+    for (int k0 = wave; k0 < nk && __ballot(alive) != 0ull; k0 += 64 * nwaves) {
+      const int kidx = k0 + lane * nwaves;
+      float4 kb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kidx < nk) {
+        const u32 q = k32[2 * (s + kidx) + 1];
+        kb = SBOX ? sbox[q] : boxes[k32[2 * q]];
+      }
+      const float ka = (kb.z - kb.x) * (kb.w - kb.y);
+      const int kk = (nk - k0 + nwaves - 1) / nwaves;       // kept boxes in this batch (<= 64)
+      for (int k = 0; k < kk && k < 64; ++k) {
+        const int ku = __builtin_amdgcn_readfirstlane(k);
+        const float4 bi = make_float4(yl_readlane_f(kb.x, ku), yl_readlane_f(kb.y, ku), yl_readlane_f(kb.z, ku),
+                                      yl_readlane_f(kb.w, ku));
+        const float ai = yl_readlane_f(ka, ku);
+        if (yl_suppress(bi, ai, bj, aj, thr, impl, alive) && alive) alive = false;
+      }
+    }
+    {
+      const u64 dm = __ballot(valid && !alive);
+      if (lane == 0 && dm) atomicOr((unsigned long long*)s_dead, (unsigned long long)dm);
+    }
+    YL_TSTAMP(6 * ci + 1);
+    __syncthreads();
+    YL_TSTAMP(6 * ci + 2);
+    if (wave == 0) {                                        // zero the other parity's scratch for the next chunk
+      if (lane == 0) s_or[(par ^ 1) * 65] = 0ull;
+      s_or[(par ^ 1) * 65 + 1 + lane] = 0ull;
+    }
+    alive = valid && ((s_dead[0] >> lane) & 1ull) == 0ull;
+    const u64 am = __ballot(alive);
+    // ---- phase B: my rows of the in-chunk suppression matrix
+    {
+      u64 M = 0ull, U = 0ull;
+      for (int r = 0; r < rows; ++r) {
+        const int i = __builtin_amdgcn_readfirstlane(wave * rows + r);
+        if (i >= 64 || ((am >> i) & 1ull) == 0ull) continue;
+        const u64 bit = 1ull << i;
+        const float4 bt = make_float4(yl_readlane_f(bj.x, i), yl_readlane_f(bj.y, i), yl_readlane_f(bj.z, i),
+                                      yl_readlane_f(bj.w, i));
+        const float at = yl_readlane_f(aj, i);
+        const float inter = yl_inter(bt, bj);
+        const float den = (impl == YL_NMS_TORCHVISION) ? (at + aj - inter) : (at + aj - inter + 1e-6f);
+        const float cmp = thr * den;
+        const bool sure_yes = den > 0.0f && inter > cmp * 1.00001f;
+        const bool sure_no = den > 0.0f && inter < cmp * 0.99999f && thr >= 0.0f;
+        const bool rel = lane > i;
+        if (rel && sure_yes) M |= bit;
+        if (rel && !(sure_yes || sure_no)) U |= bit;
+      }
+      if (__ballot(U != 0ull) != 0ull) {
+        for (u64 rem = U; rem; rem &= rem - 1) {
+          const int i = __ffsll((long long)rem) - 1;
+          const float4 bt = yl_shfl4(bj, i);
+          const float at = __shfl(aj, i);
+          if (yl_suppress_exact(yl_inter(bt, bj), at, aj, thr, impl)) M |= 1ull << i;
+        }
+      }
+      if (M) atomicOr((unsigned long long*)&s_M[lane], (unsigned long long)M);
+    }
+    YL_TSTAMP(6 * ci + 3);
+    __syncthreads();
+    YL_TSTAMP(6 * ci + 4);
+    // ---- scan (every wave, identical result)
+    const u64 kept = yl_tile_scan(am, s_M[lane]);
+    {
+      // kept entry `slot` is re-read in phase A by wave slot % nwaves only: that wave writes it (program order
+      // within a wave, no barrier needed before the next chunk)
+      const int slot = nk + __popcll(kept & ((1ull << lane) - 1ull));
+      if (((kept >> lane) & 1ull) && slot < cap && (slot % nwaves) == wave) k32[2 * (s + slot) + 1] = (u32)pos;
+    }
+    nk += __popcll(kept);
+    YL_TSTAMP(6 * ci + 5);
+  }
+  __syncthreads();                                          // kept list complete; scratch of the last parity:
+  if (wave == 0) {
+    if (lane == 0) { s_or[0] = 0ull; s_or[65] = 0ull; }
+    s_or[1 + lane] = 0ull; s_or[66 + lane] = 0ull;
+  }
+  __syncthreads();
   return nk < cap ? nk : cap;
 }
 
@@ -343,6 +533,7 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   int* ws_off = ws_kept + C;
   u32* k32 = (u32*)keys;
 
+  YL_STAMP(1);
   if (tid == 0) s_misc[1] = 0;
   for (int c = tid; c < C; c += blockDim.x) { ws_start[c] = -1; ws_end[c] = 0; ws_kept[c] = 0; ws_off[c] = 0; }
   __syncthreads();
@@ -356,7 +547,9 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   }
   for (int i = nsurv + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
   __syncthreads();
+  YL_STAMP(2);
   yl_bitonic_sort(keys, P, tid, blockDim.x);
+  YL_STAMP(3);
 
   for (int pos = tid; pos < nsurv; pos += blockDim.x) {
     const int c = (int)(keys[pos] >> 52);
@@ -370,14 +563,41 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
     if (SBOX) sbox[pos] = boxes[idx];                      // all gathers in flight at once
   }
   __syncthreads();
+  YL_STAMP(4);
 
+  // small classes: one wave per class; large classes (> YL_NMS_BIG survivors) are queued for the cooperative pass
+  int* s_big = s_misc + 8;                                    // [0] count, [1..] class ids (YL_NMS_BIGQ entries)
+  if (tid == 0) s_big[0] = 0;
+  if (tid < 130) reinterpret_cast<u64*>(s_misc + 256)[tid] = 0ull;   // OR scratch of the cooperative pass
+  __syncthreads();
   for (int c = wave; c < C; c += nwaves) {
     const int s = ws_start[c];
     if (s < 0) continue;
-    const int nk = yl_nms_segment<SBOX>(k32, s, ws_end[c], boxes, sbox, p.iou_thr, p.impl, p.cap, lane);
+    const int e = ws_end[c];
+    if (e - s > YL_NMS_BIG && e - s <= 64 * 32 * nwaves) {
+      int slot = YL_NMS_BIGQ;
+      if (lane == 0) slot = atomicAdd(&s_big[0], 1);
+      slot = __builtin_amdgcn_readfirstlane(slot);
+      if (slot < YL_NMS_BIGQ) {
+        if (lane == 0) s_big[1 + slot] = c;
+        continue;
+      }
+    }
+    const int nk = yl_nms_segment<SBOX>(k32, s, e, boxes, sbox, p.iou_thr, p.impl, p.cap, lane);
     if (lane == 0) ws_kept[c] = nk;
   }
   __syncthreads();
+  {
+    const int nbig = s_big[0] < YL_NMS_BIGQ ? s_big[0] : YL_NMS_BIGQ;
+    for (int q = 0; q < nbig; ++q) {
+      const int c = s_big[1 + q];
+      const int nk = yl_nms_segment_block<SBOX>(k32, ws_start[c], ws_end[c], boxes, sbox, p.iou_thr, p.impl, p.cap,
+                                                reinterpret_cast<u64*>(s_misc + 256));
+      if (tid == 0) ws_kept[c] = nk;
+    }
+  }
+  __syncthreads();
+  YL_STAMP(5);
 
   // -- output offsets: exclusive scan of the kept counts over classes (wave 0)
   if (wave == 0) {
@@ -415,7 +635,11 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
     }
   }
   if (!do_topk) {
-    if (tid == 0) p.counts[b] = total;
+    YL_STAMP(6);
+    if (tid == 0) { p.counts[b] = total; }
+#ifdef YL_NMS_STAMP
+    if (blockIdx.x == 0 && tid == 0) { yl_nms_stamps[7] = (unsigned long long)nsurv; yl_nms_stamps[8] = (unsigned long long)total; }
+#endif
     return;
   }
   // -- fallback global top-k (tools/infer.py:377-379): sort kept rows by score desc, take topk
@@ -439,11 +663,12 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
 
 __global__ __launch_bounds__(1024) void yl_nms_kernel(YlNmsP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char yl_smem_raw[];
-  // dynamic LDS: [lds_cap] u64 keys, then 4 ints of scratch
+  // dynamic LDS: [lds_cap] u64 keys, then YL_NMS_SCRATCH bytes: 4 counters, the big-class queue, the OR scratch
   u64* lkeys = (u64*)yl_smem_raw;
   int* s_misc = (int*)(yl_smem_raw + (size_t)p.lds_cap * 8);
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* scores = p.scores + (size_t)b * p.N;
+  YL_STAMP(0);
   if (tid == 0) s_misc[0] = 0;
   __syncthreads();
   int local = 0;
@@ -516,7 +741,7 @@ static int g_nms_lds_max = 0;
 
 hipError_t yl_post_init() {
   // 128 KiB of keys + scratch: needs the opt-in above the default 64 KiB dynamic-LDS limit
-  const int want = YL_LDS_KEYS_MAX * 8 + 64;
+  const int want = YL_LDS_KEYS_MAX * 8 + YL_NMS_SCRATCH;
   hipError_t e = hipFuncSetAttribute((const void*)yl_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want);
   if (e != hipSuccess) return e;
   g_nms_lds_max = want;
@@ -545,7 +770,7 @@ hipError_t yl_launch_decode_only(const YlLevels& lv, int B, int center_mode, int
 }
 
 hipError_t yl_launch_nms(const YlNmsP& p, int B, hipStream_t st) {
-  const size_t lds = (size_t)p.lds_cap * 8 + 64;
+  const size_t lds = (size_t)p.lds_cap * 8 + YL_NMS_SCRATCH;
   if ((int)lds > g_nms_lds_max && lds > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(yl_nms_kernel, dim3(B), dim3(1024), lds, st, p);
   return hipGetLastError();
