@@ -139,6 +139,23 @@ void pack_stem(const float* w, int cout, int cin, int k, std::vector<float>& out
       }
 }
 
+// stem of the fused entry block (3 input channels, 3x3): K order by input rows, see yl_stemblock.hip
+void pack_stem_rows(const float* w, int cout, std::vector<float>& out) {
+  const int KS = 7, NT = cdiv(cout, 16);
+  out.assign((size_t)KS * NT * 64, 0.0f);
+  for (int s = 0; s < KS; ++s)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int n = nt * 16 + (lane & 15), kq = lane >> 4;
+        int row, kx;
+        if (s < 3) { row = 2 * kq; kx = s; }
+        else if (s < 6) { row = 2 * kq + 1; kx = s - 3; }
+        else if (kq < 3) { row = 8; kx = kq; }
+        else continue;                                               // pad slot: zero weight
+        if (n < cout) out[((size_t)s * NT + nt) * 64 + lane] = w[(size_t)n * 27 + row * 3 + kx];
+      }
+}
+
 void free_post_ws(yl_ctx* c) {
   hipFree(c->ws_boxes); hipFree(c->ws_scores); hipFree(c->ws_cls); hipFree(c->ws_clsws);
   hipFree(c->ws_gkeys); hipFree(c->ws_tmp_dets); hipFree(c->ws_tmp_idx);
@@ -572,7 +589,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     std::vector<float> wp, bias;
     yl_status s;
     if (l.op == YL_OP_STEM || l.op == YL_OP_STEMBLOCK) {
-      pack_stem(l.w, l.cout, l.cin, l.k, wp);
+      if (l.op == YL_OP_STEMBLOCK) pack_stem_rows(l.w, l.cout, wp);
+      else pack_stem(l.w, l.cout, l.cin, l.k, wp);
       bias.assign(l.cout, 0.0f);
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
       if (l.op == YL_OP_STEMBLOCK) {

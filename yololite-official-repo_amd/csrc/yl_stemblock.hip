@@ -19,12 +19,16 @@
 #include "yl_internal.h"
 #include "yl_dev.h"
 
+#ifndef SB_EXP
+#define SB_EXP 0                    // timing experiments (variant builds only): 1 no gathers, 2 no stem MFMAs,
+#endif                              // 3 no 3x3 MFMAs, 4 no stores -- results are WRONG when set
 #define SB_TR 2                     // wave tile: 2 rows x 8 columns of the second conv's output grid
 #define SB_TC 8
 #define SB_PR (2 * SB_TR + 1)       // stem patch: 5 rows x 17 columns
 #define SB_PC (2 * SB_TC + 1)
 #define SB_NPATCH (SB_PR * SB_PC)   // 85 stem pixels
 #define SB_MT1 ((SB_NPATCH + 15) / 16)   // 6 m-tiles
+struct __attribute__((packed, aligned(4))) SbF3 { float a, b, c; };   // 3 consecutive taps of one input row
 
 // Every WAVE owns its tiles end to end (private LDS patch, no workgroup barrier in the loop): waves
 // drift apart and cover each other's gather latency / MFMA dependency stalls.
@@ -56,16 +60,22 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   __syncthreads();
 
   const size_t plane = (size_t)p.H * p.W;
-  // per-lane constants: tap decode of the lane's k slots and patch-pixel coordinates of its m-tile rows
+  // per-lane constants: tap decode of the lane's k slots and patch-pixel coordinates of its m-tile rows.
+  // K order (shared with pack_stem_rows in yl_api.hip): the 27 taps are 9 rows (c,ky) of 3 consecutive kx.
+  // Lane group kq owns rows 2kq and 2kq+1 whole (slots 0-2, 3-5) and one element of row 8 (slot 6, kx = kq;
+  // group 3: the zero-weight pad slot), so a lane's 7 operands per patch pixel are two 12-byte loads and one
+  // 4-byte load instead of seven scattered dwords.
   int tky[KS], tkx[KS], tc[KS], gs[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    const int k = 4 * s + kq;
-    const int kc = k < 27 ? k : 26;                                  // k = 27 is the zero-weight pad slot
-    tc[s] = kc / 9;
-    const int r = kc - 9 * tc[s];
-    tky[s] = r / 3;
-    tkx[s] = r - 3 * tky[s];
+    int row, kx;
+    if (s < 3) { row = 2 * kq; kx = s; }
+    else if (s < 6) { row = 2 * kq + 1; kx = s - 3; }
+    else if (kq < 3) { row = 8; kx = kq; }
+    else { row = 7; kx = 2; }                                        // pad slot: any valid address, weight 0
+    tc[s] = row / 3;
+    tky[s] = row - 3 * tc[s];
+    tkx[s] = kx;
     gs[s] = tc[s] * (int)plane + tky[s] * p.W + tkx[s];
   }
   int ppi[SB_MT1], ppj[SB_MT1], gm[SB_MT1];
@@ -105,6 +115,13 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   // global-load latency hides behind tile t's 3x3 / 1x1 MFMAs.
   float xv[SB_MT1][KS];
   auto gather = [&](int tile) {
+    if (SB_EXP == 1) {
+#pragma unroll
+      for (int m = 0; m < SB_MT1; ++m)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xv[m][s] = (float)(tile + m + s);
+      return;
+    }
     const int b = tile / tiles_img;
     const int trem = tile - b * tiles_img;
     const int tyi = trem / tpr, txi = trem - tyi * tpr;
@@ -116,9 +133,14 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     if (interior) {                                   // the common case: no bounds logic (wave-uniform branch)
       const float* xo = xb + (size_t)iy0 * p.W + ix0;
 #pragma unroll
-      for (int m = 0; m < SB_MT1; ++m)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) xv[m][s] = xo[gm[m] + gs[s]];
+      for (int m = 0; m < SB_MT1; ++m) {
+        const float* q = xo + gm[m];
+        const SbF3 r0 = *reinterpret_cast<const SbF3*>(q + gs[0]);
+        const SbF3 r1 = *reinterpret_cast<const SbF3*>(q + gs[3]);
+        xv[m][0] = r0.a; xv[m][1] = r0.b; xv[m][2] = r0.c;
+        xv[m][3] = r1.a; xv[m][4] = r1.b; xv[m][5] = r1.c;
+        xv[m][6] = q[gs[6]];
+      }
     } else {
 #pragma unroll
       for (int m = 0; m < SB_MT1; ++m)
@@ -150,7 +172,8 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
       for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
-          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], xv[m][s], a1[nt], 0, 0, 0);
+          if (SB_EXP != 2) a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], xv[m][s], a1[nt], 0, 0, 0);
+          else a1[nt][0] += wa[s][nt] * xv[m][s];
       bool inside = true;
       if (!interior) {
         const int sy = sy0 + ppi[m], sx = sx0 + ppj[m];
@@ -190,6 +213,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
       for (int nt = 0; nt < NT2; ++nt) {
         const f32x4 w = wq[i & 1][nt], x = xq[i & 1];
+        if (SB_EXP == 3) { a2[nt][0] += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3]; continue; }
         a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], a2[nt], 0, 0, 0);
         a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], a2b[nt], 0, 0, 0);
         a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], a2[nt], 0, 0, 0);
@@ -224,7 +248,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
       for (int nt = 0; nt < NT3; ++nt) {
         const int n = nt * 16 + 4 * kq;
         const f32x4 v = clamp4(a3[nt] + yl_ld4(p.b3 + n), lo3, hi3);
-        if (valid && n < Nout) *reinterpret_cast<f32x4*>(orow + n) = v;
+        if (valid && n < Nout && (SB_EXP != 4 || v[0] == 1234.5f)) *reinterpret_cast<f32x4*>(orow + n) = v;
       }
     } else {
 #pragma unroll
