@@ -40,9 +40,7 @@ struct YlPix {
 // ReLU-family activations as a clamp with wave-uniform bounds; SiLU behind a uniform branch
 __device__ __forceinline__ f32x4 yl_actc(f32x4 v, int act, float lo, float hi) {
   if (act == YL_ACT_SILU) return yl_act4(v, YL_ACT_SILU);
-  v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
-  v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
-  return v;
+  return yl_clamp4(v, lo, hi);
 }
 
 __device__ __forceinline__ f32x4 yl_sel4(bool keep, f32x4 v) {
@@ -146,9 +144,10 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
 
 // ---- epilogues.  Lane holds channels n..n+3 (n = ntile*16 + 4*kq) of pixel px[mt].
 // ReLU-family activations are a branch-free clamp to [lo,hi] (lo=-inf/0, hi=6/+inf).
+// add_bias = false: the accumulators were initialised with the bias (no residual pre-add in the way)
 template <int NT, int MT>
 __device__ __forceinline__ void yl_epi_fast(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT], int nt0,
-                                            int kq, float lo, float hi) {
+                                            int kq, float lo, float hi, bool add_bias) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (!px[mt].valid) continue;
@@ -156,9 +155,9 @@ __device__ __forceinline__ void yl_epi_fast(const YlConvP& p, f32x4 (&acc)[MT][N
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = (nt0 + nt) * 16 + 4 * kq;
-      f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
-      v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
-      v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
+      f32x4 v = acc[mt][nt];
+      if (add_bias) v += yl_ld4(p.bias + n);
+      v = yl_clamp4(v, lo, hi);
       if (n < p.N) *reinterpret_cast<f32x4*>(orow + n) = v;
     }
   }
@@ -286,6 +285,9 @@ __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
   // residual / upsample-add without activation: the addends initialise the accumulators (loads issued
   // with the first activation fetch instead of after the last MFMA)
   const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE && !(p.N & 3);
+  // (initialising the accumulators with the bias saves 2 VALU ops per float4, but sums bias + conv instead of
+  //  the reference's conv + shift: on the ill-conditioned golden checkpoint one score moved by 1.2e-4 -> off)
+  const bool bias0 = false;
   if (DWM) {
     const int nw = p.dw_k * p.dw_k * p.Cin;
     for (int i = tid; i < nw; i += 256) dwl[i] = p.dw_w[i];
@@ -310,9 +312,12 @@ __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
     }
     f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+      // plain epilogue ahead: start from the bias (the epilogue is then clamp + store only)
+      const f32x4 b0 = bias0 ? yl_ld4(p.bias + (nt0 + nt) * 16 + 4 * kq) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = b0;
+    }
     if (pre_add) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
 
     if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi, stg, ((size_t)tile * 4 + wave) * (MT * 16), lane);
     else if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
-    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, !bias0);
   }
 }
 
@@ -461,6 +466,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
 
   // residual add without activation: the addend initialises the accumulators (loads issued at tile start)
   const bool pre_add = YL_DWH_PREADD && p.res != nullptr && p.up == nullptr && p.act == YL_ACT_NONE;
+  const bool bias0 = false;                                           // see yl_conv_mfma_kernel
   // The depthwise input is read through a raw buffer descriptor: 32-bit byte offsets, and an offset at or
   // beyond num_records (image border, channel tail) returns 0 from the hardware range check -- no bounds
   // selects, no 64-bit address arithmetic in the loop.  The launcher guarantees the tensor is < 2 GiB.
@@ -539,8 +545,8 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int n = (nt0 + nt) * 16 + 4 * kq;
+      acc[0][nt] = bias0 ? yl_ld4(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
       if (pre_add && n < p.N) acc[0][nt] = yl_ld4(p.res + px[0].lin * p.N + n);
     }
 #if !YL_DWH_XTILE
@@ -585,7 +591,8 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
           }
         }
       }
-      const f32x4 xq = yl_sel4(c < p.Cin, yl_actc(s, p.dw_act, dlo, dhi));
+      // channel tail (c >= Cin): the packed 1x1 weights of those k slots are zero, no select needed
+      const f32x4 xq = yl_actc(s, p.dw_act, dlo, dhi);
       const f32x4* wrow = wl + (size_t)kb * NT * 64 + lane;
       f32x4 wq[NT];
 #pragma unroll
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
       }
     }
     if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
-    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, !bias0);
   }
 }
 
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(256) void yl_uib_kernel(YlConvP p) {
       }
     }
     if (!pre_add && (p.res || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
-    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi);
+    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, true);
   }
 }
 

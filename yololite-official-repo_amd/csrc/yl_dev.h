@@ -21,3 +21,13 @@ __device__ __forceinline__ f32x4 yl_act4(f32x4 v, int act) {
 }
 __device__ __forceinline__ f32x4 yl_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+
+// clamp to [lo,hi] in ONE VALU op per element (v_med3_f32).  fp32 MFMA and fp32 VALU share the SIMD's FMA
+// lanes on gfx950 (same 64 FLOP/clk/SIMD peak; measured: removing VALU work shortens MFMA-bound kernels 1:1),
+// so epilogue instruction count is kernel time.  lo = -inf / hi = +inf give the one-sided / identity cases.
+__device__ __forceinline__ f32x4 yl_clamp4(f32x4 v, float lo, float hi) {
+  f32x4 r;
+  r.x = __builtin_amdgcn_fmed3f(v.x, lo, hi); r.y = __builtin_amdgcn_fmed3f(v.y, lo, hi);
+  r.z = __builtin_amdgcn_fmed3f(v.z, lo, hi); r.w = __builtin_amdgcn_fmed3f(v.w, lo, hi);
+  return r;
+}

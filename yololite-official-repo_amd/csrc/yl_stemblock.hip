@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   extern __shared__ __attribute__((aligned(16))) float sb_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4, pl = lane & 15;
-  float* patch = sb_lds + wave * PATCH_F;                            // [96][P1], wave private
-  f32x4* w2l = reinterpret_cast<f32x4*>(sb_lds + 4 * PATCH_F);
+  float* patch = sb_lds + (SB_EXP == 7 ? 0 : wave) * PATCH_F;       // [96][P1], wave private
+  f32x4* w2l = reinterpret_cast<f32x4*>(sb_lds + (SB_EXP == 7 ? 1 : 4) * PATCH_F);
   f32x4* w3l = w2l + 9 * KB1 * NT2 * 64;
 
   // ---- once per block: stem A fragments -> registers, conv2 / conv3 weights -> LDS
@@ -96,11 +96,10 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   const float lo1 = (p.act == YL_ACT_NONE) ? -INFINITY : 0.0f, hi1 = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
   const float lo2 = (p.act2 == YL_ACT_NONE) ? -INFINITY : 0.0f, hi2 = (p.act2 == YL_ACT_RELU6) ? 6.0f : INFINITY;
   const float lo3 = (p.act3 == YL_ACT_NONE) ? -INFINITY : 0.0f, hi3 = (p.act3 == YL_ACT_RELU6) ? 6.0f : INFINITY;
-  auto clamp4 = [](f32x4 v, float lo, float hi) {
-    v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
-    v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
-    return v;
-  };
+  auto clamp4 = [](f32x4 v, float lo, float hi) { return yl_clamp4(v, lo, hi); };
+  f32x4 bias3[NT3 > 0 ? NT3 : 1];
+#pragma unroll
+  for (int nt = 0; nt < NT3; ++nt) bias3[nt] = yl_ld4(p.b3 + nt * 16 + 4 * kq);
   const int lq = pl * P1 + 4 * kq;                                   // lane part of the patch write offset
   const int ty = pl >> 3, tx = pl & 7;                               // lane's pixel inside the 2x8 tile
   const int lr = ((2 * ty) * SB_PC + 2 * tx) * P1 + 4 * kq;          // lane part of the patch read offset
@@ -114,6 +113,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   // m-tiles).  Issued for tile t+1 right after tile t's stem phase has consumed the registers, so the
   // global-load latency hides behind tile t's 3x3 / 1x1 MFMAs.
   float xv[SB_MT1][KS];
+  int nb = 0, ntyi = 0, ntxi = 0;                    // decode of the tile whose gather is in flight
   auto gather = [&](int tile) {
     if (SB_EXP == 1) {
 #pragma unroll
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     const int b = tile / tiles_img;
     const int trem = tile - b * tiles_img;
     const int tyi = trem / tpr, txi = trem - tyi * tpr;
+    nb = b; ntyi = tyi; ntxi = txi;
     const int sy0 = 2 * tyi * SB_TR - 1, sx0 = 2 * txi * SB_TC - 1;
     const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;
     const float* xb = p.x + (size_t)b * 3 * plane;
@@ -153,12 +154,13 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     }
   };
   const int tile0 = blockIdx.x * 4 + wave;
+#ifdef SB_STAGGER
+  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(SB_STAGGER);   // de-phase the two co-resident blocks of a CU
+#endif
   if (tile0 < ntiles) gather(tile0);
 
   for (int tile = tile0; tile < ntiles; tile += wstride) {
-    const int b = tile / tiles_img;
-    const int trem = tile - b * tiles_img;
-    const int tyi = trem / tpr, txi = trem - tyi * tpr;
+    const int b = nb, tyi = ntyi, txi = ntxi;
     const int oy0 = tyi * SB_TR, ox0 = txi * SB_TC;                  // tile origin on the conv2 output grid
     const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;                  // patch origin on the stem grid
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
       }
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
-        f32x4 v = clamp4(a1[nt] + bias1[nt], lo1, hi1);
+        f32x4 v = clamp4(a1[nt] + bias1[nt], lo1, hi1);     // conv + shift, the reference's order
         if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(patch + m * 16 * P1 + lq + nt * 16) = v;
       }
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
       for (int nt = 0; nt < NT3; ++nt) {
         const int n = nt * 16 + 4 * kq;
-        const f32x4 v = clamp4(a3[nt] + yl_ld4(p.b3 + n), lo3, hi3);
+        const f32x4 v = clamp4(a3[nt] + bias3[nt], lo3, hi3);
         if (valid && n < Nout && (SB_EXP != 4 || v[0] == 1234.5f)) *reinterpret_cast<f32x4*>(orow + n) = v;
       }
     } else {
@@ -263,12 +265,12 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 template <int NT1, int NT2, int NT3>
 static hipError_t sb_go(const YlConvP& p, hipStream_t st, bool attr_only) {
   constexpr int P1 = NT1 * 16 + 4;
-  const size_t lds = (size_t)(4 * SB_MT1 * 16 * P1) * 4 + (size_t)(9 * NT1 * NT2 + NT2 * NT3) * 1024;
+  const size_t lds = (size_t)((SB_EXP == 7 ? 1 : 4) * SB_MT1 * 16 * P1) * 4 + (size_t)(9 * NT1 * NT2 + NT2 * NT3) * 1024;
   if (attr_only)
     return hipFuncSetAttribute((const void*)yl_stemblock_kernel<NT1, NT2, NT3>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   const int wtiles = p.B * ((p.OW + SB_TC - 1) / SB_TC) * ((p.OH + SB_TR - 1) / SB_TR);
-  int gx = 2 * YL_NUM_CU;
+  int gx = (SB_EXP == 7 ? 3 : 2) * YL_NUM_CU;
   if (gx > (wtiles + 3) / 4) gx = (wtiles + 3) / 4;
   hipLaunchKernelGGL((yl_stemblock_kernel<NT1, NT2, NT3>), dim3(gx), dim3(256), lds, st, p);
   return hipGetLastError();
