@@ -299,6 +299,20 @@ def main():
             roof = {"bound": "hbm", "achieved": round(byts / dur / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
         roof["traffic"] = None
+        # HBM-side bytes per launch from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate runs, tools/profile_round.sh): bench.py cannot run the profiler on itself
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)["kernels"]
+            kname = {3: "yl_stemblock_kernel"}.get(L.op)
+            hit = [v for k, v in pmc.items() if kname and kname in k]
+            if hit and B == 64 and args.model == "edge_n" and S == 640:
+                # FETCH_SIZE calibration: this kernel reads 4/12-byte lanes and its counter equals the input tensor
+                # bytes (315 MB) -- factor 1; the guide's x2 applies to 16-byte/lane streaming reads
+                roof["traffic"] = round((hit[0]["FETCH_SIZE_KB_mean"] + hit[0]["WRITE_SIZE_KB_mean"]) * 1024.0)
+                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE x1 + WRITE_SIZE, eager full-batch launches)"
+        except (OSError, KeyError, ValueError):
+            pass
         roof["kernel"] = f"layer {k} {L.name} (yl_conv_mfma_kernel, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})" \
             if L.op == 1 else f"layer {k} {L.name}"
         roof["avg_launch_ms"] = round(float(lay[k]), 4)

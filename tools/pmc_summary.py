@@ -1,6 +1,23 @@
 #!/usr/bin/env python3
 """Aggregate a rocprofv3 --pmc counter_collection CSV per kernel name (mean per dispatch)."""
-import csv, sys, collections
+import csv, sys, collections, json
+
+if len(sys.argv) > 1 and sys.argv[1] == "--json":
+    # --json FETCH.csv WRITE.csv : per-kernel mean KB per dispatch of both counters (profiles/rNN_pmc_traffic.json)
+    out = collections.defaultdict(dict)
+    for path in sys.argv[2:]:
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, d in acc.items():
+            for c, v in d.items():
+                out[k][c + "_KB_mean"] = sum(v) / len(v)
+                out[k]["dispatches"] = len(v)
+    print(json.dumps({"note": "rocprofv3 --pmc, separate passes, eager launches (--graph 0 --streams 1), B=64 edge_n 640x640; "
+                              "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 of their bytes (MI355X_MICROARCH.md HBM section)",
+                      "kernels": out}, indent=1))
+    sys.exit(0)
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
