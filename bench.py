@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="internal streams the batch is split over")
     ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
+    ap.add_argument("--bf16", type=int, default=0, help="1: bf16-MFMA compute mode (f4; NOT the headline: reduced precision)")
     ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3) | track (tracker bank, f4)")
     args = ap.parse_args()
 
@@ -231,6 +232,8 @@ def main():
     if args.tile_m:
         ctx.set_option("tile_m", args.tile_m)
     ctx.set_option("streams", args.streams)
+    if args.bf16:
+        ctx.set_option("mfma_bf16", 1)
     x = synth_images(B, S, seed=1234 + rank).to(dev)
     max_out = 300                                        # packed result rows per image
     dets = torch.empty((B, max_out, 6), device=dev, dtype=torch.float32)
@@ -325,7 +328,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
             "p50_ms_per_frame": round(float(np.median(step_ms)) / B, 5),
             "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 operands / f32 accumulate and storage (reduced-precision mode, not the headline)" if args.bf16 else "f32",
+            "data": "synthetic",
             "config": {"workload": f"{args.model} {'detector+instance-seg head' if args.seg else 'detector'} 640x640 C=80 batch={B}/GPU, forward+decode+per-class NMS{'+masks' if args.seg else ''} "
                                    f"(conf {args.conf}, iou {args.iou}), input resident in HBM"
                                    + (", + RCCL all-gather of packed dets" if world > 1 else ""),

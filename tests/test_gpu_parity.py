@@ -118,6 +118,38 @@ def test_forward_zoo_models(name, B, S, uib):
     _cmp_levels(outs, ref)
 
 
+@pytest.mark.parametrize("name,B,S", [("edge_n", 2, 320), ("yololite_m", 1, 256)])
+def test_bf16_mfma_mode(name, B, S):
+    """optional reduced-precision mode (operands rounded to bf16, fp32 accumulate, fp32
+    tensors).  Not the parity path: the bound is 3e-2 of the level's largest logit (bf16 has 8 mantissa
+    bits; ~60 layers) and the detections of the fp32 run are reproduced to within a few percent."""
+    meta = zoo_meta(name, 80, S)
+    sd = synth_state_dict(meta, seed=0, head_noise=2.0)
+    x = _x(B, S)
+    with torch.no_grad():
+        ref = _oracle_for(meta, sd)(x)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    f32 = [o.clone() for o in m(x.to(DEV))]
+    _cmp_levels(f32, ref)
+    ctx.set_option("mfma_bf16", 1)
+    b16 = m(x.to(DEV))
+    differs = False
+    for o, q, r in zip(b16, f32, ref):
+        err = (o.cpu() - r).abs().max().item()
+        assert err <= 3e-2 * r.abs().max().item() + 1e-3, (name, err, r.abs().max().item())
+        differs |= not torch.equal(o, q)
+    assert differs                                              # the mode really switched kernels
+    d16, c16 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
+    c16 = c16.cpu().numpy().copy()
+    ctx.set_option("mfma_bf16", 0)
+    d32, c32 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
+    c32 = c32.cpu().numpy()
+    assert np.all(np.abs(c16 - c32) <= 0.1 * np.maximum(c32, 10))
+    for o, q in zip(m(x.to(DEV)), f32):                         # and back: bitwise the fp32 path again
+        assert torch.equal(o, q)
+
+
 def test_forward_batch_invariance_and_determinism_full_size():
     """BASELINE config 2 (edge_n 640x640 B=64): bitwise repeatable, and image i of the batch equals the
     same image run alone (size-independent property; the oracle is too slow at this size)."""

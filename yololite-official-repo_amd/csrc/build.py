@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build libyololite_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
-seven translation units, one shared library with a plain C ABI (include/yololite_hip.h).
+seven translation units (two of them compiled twice: fp32 and bf16-MFMA builds), one shared library with a plain C ABI (include/yololite_hip.h).
 
     python yololite-official-repo_amd/csrc/build.py [--force]
 """
@@ -13,17 +13,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libyololite_hip.so")
 OBJ = os.path.join(HERE, "_obj")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
-UNITS = [
-    ("yl_api.hip", []),
-    ("yl_conv.hip", []),
-    ("yl_stemblock.hip", []),
+UNITS = [   # (source, extra flags, object name)
+    ("yl_api.hip", [], "yl_api.o"),
+    ("yl_conv.hip", [], "yl_conv.o"),
+    ("yl_stemblock.hip", [], "yl_stemblock.o"),
+    # bf16-MFMA inference mode: the same two units compiled again under distinct symbol names (yl_dev.h)
+    ("yl_conv.hip", ["-DYL_BF16=1"], "yl_conv_bf16.o"),
+    ("yl_stemblock.hip", ["-DYL_BF16=1"], "yl_stemblock_bf16.o"),
     # reference-exact fp32 arithmetic in decode/NMS: no fused multiply-add contraction
-    ("yl_post.hip", ["-ffp-contract=off"]),
-    ("yl_pre.hip", ["-ffp-contract=off"]),
+    ("yl_post.hip", ["-ffp-contract=off"], "yl_post.o"),
+    ("yl_pre.hip", ["-ffp-contract=off"], "yl_pre.o"),
     # evaluation consumers: python-float / numpy-float32 exact IoU arithmetic
-    ("yl_eval.hip", ["-ffp-contract=off"]),
+    ("yl_eval.hip", ["-ffp-contract=off"], "yl_eval.o"),
     # tracker: float32 scalar arithmetic of the reference's bbox conversions / IoU, op by op
-    ("yl_track.hip", ["-ffp-contract=off"]),
+    ("yl_track.hip", ["-ffp-contract=off"], "yl_track.o"),
 ]
 DEPS = ["yl_internal.h", "yl_dev.h", os.path.join("..", "..", "include", "yololite_hip.h")]
 
@@ -47,9 +50,9 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     deps = [os.path.join(HERE, d) for d in DEPS] + [os.path.abspath(__file__)]
     jobs = []
-    for src, extra in UNITS:
+    for src, extra, oname in UNITS:
         s = os.path.join(HERE, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, oname)
         if force or _stale(o, [s] + deps):
             jobs.append([hipcc] + COMMON + extra + ["-c", s, "-o", o])
 
@@ -58,9 +61,9 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=7) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src, _ in UNITS]
+    objs = [os.path.join(OBJ, oname) for _, _, oname in UNITS]
     if force or jobs or _stale(OUT, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     return OUT

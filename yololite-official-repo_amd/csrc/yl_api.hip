@@ -60,6 +60,7 @@ struct yl_ctx {
   int nms_gP = 0;
   // options
   int opt_graph = 0, opt_tile_m = 0, opt_streams = 2;
+  int opt_bf16 = 0;   // 1: conv / stem-block launches use the bf16-MFMA builds (fp32 storage, fp32 accumulate)
   // batch chunks run on `opt_streams` internal streams (fork/join around every call): the
   // latency-bound low-resolution layers of one chunk overlap the bandwidth-bound layers of another
   hipStream_t work[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -277,8 +278,8 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
     hipError_t e;
     switch (c->layers[i].d.op) {
       case YL_OP_STEM: e = yl_launch_stem(p, st); break;
-      case YL_OP_CONV: e = yl_launch_conv(p, c->opt_tile_m, st); break;
-      case YL_OP_STEMBLOCK: e = yl_launch_stemblock(p, st); break;
+      case YL_OP_CONV: e = c->opt_bf16 ? yl_launch_conv_bf16(p, c->opt_tile_m, st) : yl_launch_conv(p, c->opt_tile_m, st); break;
+      case YL_OP_STEMBLOCK: e = c->opt_bf16 ? yl_launch_stemblock_bf16(p, st) : yl_launch_stemblock(p, st); break;
       default: e = yl_launch_dw(p, st); break;
     }
     if (e != hipSuccess) {
@@ -460,7 +461,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return YL_ERR_HIP;
   if (hipSetDevice(device_id) != hipSuccess) return YL_ERR_HIP;
   if (!g_inited) {
-    if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess || yl_stemblock_init() != hipSuccess)
+    if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess || yl_stemblock_init() != hipSuccess ||
+        yl_conv_init_bf16() != hipSuccess || yl_stemblock_init_bf16() != hipSuccess)
       return YL_ERR_HIP;
     g_inited = true;
   }
@@ -650,6 +652,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
 yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }
   return fail(c, YL_ERR_INVALID, std::string("unknown option ") + name);

@@ -20,6 +20,21 @@
 // Replaces nn.Conv2d/BatchNorm2d(eval, folded)/ReLU/ReLU6/SiLU, F.interpolate(nearest)+add and the
 // head's view/cat/permute of the reference (scripts/model/model_v2.py:15-53,179-192,337-350) and of
 // the timm backbones it wraps (model_v2.py:94-100,266-272).
+// Second compilation with -DYL_BF16=1 (csrc/build.py) produces the bf16-MFMA variant of this translation unit
+// under distinct symbol names; yl_api.hip picks one per context (yl_set_option "mfma_bf16").
+#if defined(YL_BF16) && YL_BF16
+#define yl_conv_mfma_kernel yl_conv_mfma_kernel_bf16
+#define yl_conv_dwh_kernel yl_conv_dwh_kernel_bf16
+#define yl_uib_kernel yl_uib_kernel_bf16
+#define yl_stem_mfma_kernel yl_stem_mfma_kernel_bf16
+#define yl_dw_kernel yl_dw_kernel_bf16
+#define yl_launch_conv yl_launch_conv_bf16
+#define yl_launch_stem yl_launch_stem_bf16
+#define yl_launch_dw yl_launch_dw_bf16
+#define yl_conv_init yl_conv_init_bf16
+#define yl_uib_supported yl_uib_supported_bf16
+#define yl_uib_lds_bytes yl_uib_lds_bytes_bf16
+#endif
 #include "yl_internal.h"
 #include <math.h>
 
@@ -249,6 +264,9 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
 // grid.x: persistent over M tiles (4 waves x MT x 16 pixels each), grid.y: chunks of NT n-tiles.
 // LDS: weight chunk [CH][NT][64] float4 (n-tiles beyond the layer's last one are zero-filled so the
 // hot loop needs no tile predicate).
+#ifndef YL_PW_SCHED
+#define YL_PW_SCHED 24         // pin loads-before-MFMAs (A/B: 0 -> 29.33k, 12 -> 29.69k, 24 -> 29.75k img/s) in the 1x1/kxk loop (value = VALU ops in the address group)
+#endif
 template <int NT, int MT, int MODE>
 __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
   extern __shared__ __attribute__((aligned(16))) float yl_wlds[];
@@ -376,17 +394,19 @@ __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
         f32x4 wq[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[nt][s], xq[mt][s], acc[mt][nt], 0, 0, 0);
+        yl_mma_step<NT, MT>(wq, xq, acc);
         kb = kb2; ky = ky2; kx = kx2;
         if (!DWM) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) xq[mt] = xn[mt];
+#if YL_PW_SCHED
+          // pin the order: next step's address math + loads FIRST, then the weight reads, then the MFMAs (left
+          // alone the scheduler sinks the loads behind most of the MFMAs and waits for them at the end of the step)
+          __builtin_amdgcn_sched_group_barrier(0x002, YL_PW_SCHED, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, MT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, YL_MFMA_PER_BLOCK * NT * MT, 0);
+#endif
         }
       }
     }
@@ -592,16 +612,13 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
         }
       }
       // channel tail (c >= Cin): the packed 1x1 weights of those k slots are zero, no select needed
-      const f32x4 xq = yl_actc(s, p.dw_act, dlo, dhi);
+      f32x4 xq[1];
+      xq[0] = yl_actc(s, p.dw_act, dlo, dhi);
       const f32x4* wrow = wl + (size_t)kb * NT * 64 + lane;
       f32x4 wq[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
-#pragma unroll
-      for (int ss = 0; ss < 4; ++ss)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[nt][ss], xq[ss], acc[0][nt], 0, 0, 0);
+      yl_mma_step<NT, 1>(wq, xq, acc);
       if (more) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // this step's tap reads are complete
         stage_store(stg);

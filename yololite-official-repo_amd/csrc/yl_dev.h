@@ -31,3 +31,53 @@ __device__ __forceinline__ f32x4 yl_clamp4(f32x4 v, float lo, float hi) {
   r.z = __builtin_amdgcn_fmed3f(v.z, lo, hi); r.w = __builtin_amdgcn_fmed3f(v.w, lo, hi);
   return r;
 }
+
+// ---- MFMA step: one 16-channel k-block, NT n-tiles x MT m-tiles.  Lane (kq = lane >> 4, i = lane & 15) holds
+// four consecutive channels 4kq..4kq+3 of its row in both operands (the transposed-GEMM layout of yl_conv.hip).
+//   fp32 build:  4 x v_mfma_f32_16x16x4_f32 per (nt, mt)  -- exact fp32 (the parity path)
+//   YL_BF16 build (second compilation of the conv translation units, SURVEY 8(f) f4 "bf16 MFMA inference
+//   mode"): operands rounded to bf16 in registers (v_cvt_pk_bf16_f32, RNE), ONE v_mfma_f32_16x16x16_bf16 per
+//   (nt, mt), fp32 accumulate; activations and weights stay fp32 in HBM / LDS, so layouts, loads and epilogues
+//   are shared with the fp32 build.  Selected per context with yl_set_option("mfma_bf16", 1).
+#ifndef YL_BF16
+#define YL_BF16 0
+#endif
+typedef short yl_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ yl_s16x4 yl_pk_bf16(f32x4 v) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  u32x2_ r;
+  r.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v.x, v.y}, bf16x2_));
+  r.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v.z, v.w}, bf16x2_));
+  return __builtin_bit_cast(yl_s16x4, r);
+}
+#if YL_BF16
+#define YL_MFMA_PER_BLOCK 1
+#define yl_mma_step yl_mma_step_bf16
+#else
+#define YL_MFMA_PER_BLOCK 4
+#endif
+template <int NT, int MT>
+__device__ __forceinline__ void yl_mma_step(const f32x4 (&wq)[NT], const f32x4 (&xq)[MT], f32x4 (&acc)[MT][NT]) {
+#if YL_BF16
+  yl_s16x4 xb[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xb[mt] = yl_pk_bf16(xq[mt]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const yl_s16x4 wb = yl_pk_bf16(wq[nt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb, xb[mt], acc[mt][nt], 0, 0, 0);
+  }
+#else
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[nt][s], xq[mt][s], acc[mt][nt], 0, 0, 0);
+#endif
+}

@@ -103,3 +103,8 @@ hipError_t yl_stemblock_init();
 bool yl_stemblock_supported(int c1, int c2, int c3);
 hipError_t yl_conv_init();
 bool yl_uib_supported(int c1, int cmid, int n, int dk);
+// bf16-MFMA builds of yl_conv.hip / yl_stemblock.hip (compiled a second time with -DYL_BF16=1, see yl_dev.h)
+hipError_t yl_launch_conv_bf16(const YlConvP& p, int tile_hint, hipStream_t st);
+hipError_t yl_conv_init_bf16();
+hipError_t yl_launch_stemblock_bf16(const YlConvP& p, hipStream_t st);
+hipError_t yl_stemblock_init_bf16();

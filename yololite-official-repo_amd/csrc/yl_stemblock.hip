@@ -16,6 +16,13 @@
 //
 // Replaces timm conv_stem+bn1 and blocks.0.{0,1} (ConvBnAct) of mobilenetv4_conv_small*, i.e. the
 // first three conv/BN/ReLU triples behind model_v2.py:94-100,266-272.
+// bf16-MFMA variant: second compilation with -DYL_BF16=1 under distinct symbol names (see yl_dev.h: yl_mma_step)
+#if defined(YL_BF16) && YL_BF16
+#define yl_stemblock_kernel yl_stemblock_kernel_bf16
+#define yl_launch_stemblock yl_launch_stemblock_bf16
+#define yl_stemblock_init yl_stemblock_init_bf16
+#define yl_stemblock_supported yl_stemblock_supported_bf16
+#endif
 #include "yl_internal.h"
 #include "yl_dev.h"
 
@@ -49,6 +56,14 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   for (int s = 0; s < KS; ++s)
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) wa[s][nt] = p.wp[(s * NT1 + nt) * 64 + lane];
+#if YL_BF16
+  yl_s16x4 wab[2][NT1];
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) {
+    wab[0][nt] = yl_pk_bf16((f32x4){wa[0][nt], wa[1][nt], wa[2][nt], wa[3][nt]});
+    wab[1][nt] = yl_pk_bf16((f32x4){wa[4][nt], wa[5][nt], wa[6][nt], 0.0f});
+  }
+#endif
   {
     const f32x4* g2 = reinterpret_cast<const f32x4*>(p.w2p);
     for (int i = tid; i < 9 * KB1 * NT2 * 64; i += 256) w2l[i] = g2[i];
@@ -170,12 +185,24 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
       f32x4 a1[NT1];
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) a1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if YL_BF16
+      {   // the lane's 7 k slots as two 4-wide bf16 operands (slot 7 = zero); same slot <-> lane pairing in A and B
+        const yl_s16x4 x0 = yl_pk_bf16((f32x4){xv[m][0], xv[m][1], xv[m][2], xv[m][3]});
+        const yl_s16x4 x1 = yl_pk_bf16((f32x4){xv[m][4], xv[m][5], xv[m][6], 0.0f});
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wab[0][nt], x0, a1[nt], 0, 0, 0);
+          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wab[1][nt], x1, a1[nt], 0, 0, 0);
+        }
+      }
+#else
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
           if (SB_EXP != 2) a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], xv[m][s], a1[nt], 0, 0, 0);
           else a1[nt][0] += wa[s][nt] * xv[m][s];
+#endif
       bool inside = true;
       if (!interior) {
         const int sy = sy0 + ppi[m], sx = sx0 + ppj[m];
@@ -216,13 +243,20 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
       for (int nt = 0; nt < NT2; ++nt) {
         const f32x4 w = wq[i & 1][nt], x = xq[i & 1];
         if (SB_EXP == 3) { a2[nt][0] += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3]; continue; }
+#if YL_BF16
+        if (i & 1) a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2b[nt], 0, 0, 0);
+        else a2[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2[nt], 0, 0, 0);
+#else
         a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], a2[nt], 0, 0, 0);
         a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], a2b[nt], 0, 0, 0);
         a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], a2[nt], 0, 0, 0);
         a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[3], a2b[nt], 0, 0, 0);
+#endif
       }
+#if !YL_BF16
       __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT2, 0);       // DS reads of step i+1
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT2, 0);       // MFMAs of step i
+#endif
     }
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) a2[nt] = clamp4((a2[nt] + a2b[nt]) + bias2[nt], lo2, hi2);
@@ -242,9 +276,13 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
         for (int nt = 0; nt < NT3; ++nt) {
           const f32x4 wq = w3l[(kb * NT3 + nt) * 64 + lane];
+#if YL_BF16
+          a3[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(wq), yl_pk_bf16(a2[kb]), a3[nt], 0, 0, 0);
+#else
 #pragma unroll
           for (int s = 0; s < 4; ++s)
             a3[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s], a2[kb][s], a3[nt], 0, 0, 0);
+#endif
         }
 #pragma unroll
       for (int nt = 0; nt < NT3; ++nt) {
