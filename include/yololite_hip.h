@@ -163,7 +163,8 @@ yl_status yl_forward_timed(yl_ctx* ctx, const float* x_dev, int32_t batch, float
 /* Copies activation slot `slot` (NHWC fp32, [B,h,w,c]) of the last forward to dst_dev (testing aid). */
 yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev, void* stream);
 /* Options: "graph" (0/1: replay the whole call from a captured hipGraph), "streams" (1..4 internal
- * streams the batch is split over; default 2), "tile_m" (conv M-tile hint),
+ * streams the batch is split over; default 2), "tile_m" (conv M-tile hint), "lanes" (0/1, default 0: neck/head
+ * layers of the coarser levels run on a side stream next to the finest level's chain),
  * "mfma_bf16" (0/1, default 0: SURVEY 8(f) f4 reduced-precision inference mode -- conv operands are rounded
  * to bf16 in registers and multiplied on v_mfma_f32_16x16x16_bf16 with fp32 accumulation; tensors stay
  * fp32 in memory.  The reference's counterpart is fp16 autocast in evaluate_model

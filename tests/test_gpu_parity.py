@@ -150,6 +150,29 @@ def test_bf16_mfma_mode(name, B, S):
         assert torch.equal(o, q)
 
 
+def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
+    """side-stream lane for the coarse-level neck/head layers + one hipGraph per batch chunk: same bits as the
+    single-stream eager path (scheduling must not change results)."""
+    meta = zoo_meta("edge_n", 80, 320)
+    sd = synth_state_dict(meta, seed=0, head_noise=2.0)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(320)
+    x = _x(16, 320).to(DEV)
+    ctx.set_option("graph", 0); ctx.set_option("streams", 1); ctx.set_option("lanes", 0)
+    d0, c0 = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
+    d0, c0 = d0.clone(), c0.clone()
+    for graph in (0, 1):
+        for streams in (1, 2, 3):
+            for lanes in (0, 1):
+                ctx.set_option("graph", graph); ctx.set_option("streams", streams); ctx.set_option("lanes", lanes)
+                for _ in range(2):
+                    d, c = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
+                    assert torch.equal(c, c0), (graph, streams, lanes)
+                    for b in range(16):
+                        k = int(c0[b])
+                        assert torch.equal(d[b, :k], d0[b, :k]), (graph, streams, lanes, b)
+
+
 def test_forward_batch_invariance_and_determinism_full_size():
     """BASELINE config 2 (edge_n 640x640 B=64): bitwise repeatable, and image i of the batch equals the
     same image run alone (size-independent property; the oracle is too slow at this size)."""

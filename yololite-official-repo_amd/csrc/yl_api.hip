@@ -65,8 +65,19 @@ struct yl_ctx {
   // latency-bound low-resolution layers of one chunk overlap the bandwidth-bound layers of another
   hipStream_t work[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  // branch lanes inside a chunk: neck/head layers that only feed the heads of the coarser levels (smooth5,
+  // head5, smooth4, head4, ...) run on a side stream next to the 80x80 chain (lateral3 -> smooth3 -> head3);
+  // lane[i] is derived from the slot graph at yl_create.  Off by default ("lanes" option): measured no gain
+  // (29.3 k img/s either way) -- the conv grids are occupancy-sized persistent grids, so a second kernel only
+  // gets CUs at the tail of the first
+  int opt_lanes = 0;
+  std::vector<unsigned char> lane;
+  hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_la[4] = {nullptr, nullptr, nullptr, nullptr}, ev_lb[4] = {nullptr, nullptr, nullptr, nullptr};
   // single-entry hipGraph cache keyed on everything baked into the captured launches
-  hipGraphExec_t graph_exec = nullptr;
+  hipGraphExec_t graph_exec = nullptr;          // chunk 0 (or the whole job when it is not split)
+  hipGraphExec_t graph_chunk[4] = {nullptr, nullptr, nullptr, nullptr};   // chunks 1.. : one graph per chunk
+  int graph_n = 0;
   std::vector<unsigned char> graph_key;
   std::string err;
 };
@@ -168,6 +179,11 @@ void free_post_ws(yl_ctx* c) {
 void drop_graph(yl_ctx* c) {
   if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
   c->graph_exec = nullptr;
+  for (int i = 0; i < 4; ++i) {
+    if (c->graph_chunk[i]) hipGraphExecDestroy(c->graph_chunk[i]);
+    c->graph_chunk[i] = nullptr;
+  }
+  c->graph_n = 0;
   c->graph_key.clear();
 }
 
@@ -270,17 +286,47 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
 }
 
 yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* level_out, hipStream_t st,
-                     hipEvent_t* evs /*nullable: num_layers+1 events*/) {
+                     hipEvent_t* evs /*nullable: num_layers+1 events*/, int chunk = 0) {
   if (evs) HIPCHK(c, hipEventRecord(evs[0], st));
+  // two lanes (see yl_ctx::lane): lane-1 layers go to the chunk's side stream; an event edge is inserted
+  // wherever a layer reads a slot produced on the other lane, and the side stream is joined at the end.
+  // Per-layer timing (evs) keeps everything on one stream.
+  const bool lanes = !evs && c->opt_lanes && !c->lane.empty() && chunk >= 0 && chunk < 4;
+  hipStream_t sd = nullptr;
+  if (lanes) {
+    if (!c->side[chunk]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[chunk], hipStreamNonBlocking));
+    if (!c->ev_la[chunk]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_la[chunk], hipEventDisableTiming));
+    if (!c->ev_lb[chunk]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lb[chunk], hipEventDisableTiming));
+    sd = c->side[chunk];
+  }
+  std::vector<unsigned char> prod(c->slots.size(), 0);     // lane that produced each slot
+  bool side_used = false;
   for (size_t i = 0; i < c->layers.size(); ++i) {
     YlConvP p;
     layer_params(c, c->layers[i], b0, B, x, level_out, p);
+    const yl_layer& d = c->layers[i].d;
+    const int ln = (lanes && c->lane[i]) ? 1 : 0;
+    hipStream_t ls = ln ? sd : st;
+    if (lanes) {
+      bool cross = false;
+      const int ins[3] = {d.in_slot, d.res_slot, d.up_slot};
+      for (int k = 0; k < 3; ++k)
+        if (ins[k] >= 0 && d.op != YL_OP_STEM && d.op != YL_OP_STEMBLOCK && prod[ins[k]] != ln) cross = true;
+      if (ln == 1 && !side_used) cross = true;             // first side launch: order after everything enqueued so far
+      if (cross) {
+        hipEvent_t ev = ln ? c->ev_la[chunk] : c->ev_lb[chunk];
+        HIPCHK(c, hipEventRecord(ev, ln ? st : sd));
+        HIPCHK(c, hipStreamWaitEvent(ls, ev, 0));
+      }
+      if (ln) side_used = true;
+      if (d.head_level < 0 && d.out_slot >= 0) prod[d.out_slot] = (unsigned char)ln;
+    }
     hipError_t e;
-    switch (c->layers[i].d.op) {
-      case YL_OP_STEM: e = yl_launch_stem(p, st); break;
-      case YL_OP_CONV: e = c->opt_bf16 ? yl_launch_conv_bf16(p, c->opt_tile_m, st) : yl_launch_conv(p, c->opt_tile_m, st); break;
-      case YL_OP_STEMBLOCK: e = c->opt_bf16 ? yl_launch_stemblock_bf16(p, st) : yl_launch_stemblock(p, st); break;
-      default: e = yl_launch_dw(p, st); break;
+    switch (d.op) {
+      case YL_OP_STEM: e = yl_launch_stem(p, ls); break;
+      case YL_OP_CONV: e = c->opt_bf16 ? yl_launch_conv_bf16(p, c->opt_tile_m, ls) : yl_launch_conv(p, c->opt_tile_m, ls); break;
+      case YL_OP_STEMBLOCK: e = c->opt_bf16 ? yl_launch_stemblock_bf16(p, ls) : yl_launch_stemblock(p, ls); break;
+      default: e = yl_launch_dw(p, ls); break;
     }
     if (e != hipSuccess) {
       char b[256];
@@ -289,7 +335,38 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
     }
     if (evs) HIPCHK(c, hipEventRecord(evs[i + 1], st));
   }
+  if (side_used) {                                          // join: decode / the caller see both lanes
+    HIPCHK(c, hipEventRecord(c->ev_lb[chunk], sd));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_lb[chunk], 0));
+  }
   return YL_OK;
+}
+
+// lane assignment from the slot graph: a layer goes to lane 1 iff everything it feeds ends in head outputs of
+// levels >= 1 only (the finest level's chain, the backbone, the top-down laterals and the prototype branch stay
+// on lane 0)
+void assign_lanes(yl_ctx* c) {
+  const size_t n = c->layers.size();
+  c->lane.assign(n, 0);
+  std::vector<unsigned> reach(n, 0u);
+  for (size_t ii = n; ii-- > 0;) {
+    const yl_layer& d = c->layers[ii].d;
+    unsigned r = 0;
+    if (d.head_level >= 0) r |= 1u << (d.head_level > 30 ? 30 : d.head_level);
+    if (d.out_slot >= 0 && d.out_slot == c->proto_slot) r |= 1u << 31;
+    if (d.head_level < 0 && d.out_slot >= 0)
+      for (size_t j = ii + 1; j < n; ++j) {
+        const yl_layer& e = c->layers[j].d;
+        if (e.in_slot == d.out_slot || e.res_slot == d.out_slot || e.up_slot == d.out_slot) r |= reach[j];
+      }
+    reach[ii] = r;
+  }
+  bool any = false;
+  for (size_t i = 0; i < n; ++i) {
+    c->lane[i] = (reach[i] != 0 && (reach[i] & 1u) == 0 && (reach[i] >> 31) == 0) ? 1 : 0;
+    any |= c->lane[i] != 0;
+  }
+  if (!any) c->lane.clear();
 }
 
 yl_status check_cfg(yl_ctx* c, const yl_post_cfg* cfg) {
@@ -344,9 +421,9 @@ struct Job {
   int* keep_idx = nullptr;
 };
 
-yl_status run_chunk(yl_ctx* c, const Job& j, int b0, int bn, hipStream_t st) {
+yl_status run_chunk(yl_ctx* c, const Job& j, int b0, int bn, hipStream_t st, int chunk) {
   yl_status s = YL_OK;
-  if (j.x) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr);
+  if (j.x) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr, chunk);
   if (s == YL_OK && j.cfg) s = do_post(c, j.outs, b0, bn, j.cfg, j.dets, j.counts, j.keep_idx, st);
   return s;
 }
@@ -356,7 +433,7 @@ yl_status run_chunk(yl_ctx* c, const Job& j, int b0, int bn, hipStream_t st) {
 yl_status enqueue(yl_ctx* c, const Job& j, hipStream_t st) {
   int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
   if (j.B < 4 * n) n = 1;
-  if (n == 1) return run_chunk(c, j, 0, j.B, st);
+  if (n == 1) return run_chunk(c, j, 0, j.B, st, 0);
   if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   for (int i = 1; i < n; ++i) {
     if (!c->work[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));
@@ -370,7 +447,7 @@ yl_status enqueue(yl_ctx* c, const Job& j, hipStream_t st) {
     const int bn = base + (i < rem ? 1 : 0);
     hipStream_t ws = (i == 0) ? st : c->work[i];
     if (i > 0) HIPCHK(c, hipStreamWaitEvent(ws, c->ev_fork, 0));
-    if (s == YL_OK) s = run_chunk(c, j, b0, bn, ws);
+    if (s == YL_OK) s = run_chunk(c, j, b0, bn, ws, i);
     if (i > 0) {
       HIPCHK(c, hipEventRecord(c->ev_join[i], ws));
       HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
@@ -386,26 +463,63 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
   std::vector<unsigned char> key(sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), 0);
   memcpy(key.data(), &j, sizeof(Job));
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
-  memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &c->opt_streams, sizeof(int));
+  const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9);
+  memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
   memset(key.data() + offsetof(Job, cfg), 0, sizeof(void*));
+  // chunk plan (same split as enqueue).  Every chunk is captured into its OWN graph (main + side lane = two
+  // captured streams each) and the chunk graphs are launched on the chunk streams with an eager fork/join:
+  // capturing all chunks and their side lanes into one graph (4 streams) crashes hipGraphInstantiate on ROCm 7.2.
+  int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
+  if (j.B < 4 * n) n = 1;
+  const int base = j.B / n, rem = j.B % n;
   if (!c->graph_exec || key != c->graph_key) {
     drop_graph(c);
+    // every internal stream / event the captures and the launch will touch exists BEFORE capturing
+    for (int i = 0; i < 4; ++i) {
+      if (i > 0 && !c->work[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));
+      if (i > 0 && !c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+      if (!c->side[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+      if (!c->ev_la[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_la[i], hipEventDisableTiming));
+      if (!c->ev_lb[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lb[i], hipEventDisableTiming));
+    }
+    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     hipStream_t cs;
     HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    hipGraph_t g = nullptr;
-    HIPCHK(c, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    yl_status s = enqueue(c, j, cs);
-    hipError_t e = hipStreamEndCapture(cs, &g);
-    if (s == YL_OK && e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
-    if (g) hipGraphDestroy(g);
+    yl_status s = YL_OK;
+    hipError_t e = hipSuccess;
+    int b0 = 0;
+    for (int i = 0; i < n && s == YL_OK && e == hipSuccess; ++i) {
+      const int bn = base + (i < rem ? 1 : 0);
+      hipGraph_t g = nullptr;
+      e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+      if (e != hipSuccess) break;
+      s = run_chunk(c, j, b0, bn, cs, i);
+      e = hipStreamEndCapture(cs, &g);
+      if (s == YL_OK && e == hipSuccess)
+        e = hipGraphInstantiate(i == 0 ? &c->graph_exec : &c->graph_chunk[i], g, nullptr, nullptr, 0);
+      if (g) hipGraphDestroy(g);
+      b0 += bn;
+    }
     hipStreamDestroy(cs);
-    if (s != YL_OK) return s;
-    HIPCHK(c, e);
+    if (s != YL_OK) { drop_graph(c); return s; }
+    if (e != hipSuccess) { drop_graph(c); HIPCHK(c, e); }
     c->graph_key = key;
+    c->graph_n = n;
+  }
+  if (c->graph_n == 1) {
+    HIPCHK(c, hipGraphLaunch(c->graph_exec, st));
+    return YL_OK;
+  }
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));
+  for (int i = 1; i < c->graph_n; ++i) {
+    HIPCHK(c, hipStreamWaitEvent(c->work[i], c->ev_fork, 0));
+    HIPCHK(c, hipGraphLaunch(c->graph_chunk[i], c->work[i]));
+    HIPCHK(c, hipEventRecord(c->ev_join[i], c->work[i]));
   }
   HIPCHK(c, hipGraphLaunch(c->graph_exec, st));
+  for (int i = 1; i < c->graph_n; ++i) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
   return YL_OK;
 }
 
@@ -441,6 +555,9 @@ void yl_destroy(yl_ctx* c) {
   for (int i = 0; i < 4; ++i) {
     if (c->work[i]) hipStreamDestroy(c->work[i]);
     if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+    if (c->side[i]) hipStreamDestroy(c->side[i]);
+    if (c->ev_la[i]) hipEventDestroy(c->ev_la[i]);
+    if (c->ev_lb[i]) hipEventDestroy(c->ev_lb[i]);
   }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   hipFree(c->ws_nms_gkeys);
@@ -646,6 +763,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     if (c->proto_slot < 0 || c->proto_slot >= d->num_slots || c->slots[c->proto_slot].c != c->NM)
       return fail(c, YL_ERR_INVALID, "num_masks > 0 needs proto_slot with num_masks channels");
   }
+  assign_lanes(c);
   return YL_OK;
 }
 
@@ -653,6 +771,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "lanes")) { c->opt_lanes = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }
   return fail(c, YL_ERR_INVALID, std::string("unknown option ") + name);
