@@ -165,6 +165,8 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
 /* Options: "graph" (0/1: replay the whole call from a captured hipGraph), "streams" (1..4 internal
  * streams the batch is split over; default 2), "tile_m" (conv M-tile hint), "lanes" (0/1, default 0: neck/head
  * layers of the coarser levels run on a side stream next to the finest level's chain),
+ * "fuse_decode" (0/1, default 1: yl_predict decodes inside the head-output convs; the raw level tensors are
+ * then NOT materialised unless the model has mask coefficients),
  * "mfma_bf16" (0/1, default 0: SURVEY 8(f) f4 reduced-precision inference mode -- conv operands are rounded
  * to bf16 in registers and multiplied on v_mfma_f32_16x16x16_bf16 with fp32 accumulation; tensors stay
  * fp32 in memory.  The reference's counterpart is fp16 autocast in evaluate_model
@@ -202,7 +204,8 @@ yl_status yl_decode(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, 
 yl_status yl_postprocess(yl_ctx* ctx, const float* const* levels_dev, int32_t batch,
                          const yl_post_cfg* cfg, float* dets_dev, int32_t* counts_dev,
                          int32_t* keep_idx_dev, void* stream);
-/* forward + postprocess on the context's own level buffers (YoloLite.predict hot loop).
+/* forward + postprocess (YoloLite.predict hot loop).  With option "fuse_decode" (default) the raw head rows
+ * never reach memory; set it to 0 to have the context's level buffers filled as by yl_forward.
  * keep_idx_dev: optional [B][max_out] candidate indices (needed by yl_masks), NULL to skip.          */
 yl_status yl_predict(yl_ctx* ctx, const float* x_dev, int32_t batch, const yl_post_cfg* cfg,
                      float* dets_dev, int32_t* counts_dev, int32_t* keep_idx_dev, void* stream);

@@ -345,6 +345,35 @@ def test_predict_fused_equals_forward_plus_postprocess_and_graph():
     ctx.set_option("graph", 0)
 
 
+@pytest.mark.parametrize("idx", range(len(TINY)))
+def test_fused_decode_epilogue_equals_decode_kernel(idx):
+    """yl_predict decodes inside the head-output conv (no raw level tensor); yl_postprocess runs the decode
+    kernel on the levels yl_forward wrote.  Same arithmetic on the same logits: bitwise equal detections for
+    every post mode, C == 1, A == 2, P2/P6 levels and the centre/size variants."""
+    meta = make_meta(img_size=96, **TINY[idx])
+    sd = synth_state_dict(meta, seed=20 + idx, head_noise=2.0)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(96)
+    x = _x(5, 96, seed=idx).to(DEV)
+    outs = [o.clone() for o in m(x)]
+    cases = [(_lib.POST_MAIN, 0.05, 0.5, 300, 0, "v8", "softplus"), (_lib.POST_FALLBACK, 0.05, 0.45, 300, 50, "v8", "softplus"),
+             (_lib.POST_EVAL, 0.001, 0.65, 0, 0, "v8", "softplus"), (_lib.POST_MAIN, 0.05, 0.5, 300, 0, "simple", "v8"),
+             (_lib.POST_MAIN, 0.05, 0.5, 300, 0, "v8", "exp")]
+    total = 0
+    for mode, conf, iou, cap, topk, cm, wm in cases:
+        d1, c1 = ctx.postprocess(outs, mode, conf, iou, cap, topk, center_mode=cm, wh_mode=wm)
+        for fuse in (1, 0):
+            ctx.set_option("fuse_decode", fuse)
+            d2, c2 = ctx.predict(x, mode, conf, iou, cap, topk, center_mode=cm, wh_mode=wm)
+            assert torch.equal(c1, c2), (mode, cm, wm, fuse)
+            for b in range(5):
+                k = min(int(c1[b]), d1.shape[1])
+                assert torch.equal(d1[b, :k], d2[b, :k]), (mode, cm, wm, fuse, b)
+        ctx.set_option("fuse_decode", 1)
+        total += int(c1.sum())
+    assert total > 0
+
+
 def test_cli_infer_and_evaluate(tmp_path, golden_dir):
     """tools/infer.py and tools/evaluate.py (reference CLI surface) end to end on the tiny golden checkpoint."""
     import subprocess, sys

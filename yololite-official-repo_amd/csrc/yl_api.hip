@@ -60,6 +60,7 @@ struct yl_ctx {
   int nms_gP = 0;
   // options
   int opt_graph = 0, opt_tile_m = 0, opt_streams = 2;
+  int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
   int opt_bf16 = 0;   // 1: conv / stem-block launches use the bf16-MFMA builds (fp32 storage, fp32 accumulate)
   // batch chunks run on `opt_streams` internal streams (fork/join around every call): the
   // latency-bound low-resolution layers of one chunk overlap the bandwidth-bound layers of another
@@ -285,8 +286,24 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   }
 }
 
+// decode can be fused into the head-output convs when every one of them is a plain 1x1 conv whose 5+C(+masks)
+// columns fit one block's n-tiles (<= 128)
+bool can_fuse_decode(const yl_ctx* c) {
+  if (!c->opt_fuse_decode) return false;
+  bool any = false;
+  for (const auto& L : c->layers) {
+    if (L.d.head_level < 0) continue;
+    if (L.d.op != YL_OP_CONV || L.d.k != 1 || L.d.dw_k > 0 || L.d.c2 > 0 || L.d.cout > 128 || L.d.cout != c->E ||
+        L.d.act != YL_ACT_NONE || L.d.res_slot >= 0 || L.d.up_slot >= 0)
+      return false;
+    any = true;
+  }
+  return any;
+}
+
 yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* level_out, hipStream_t st,
-                     hipEvent_t* evs /*nullable: num_layers+1 events*/, int chunk = 0) {
+                     hipEvent_t* evs /*nullable: num_layers+1 events*/, int chunk = 0,
+                     const yl_post_cfg* fuse = nullptr /*non-null: head outputs decode in their epilogue*/) {
   if (evs) HIPCHK(c, hipEventRecord(evs[0], st));
   // two lanes (see yl_ctx::lane): lane-1 layers go to the chunk's side stream; an event edge is inserted
   // wherever a layer reads a slot produced on the other lane, and the side stream is joined at the end.
@@ -305,6 +322,16 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
     YlConvP p;
     layer_params(c, c->layers[i], b0, B, x, level_out, p);
     const yl_layer& d = c->layers[i].d;
+    if (fuse && d.head_level >= 0) {
+      const int l = d.head_level, S = c->level_S[l];
+      const size_t o = (size_t)b0 * c->N;
+      p.dec_boxes = c->ws_boxes + o; p.dec_scores = c->ws_scores + o; p.dec_cls = c->ws_cls + o;
+      p.dec_N = c->N; p.dec_off = c->level_off[l] + c->layers[i].head_anchor * S * S; p.dec_C = c->C;
+      p.dec_mode = fuse->mode; p.dec_center = fuse->center_mode; p.dec_wh = fuse->wh_mode;
+      p.dec_raw = c->NM > 0 ? 1 : 0;                          // mask coefficients are read from the raw rows
+      p.dec_stride = (float)((double)c->img_size / (double)S);   // utils_ms.py:71, as fill_levels
+      p.dec_hi = (float)(c->img_size - 1);
+    }
     const int ln = (lanes && c->lane[i]) ? 1 : 0;
     hipStream_t ls = ln ? sd : st;
     if (lanes) {
@@ -380,7 +407,7 @@ yl_status check_cfg(yl_ctx* c, const yl_post_cfg* cfg) {
 
 // post-processing of images [b0, b0+B) of a batch (workspaces must already cover b0+B images)
 yl_status do_post(yl_ctx* c, const float* const* levels_all, int b0, int B, const yl_post_cfg* cfg, float* dets,
-                  int* counts, int* keep_idx, hipStream_t st) {
+                  int* counts, int* keep_idx, hipStream_t st, bool decoded = false /*NMS inputs already written*/) {
   const float* levels[YL_MAX_LEVELS];
   for (int l = 0; l < c->L; ++l)
     levels[l] = levels_all[l] + (size_t)b0 * c->level_A[l] * c->level_S[l] * c->level_S[l] * c->E;
@@ -390,7 +417,7 @@ yl_status do_post(yl_ctx* c, const float* const* levels_all, int b0, int B, cons
   YlDecodeP dp;
   dp.mode = cfg->mode; dp.center_mode = cfg->center_mode; dp.wh_mode = cfg->wh_mode;
   dp.boxes = c->ws_boxes + o; dp.scores = c->ws_scores + o; dp.cls = c->ws_cls + o;
-  HIPCHK(c, yl_launch_decode_score(lv, B, dp, st));
+  if (!decoded) HIPCHK(c, yl_launch_decode_score(lv, B, dp, st));
   YlNmsP np;
   memset(&np, 0, sizeof(np));
   np.boxes = c->ws_boxes + o; np.scores = c->ws_scores + o; np.cls = c->ws_cls + o;
@@ -423,8 +450,9 @@ struct Job {
 
 yl_status run_chunk(yl_ctx* c, const Job& j, int b0, int bn, hipStream_t st, int chunk) {
   yl_status s = YL_OK;
-  if (j.x) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr, chunk);
-  if (s == YL_OK && j.cfg) s = do_post(c, j.outs, b0, bn, j.cfg, j.dets, j.counts, j.keep_idx, st);
+  const bool fused = j.x && j.cfg && can_fuse_decode(c);
+  if (j.x) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr, chunk, fused ? j.cfg : nullptr);
+  if (s == YL_OK && j.cfg) s = do_post(c, j.outs, b0, bn, j.cfg, j.dets, j.counts, j.keep_idx, st, fused);
   return s;
 }
 
@@ -463,7 +491,7 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
   std::vector<unsigned char> key(sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), 0);
   memcpy(key.data(), &j, sizeof(Job));
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
-  const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9);
+  const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10);
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
@@ -771,6 +799,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "fuse_decode")) { c->opt_fuse_decode = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "lanes")) { c->opt_lanes = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }

@@ -82,6 +82,18 @@ struct YlConvP {
   int C1, C2, C3, act2, act3;
   int SH, SW;            // stem output grid
   int tiles_x, tiles_y;  // 8x8 output tiles per image
+  // decode fused into the head-output conv (yl_predict): the epilogue turns the lane-distributed row of a
+  // candidate (tx,ty,tw,th,obj,cls...) into box / score / class and writes the NMS inputs directly; the
+  // raw level tensor is then only written when something else needs it (dec_raw: mask coefficients).
+  float4* dec_boxes;     // [B][dec_N] of this launch's images, nullptr = off
+  float* dec_scores;
+  int* dec_cls;
+  int dec_N;             // candidates per image (all levels)
+  int dec_off;           // candidate index of this layer's cell 0 (level offset + anchor * S*S)
+  int dec_C;             // classes
+  int dec_mode, dec_center, dec_wh;
+  int dec_raw;           // also write the raw rows
+  float dec_stride, dec_hi;
 };
 
 // launchers implemented in the .hip files

@@ -21,46 +21,7 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float yl_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float yl_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float yl_clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
-
-__device__ __forceinline__ int yl_level_of(const YlLevels& lv, int n) {
-  int l = 0;
-#pragma unroll
-  for (int i = 1; i < YL_MAX_LEVELS; ++i)
-    if (i < lv.L && n >= lv.off[i]) l = i;
-  return l;
-}
-
-__device__ __forceinline__ void yl_decode_box(const YlLevels& lv, int l, int r, float tx, float ty, float tw,
-                                              float th, int center_mode, int wh_mode, float& px, float& py,
-                                              float& pw, float& ph) {
-  const int S = lv.S[l];
-  const int cell = r % (S * S);
-  const float gx = (float)(cell % S), gy = (float)(cell / S);
-  const float st = lv.stride[l];
-  const float sx = yl_sigmoid(tx), sy = yl_sigmoid(ty);
-  if (center_mode == YL_CENTER_V8) {
-    px = ((sx * 2.0f - 0.5f) + gx) * st;
-    py = ((sy * 2.0f - 0.5f) + gy) * st;
-  } else {
-    px = (sx + gx) * st;
-    py = (sy + gy) * st;
-  }
-  if (wh_mode == YL_WH_SOFTPLUS) {
-    pw = yl_softplus(tw) * st;
-    ph = yl_softplus(th) * st;
-  } else if (wh_mode == YL_WH_V8) {
-    const float a = yl_sigmoid(tw) * 2.0f, b = yl_sigmoid(th) * 2.0f;
-    pw = (a * a) * st;
-    ph = (b * b) * st;
-  } else {
-    pw = expf(yl_clampf(tw, -4.0f, 4.0f)) * st;
-    ph = expf(yl_clampf(th, -4.0f, 4.0f)) * st;
-  }
-}
+#include "yl_decode.h"
 
 // ------------------------------------------------------------------------------------------------
 // decode + score: one lane per candidate.  A wave stages its 64 candidate rows (64*E contiguous

@@ -216,14 +216,14 @@ class HipContext:
         return out
 
     def predict(self, x: torch.Tensor, mode, conf, iou, per_class_cap=300, topk=0, max_out=None, backmap=None,
-                out: Optional[tuple] = None, want_idx: bool = False):
+                out: Optional[tuple] = None, want_idx: bool = False, center_mode="v8", wh_mode="softplus"):
         """Fused forward + post-processing on the context's own level buffers (no raw output copy)."""
         B = x.shape[0]
         if max_out is None:
             max_out = self.default_max_out(mode, per_class_cap, topk)
         if backmap is not None:
             backmap = backmap.to(device=self.device, dtype=torch.float32).contiguous()
-        cfg = self.make_cfg(mode, conf, iou, per_class_cap, topk, max_out, backmap=backmap)
+        cfg = self.make_cfg(mode, conf, iou, per_class_cap, topk, max_out, center_mode, wh_mode, backmap)
         if out is None:
             dets = torch.empty((B, max_out, 6), device=self.device, dtype=torch.float32)
             counts = torch.empty((B,), device=self.device, dtype=torch.int32)
