@@ -25,6 +25,7 @@
 #endif
 #include "yl_internal.h"
 #include "yl_dev.h"
+#include <type_traits>
 
 #ifndef SB_EXP
 #define SB_EXP 0                    // timing experiments (variant builds only): 1 no gathers, 2 no stem MFMAs,
@@ -179,7 +180,11 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     const int oy0 = tyi * SB_TR, ox0 = txi * SB_TC;                  // tile origin on the conv2 output grid
     const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;                  // patch origin on the stem grid
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW;
-    // ---- phase 1: stem on the patch -> wave-private LDS
+    // ---- phase 1: stem on the patch -> wave-private LDS.  Two copies of the code, selected by a wave-uniform
+    // branch: interior tiles (all but the image border) carry no padding logic at all -- left as a runtime flag
+    // the compiler predicates it per lane (compares, exec masking and 8 v_cndmask per m-tile on every tile)
+    auto phase1 = [&](auto interior_tag) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
     for (int m = 0; m < SB_MT1; ++m) {
       f32x4 a1[NT1];
@@ -204,17 +209,20 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
           else a1[nt][0] += wa[s][nt] * xv[m][s];
 #endif
       bool inside = true;
-      if (!interior) {
+      if (!INTERIOR) {
         const int sy = sy0 + ppi[m], sx = sx0 + ppj[m];
         inside = sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;       // else: zero padding of the second conv
       }
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
         f32x4 v = clamp4(a1[nt] + bias1[nt], lo1, hi1);     // conv + shift, the reference's order
-        if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!INTERIOR && !inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(patch + m * 16 * P1 + lq + nt * 16) = v;
       }
     }
+    };
+    if (interior) phase1(std::true_type{});
+    else phase1(std::false_type{});
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // LDS writes of other lanes -> reads below
     __builtin_amdgcn_wave_barrier();
     if (tile + wstride < ntiles) gather(tile + wstride);             // next tile's inputs: in flight during phases 2-3
