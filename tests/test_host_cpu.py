@@ -139,6 +139,20 @@ def fake_predict(x):            # stands in for HipContext.predict on this rank'
     return full_d[lo:hi].clone(), full_c[lo:hi].clone()
 d, c = ydist.sharded_predict(fake_predict, torch.zeros(total, 1), "cpu")
 assert torch.equal(d, full_d) and torch.equal(c, full_c), (rank, d.shape)
+if total % world == 0:          # zero-copy gatherer (equal shards): results written in place, one collective
+    b = total // world
+    gat = ydist.DetGatherer(b, 4, "cpu")
+    lo, hi = ydist.shard_range(total, rank, world)
+    for it in range(3):                                  # pipelined: gather() returns the previous step's result
+        gat.dets.copy_(full_d[lo:hi] + it); gat.counts.copy_(full_c[lo:hi] + it)
+        prev = gat.gather()
+        if it == 0:
+            assert prev is None
+        else:
+            assert torch.equal(prev[0].reshape(total, 4, 6), full_d + (it - 1))
+            assert torch.equal(prev[1].reshape(total), full_c + (it - 1))
+    gd, gc = gat.flush()
+    assert torch.equal(gd.reshape(total, 4, 6), full_d + 2) and torch.equal(gc.reshape(total), full_c + 2)
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 '''

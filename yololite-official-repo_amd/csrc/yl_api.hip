@@ -35,6 +35,7 @@ struct Slot {
 
 }  // namespace
 
+#define YL_GRAPH_SLOTS 4
 struct yl_ctx {
   int device = 0;
   int img_size = 0, in_ch = 3, C = 0, L = 0, N = 0, E = 0, NM = 0, proto_slot = -1;
@@ -76,10 +77,16 @@ struct yl_ctx {
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_la[4] = {nullptr, nullptr, nullptr, nullptr}, ev_lb[4] = {nullptr, nullptr, nullptr, nullptr};
   // single-entry hipGraph cache keyed on everything baked into the captured launches
-  hipGraphExec_t graph_exec = nullptr;          // chunk 0 (or the whole job when it is not split)
-  hipGraphExec_t graph_chunk[4] = {nullptr, nullptr, nullptr, nullptr};   // chunks 1.. : one graph per chunk
-  int graph_n = 0;
-  std::vector<unsigned char> graph_key;
+  // hipGraph cache: up to YL_GRAPH_SLOTS jobs (a serving loop alternates between a few input / output buffers,
+  // e.g. the two slots of the pipelined all-gather), least recently used evicted
+  struct GraphEntry {
+    hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};   // one graph per batch chunk
+    int n = 0;
+    std::vector<unsigned char> key;
+    unsigned long long stamp = 0;
+  };
+  std::vector<GraphEntry> graphs;
+  unsigned long long graph_clock = 0;
   std::string err;
 };
 
@@ -178,14 +185,10 @@ void free_post_ws(yl_ctx* c) {
 }
 
 void drop_graph(yl_ctx* c) {
-  if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
-  c->graph_exec = nullptr;
-  for (int i = 0; i < 4; ++i) {
-    if (c->graph_chunk[i]) hipGraphExecDestroy(c->graph_chunk[i]);
-    c->graph_chunk[i] = nullptr;
-  }
-  c->graph_n = 0;
-  c->graph_key.clear();
+  for (auto& g : c->graphs)
+    for (int i = 0; i < 4; ++i)
+      if (g.exec[i]) hipGraphExecDestroy(g.exec[i]);
+  c->graphs.clear();
 }
 
 void free_act(yl_ctx* c) {
@@ -502,8 +505,10 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
   int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
   if (j.B < 4 * n) n = 1;
   const int base = j.B / n, rem = j.B % n;
-  if (!c->graph_exec || key != c->graph_key) {
-    drop_graph(c);
+  yl_ctx::GraphEntry* ge = nullptr;
+  for (auto& g : c->graphs)
+    if (g.key == key) { ge = &g; break; }
+  if (!ge) {
     // every internal stream / event the captures and the launch will touch exists BEFORE capturing
     for (int i = 0; i < 4; ++i) {
       if (i > 0 && !c->work[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));
@@ -513,6 +518,7 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
       if (!c->ev_lb[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lb[i], hipEventDisableTiming));
     }
     if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    yl_ctx::GraphEntry fresh;
     hipStream_t cs;
     HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     yl_status s = YL_OK;
@@ -525,29 +531,43 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
       if (e != hipSuccess) break;
       s = run_chunk(c, j, b0, bn, cs, i);
       e = hipStreamEndCapture(cs, &g);
-      if (s == YL_OK && e == hipSuccess)
-        e = hipGraphInstantiate(i == 0 ? &c->graph_exec : &c->graph_chunk[i], g, nullptr, nullptr, 0);
+      if (s == YL_OK && e == hipSuccess) e = hipGraphInstantiate(&fresh.exec[i], g, nullptr, nullptr, 0);
       if (g) hipGraphDestroy(g);
       b0 += bn;
     }
     hipStreamDestroy(cs);
-    if (s != YL_OK) { drop_graph(c); return s; }
-    if (e != hipSuccess) { drop_graph(c); HIPCHK(c, e); }
-    c->graph_key = key;
-    c->graph_n = n;
+    if (s != YL_OK || e != hipSuccess) {
+      for (int i = 0; i < 4; ++i)
+        if (fresh.exec[i]) hipGraphExecDestroy(fresh.exec[i]);
+      if (s != YL_OK) return s;
+      HIPCHK(c, e);
+    }
+    fresh.key = key;
+    fresh.n = n;
+    if (c->graphs.size() >= YL_GRAPH_SLOTS) {                 // evict the least recently used entry
+      size_t v = 0;
+      for (size_t i = 1; i < c->graphs.size(); ++i)
+        if (c->graphs[i].stamp < c->graphs[v].stamp) v = i;
+      for (int i = 0; i < 4; ++i)
+        if (c->graphs[v].exec[i]) hipGraphExecDestroy(c->graphs[v].exec[i]);
+      c->graphs.erase(c->graphs.begin() + v);
+    }
+    c->graphs.push_back(fresh);
+    ge = &c->graphs.back();
   }
-  if (c->graph_n == 1) {
-    HIPCHK(c, hipGraphLaunch(c->graph_exec, st));
+  ge->stamp = ++c->graph_clock;
+  if (ge->n == 1) {
+    HIPCHK(c, hipGraphLaunch(ge->exec[0], st));
     return YL_OK;
   }
   HIPCHK(c, hipEventRecord(c->ev_fork, st));
-  for (int i = 1; i < c->graph_n; ++i) {
+  for (int i = 1; i < ge->n; ++i) {
     HIPCHK(c, hipStreamWaitEvent(c->work[i], c->ev_fork, 0));
-    HIPCHK(c, hipGraphLaunch(c->graph_chunk[i], c->work[i]));
+    HIPCHK(c, hipGraphLaunch(ge->exec[i], c->work[i]));
     HIPCHK(c, hipEventRecord(c->ev_join[i], c->work[i]));
   }
-  HIPCHK(c, hipGraphLaunch(c->graph_exec, st));
-  for (int i = 1; i < c->graph_n; ++i) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
+  HIPCHK(c, hipGraphLaunch(ge->exec[0], st));
+  for (int i = 1; i < ge->n; ++i) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
   return YL_OK;
 }
 

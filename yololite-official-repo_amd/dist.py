@@ -56,3 +56,61 @@ def sharded_predict(predict_fn, x_global_cpu_or_dev: torch.Tensor, device, group
     lo, hi = shard_range(total, rank, world)
     dets, counts = predict_fn(x_global_cpu_or_dev[lo:hi].to(device))
     return allgather_dets(dets, counts, total, group)
+
+
+class DetGatherer:
+    """Zero-copy, pipelined exchange for equal shards (the serving / benchmark case: b_local images on every
+    rank).  The per-rank result lives in ONE flat buffer [dets (b*max_out*6 floats) | counts (b int32)] that
+    yl_predict writes in place (`.dets`, `.counts` are views of the CURRENT slot); `gather()` starts a single
+    asynchronous all_gather_into_tensor of that buffer into a preallocated [world, row] tensor and flips to the
+    other slot, so the collective of step i overlaps the forward pass of step i+1 (no pack / unpack kernels, no
+    host-blocking wait: on ROCm 7 a synchronous all_gather issued behind a busy compute stream costs ~0.7 ms,
+    the asynchronous one ~0.03 ms -- tools/ag_probe.py).  `gather()` returns the PREVIOUS step's result views
+    (None on the first call); `flush()` waits for everything in flight and returns the last one.
+    Results: dets [world, b, max_out, 6], counts [world, b]; image i of the global batch is (i // b, i % b)."""
+
+    def __init__(self, b_local: int, max_out: int, device, group=None, slots: int = 2):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.b, self.max_out = int(b_local), int(max_out)
+        nd = self.b * self.max_out * 6
+        self._nd = nd
+        self._loc = [torch.zeros((nd + self.b,), device=device, dtype=torch.float32) for _ in range(slots)]
+        self._out = [torch.zeros((self.world, nd + self.b), device=device, dtype=torch.float32) for _ in range(slots)]
+        self._work = [None] * slots
+        self._k = 0
+        self._last = None
+
+    @property
+    def dets(self) -> torch.Tensor:
+        return self._loc[self._k][:self._nd].view(self.b, self.max_out, 6)
+
+    @property
+    def counts(self) -> torch.Tensor:
+        return self._loc[self._k][self._nd:].view(torch.int32)
+
+    def _views(self, k):
+        return (self._out[k][:, :self._nd].view(self.world, self.b, self.max_out, 6),
+                self._out[k][:, self._nd:].view(torch.int32))
+
+    def gather(self):
+        k = self._k
+        if dist.is_initialized():
+            self._work[k] = dist.all_gather_into_tensor(self._out[k].view(-1), self._loc[k], group=self.group,
+                                                        async_op=True)
+        else:
+            self._out[k][0].copy_(self._loc[k])
+        prev, self._last = self._last, k
+        self._k = (k + 1) % len(self._loc)
+        nxt = self._k                      # the slot yl_predict writes next must not be in flight any more
+        if self._work[nxt] is not None:
+            self._work[nxt].wait()
+            self._work[nxt] = None
+        return None if prev is None else self._views(prev)
+
+    def flush(self):
+        for i, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[i] = None
+        return None if self._last is None else self._views(self._last)
