@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="internal streams the batch is split over")
     ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
+    ap.add_argument("--batch-levels", type=int, default=1, help="smooth / head layers of all pyramid levels as one launch")
     ap.add_argument("--fuse-decode", type=int, default=1, help="decode inside the head-output conv epilogue")
     ap.add_argument("--lanes", type=int, default=0, help="side-stream lane for the coarse-level neck/head layers")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16-MFMA compute mode (f4; NOT the headline: reduced precision)")
@@ -246,6 +247,7 @@ def main():
         ctx.set_option("mfma_bf16", 1)
     ctx.set_option("lanes", args.lanes)
     ctx.set_option("fuse_decode", args.fuse_decode)
+    ctx.set_option("batch_levels", args.batch_levels)
     x = synth_images(B, S, seed=1234 + rank).to(dev)
     max_out = 300                                        # packed result rows per image
     gat = None

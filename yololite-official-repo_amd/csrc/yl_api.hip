@@ -61,6 +61,8 @@ struct yl_ctx {
   int nms_gP = 0;
   // options
   int opt_graph = 0, opt_tile_m = 0, opt_streams = 2;
+  int opt_batch_levels = 1;  // runs of independent, identically shaped layers (FPN smooth / head trunk / head out of all
+                             // levels) go out as ONE launch (YlConvMulti)
   int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
   int opt_bf16 = 0;   // 1: conv / stem-block launches use the bf16-MFMA builds (fp32 storage, fp32 accumulate)
   // batch chunks run on `opt_streams` internal streams (fork/join around every call): the
@@ -321,8 +323,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
   }
   std::vector<unsigned char> prod(c->slots.size(), 0);     // lane that produced each slot
   bool side_used = false;
-  for (size_t i = 0; i < c->layers.size(); ++i) {
-    YlConvP p;
+  auto params = [&](size_t i, YlConvP& p) {
     layer_params(c, c->layers[i], b0, B, x, level_out, p);
     const yl_layer& d = c->layers[i].d;
     if (fuse && d.head_level >= 0) {
@@ -335,6 +336,45 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
       p.dec_stride = (float)((double)c->img_size / (double)S);   // utils_ms.py:71, as fill_levels
       p.dec_hi = (float)(c->img_size - 1);
     }
+  };
+  // layers i and j can share a launch: same kernel configuration, no residual / upsample operands
+  auto same_shape = [&](size_t i, size_t j) {
+    const yl_layer& a = c->layers[i].d; const yl_layer& e = c->layers[j].d;
+    return a.op == YL_OP_CONV && e.op == YL_OP_CONV && a.cin == e.cin && a.cout == e.cout && a.k == e.k &&
+           a.stride == e.stride && a.pad_t == e.pad_t && a.pad_l == e.pad_l && a.act == e.act &&
+           a.in_shift == e.in_shift && a.dw_k == e.dw_k && a.dw_stride == e.dw_stride && a.dw_pad_t == e.dw_pad_t &&
+           a.dw_pad_l == e.dw_pad_l && a.dw_act == e.dw_act && a.c2 == 0 && e.c2 == 0 && a.res_slot < 0 &&
+           e.res_slot < 0 && a.up_slot < 0 && e.up_slot < 0 && (a.head_level >= 0) == (e.head_level >= 0) &&
+           (a.cout + 15) / 16 <= 8;
+  };
+  for (size_t i = 0; i < c->layers.size();) {
+    const yl_layer& d = c->layers[i].d;
+    // ---- level-batched run starting at i (not under per-layer timing, not with side lanes)
+    size_t gend = i + 1;
+    if (!evs && !lanes && c->opt_batch_levels && d.op == YL_OP_CONV) {
+      while (gend < c->layers.size() && gend - i < 4 && same_shape(i, gend)) {
+        bool dep = false;
+        for (size_t q = i; q < gend; ++q)
+          if (c->layers[q].d.head_level < 0 && c->layers[q].d.out_slot == c->layers[gend].d.in_slot) dep = true;
+        if (dep) break;
+        ++gend;
+      }
+    }
+    if (gend - i > 1) {
+      YlConvP ps[4];
+      for (size_t q = i; q < gend; ++q) params(q, ps[q - i]);
+      const hipError_t e = c->opt_bf16 ? yl_launch_conv_multi_bf16(ps, (int)(gend - i), c->opt_tile_m, st)
+                                       : yl_launch_conv_multi(ps, (int)(gend - i), c->opt_tile_m, st);
+      if (e != hipSuccess) {
+        char b[256];
+        snprintf(b, sizeof(b), "layers %zu..%zu batched launch failed: %s", i, gend - 1, hipGetErrorString(e));
+        return fail(c, YL_ERR_HIP, b);
+      }
+      i = gend;
+      continue;
+    }
+    YlConvP p;
+    params(i, p);
     const int ln = (lanes && c->lane[i]) ? 1 : 0;
     hipStream_t ls = ln ? sd : st;
     if (lanes) {
@@ -364,6 +404,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
       return fail(c, YL_ERR_HIP, b);
     }
     if (evs) HIPCHK(c, hipEventRecord(evs[i + 1], st));
+    ++i;
   }
   if (side_used) {                                          // join: decode / the caller see both lanes
     HIPCHK(c, hipEventRecord(c->ev_lb[chunk], sd));
@@ -494,7 +535,7 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
   std::vector<unsigned char> key(sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), 0);
   memcpy(key.data(), &j, sizeof(Job));
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
-  const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10);
+  const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10) | (c->opt_batch_levels << 11);
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
@@ -819,6 +860,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "batch_levels")) { c->opt_batch_levels = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "fuse_decode")) { c->opt_fuse_decode = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "lanes")) { c->opt_lanes = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }

@@ -29,6 +29,7 @@
 #define yl_stem_mfma_kernel yl_stem_mfma_kernel_bf16
 #define yl_dw_kernel yl_dw_kernel_bf16
 #define yl_launch_conv yl_launch_conv_bf16
+#define yl_launch_conv_multi yl_launch_conv_multi_bf16
 #define yl_launch_stem yl_launch_stem_bf16
 #define yl_launch_dw yl_launch_dw_bf16
 #define yl_conv_init yl_conv_init_bf16
@@ -338,8 +339,19 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
 #ifndef YL_PW_SCHED
 #define YL_PW_SCHED 24         // pin loads-before-MFMAs (A/B: 0 -> 29.33k, 12 -> 29.69k, 24 -> 29.75k img/s) in the 1x1/kxk loop (value = VALU ops in the address group)
 #endif
+// problem of this block in a level-batched launch (YlConvMulti) and the block's index / count inside it
+#define YL_SELECT_PROBLEM(m)                                                        \
+  int yl_k = 0;                                                                     \
+  if ((m).n > 1 && (int)blockIdx.x >= (m).p[1].blk0) yl_k = 1;                     \
+  if ((m).n > 2 && (int)blockIdx.x >= (m).p[2].blk0) yl_k = 2;                     \
+  if ((m).n > 3 && (int)blockIdx.x >= (m).p[3].blk0) yl_k = 3;                     \
+  const YlConvP& p = (m).p[yl_k];                                                   \
+  const int bx = p.nblk ? (int)blockIdx.x - p.blk0 : (int)blockIdx.x;               \
+  const int gx = p.nblk ? p.nblk : (int)gridDim.x;
+
 template <int NT, int MT, int MODE>
-__global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
+__global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvMulti mp) {
+  YL_SELECT_PROBLEM(mp)
   extern __shared__ __attribute__((aligned(16))) float yl_wlds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4, pl = lane & 15;
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
   if (single) load_chunk(0, TK);
   bool need_sync = single || DWM;     // first LDS read happens after the first activation loads are in flight
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  for (int tile = bx; tile < p.ntiles; tile += gx) {
     YlPix px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -514,7 +526,8 @@ __global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvP p) {
 #define YL_DWH_PREADD 1
 #endif
 template <int NT, int DK, int DS>
-__global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
+__global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
+  YL_SELECT_PROBLEM(mp)
   constexpr int HP = 3 * DS + DK;                         // halo edge in pixels
   // row pitch in floats, == 56 (mod 64): consecutive patch rows start 32 B "earlier" modulo the 256-B LDS
   // row, which makes the 16 lanes of every ds_read_b128 group (2 tile rows x 4 pixels x 2 channel quads)
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
   const int tw = p.OW >> 2, th = p.OH >> 2;
   const int tiles_img = tw * th;
   const int ntiles = p.B * tiles_img;
-  const int wstride = gridDim.x * 4;
+  const int wstride = gx * 4;
   // lane constants: LDS offsets of the staging slots (halo pixel / channel quad) and the read base of the
   // lane's output pixel
   int s_lo[NSLOT];
@@ -600,7 +613,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvP p) {
       if (s_ok[j]) *reinterpret_cast<f32x4*>(halo + s_lo[j]) = r[j];
   };
   f32x4 stg[NSLOT];
-  int tile = blockIdx.x * 4 + wave;
+  int tile = bx * 4 + wave;
 #if YL_DWH_XTILE
   if (tile < ntiles) {                  // software pipeline over (tile, channel block): prime with (tile0, 0);
     tile_geom(tile);                    // its loads fly under the weight fill below
@@ -1104,11 +1117,12 @@ static int yl_dwh_resident(const YlConvP& p, size_t lds) {
 }
 
 template <int NT>
-static bool yl_dwh_go(const YlConvP& p, dim3 grid, size_t lds, hipStream_t st) {
-  if (p.dw_k == 3 && p.dw_stride == 1) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 3, 1>), grid, dim3(256), lds, st, p);
-  else if (p.dw_k == 3 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 3, 2>), grid, dim3(256), lds, st, p);
-  else if (p.dw_k == 5 && p.dw_stride == 1) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 5, 1>), grid, dim3(256), lds, st, p);
-  else if (p.dw_k == 5 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 5, 2>), grid, dim3(256), lds, st, p);
+static bool yl_dwh_go(const YlConvMulti& m, dim3 grid, size_t lds, hipStream_t st) {
+  const YlConvP& p = m.p[0];
+  if (p.dw_k == 3 && p.dw_stride == 1) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 3, 1>), grid, dim3(256), lds, st, m);
+  else if (p.dw_k == 3 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 3, 2>), grid, dim3(256), lds, st, m);
+  else if (p.dw_k == 5 && p.dw_stride == 1) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 5, 1>), grid, dim3(256), lds, st, m);
+  else if (p.dw_k == 5 && p.dw_stride == 2) hipLaunchKernelGGL((yl_conv_dwh_kernel<NT, 5, 2>), grid, dim3(256), lds, st, m);
   else return false;
   return true;
 }
@@ -1134,28 +1148,59 @@ static int yl_conv_resident_nt(int NT, int mode, size_t lds) {
 }
 
 template <int NT, int MT>
-static void yl_conv_go(const YlConvP& p, int mode, dim3 grid, size_t lds, hipStream_t st) {
-  if (mode == YL_CM_PW) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_PW>), grid, dim3(256), lds, st, p);
-  else if (mode == YL_CM_KXK) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_KXK>), grid, dim3(256), lds, st, p);
-  else if (mode == YL_CM_DW3) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DW3>), grid, dim3(256), lds, st, p);
-  else if (mode == YL_CM_DW5) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DW5>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DWPRO>), grid, dim3(256), lds, st, p);
+static void yl_conv_go(const YlConvMulti& m, int mode, dim3 grid, size_t lds, hipStream_t st) {
+  if (mode == YL_CM_PW) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_PW>), grid, dim3(256), lds, st, m);
+  else if (mode == YL_CM_KXK) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_KXK>), grid, dim3(256), lds, st, m);
+  else if (mode == YL_CM_DW3) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DW3>), grid, dim3(256), lds, st, m);
+  else if (mode == YL_CM_DW5) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DW5>), grid, dim3(256), lds, st, m);
+  else hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DWPRO>), grid, dim3(256), lds, st, m);
 }
 template <int MT>
-static void yl_conv_go_nt(const YlConvP& p, int NT, int mode, dim3 grid, size_t lds, hipStream_t st) {
+static void yl_conv_go_nt(const YlConvMulti& m, int NT, int mode, dim3 grid, size_t lds, hipStream_t st) {
   switch (NT) {
-    case 1: yl_conv_go<1, MT>(p, mode, grid, lds, st); break;
-    case 2: yl_conv_go<2, MT>(p, mode, grid, lds, st); break;
-    case 3: yl_conv_go<3, MT>(p, mode, grid, lds, st); break;
-    case 4: yl_conv_go<4, MT>(p, mode, grid, lds, st); break;
-    case 6: yl_conv_go<6, MT>(p, mode, grid, lds, st); break;
-    default: yl_conv_go<8, MT>(p, mode, grid, lds, st); break;
+    case 1: yl_conv_go<1, MT>(m, mode, grid, lds, st); break;
+    case 2: yl_conv_go<2, MT>(m, mode, grid, lds, st); break;
+    case 3: yl_conv_go<3, MT>(m, mode, grid, lds, st); break;
+    case 4: yl_conv_go<4, MT>(m, mode, grid, lds, st); break;
+    case 6: yl_conv_go<6, MT>(m, mode, grid, lds, st); break;
+    default: yl_conv_go<8, MT>(m, mode, grid, lds, st); break;
   }
 }
 
-// choose (NT, MT, chunking) for a layer and launch.  tile_hint: 0 = auto, 1/2 = force MT.
-hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
-  YlConvP p = p0;
+// split `gx` blocks over the problems in proportion to their tile counts (every problem gets >= 1 block and
+// never more blocks than tiles); n == 1 keeps the whole grid (nblk = 0)
+static int yl_partition_blocks(YlConvMulti& m, const long* tiles, int gx) {
+  if (m.n == 1) { m.p[0].blk0 = 0; m.p[0].nblk = 0; return gx; }
+  long total = 0;
+  for (int k = 0; k < m.n; ++k) total += tiles[k];
+  int at = 0;
+  for (int k = 0; k < m.n; ++k) {
+    long nb = (tiles[k] * gx + total / 2) / total;
+    if (nb < 1) nb = 1;
+    if (nb > tiles[k]) nb = tiles[k];
+    m.p[k].blk0 = at;
+    m.p[k].nblk = (int)nb;
+    at += (int)nb;
+  }
+  return at;
+}
+
+// choose (NT, MT, chunking) for a layer -- or for up to 4 layers of identical configuration that run as ONE
+// launch (YlConvMulti) -- and launch.  tile_hint: 0 = auto, 1/2 = force MT.
+hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStream_t st) {
+  if (n < 1 || n > 4) return hipErrorInvalidValue;
+  YlConvMulti m = {};
+  m.n = n;
+  int big = 0;
+  for (int k = 0; k < n; ++k) {
+    m.p[k] = ps[k];
+    if (ps[k].M > ps[big].M) big = k;
+    if (ps[k].NTtot != ps[0].NTtot || ps[k].KB != ps[0].KB || ps[k].TK != ps[0].TK || ps[k].dw_k != ps[0].dw_k ||
+        ps[k].dw_stride != ps[0].dw_stride || ps[k].k != ps[0].k || ps[k].stride != ps[0].stride ||
+        ps[k].N != ps[0].N || ps[k].Cin != ps[0].Cin || (ps[k].C1 > 0) != (ps[0].C1 > 0))
+      return hipErrorInvalidValue;
+  }
+  const YlConvP& p = m.p[big];                              // decisions follow the largest problem
   const int nts[6] = {1, 2, 3, 4, 6, 8};
   int NT = 8;
   if (p.NTtot <= 8) {
@@ -1170,18 +1215,28 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
     NT = best;
   }
   const int gy = (p.NTtot + NT - 1) / NT;
+  if (n > 1 && gy != 1) return hipErrorInvalidValue;
   if (p.C1 > 0) {          // fused inverted-residual block (expand -> depthwise -> project)
-    if (gy != 1 || (p.OH & 3) || (p.OW & 3) || p.dw_stride != 1) return hipErrorInvalidValue;
+    if (n != 1 || gy != 1 || (p.OH & 3) || (p.OW & 3) || p.dw_stride != 1) return hipErrorInvalidValue;
     return yl_uib_dispatch(p, yl_uib_lds_bytes(p.Cin, NT, p.dw_k), st, false, NT, p.dw_k, (p.C1 + 15) / 16);
   }
   // depthwise prologue with LDS-staged halo tiles (4x4 output pixels per wave)
-  if (p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.OH & 3) == 0 &&
-      (p.OW & 3) == 0 && (p.N & 3) == 0 && tile_hint != 3) {
+  bool halo = p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.N & 3) == 0 &&
+              tile_hint != 3;
+  for (int k = 0; k < n; ++k)
+    halo = halo && (m.p[k].OH & 3) == 0 && (m.p[k].OW & 3) == 0 &&
+           (size_t)m.p[k].B * m.p[k].H * m.p[k].W * m.p[k].Cin * 4 < ((size_t)1 << 31);
+  if (halo) {
     const int HP = 3 * p.dw_stride + p.dw_k;
     const int PITCHF = ((HP * 16 + 7) / 64) * 64 + 56;
     const size_t lds = (size_t)p.KB * NT * 1024 + (size_t)(p.dw_k * p.dw_k + 1) * p.Cin * 4 + (size_t)4 * HP * PITCHF * 4;
-    if (lds <= YL_DWH_LDS_MAX && (size_t)p.B * p.H * p.W * p.Cin * 4 < ((size_t)1 << 31)) {
-      const long wtiles = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
+    if (lds <= YL_DWH_LDS_MAX) {
+      long tiles[4], wtotal = 0;
+      for (int k = 0; k < n; ++k) {
+        const long wt = (long)m.p[k].B * (m.p[k].OH >> 2) * (m.p[k].OW >> 2);
+        tiles[k] = (wt + 3) / 4;                            // block-sized units (4 waves)
+        wtotal += tiles[k];
+      }
       int res = 0;
       switch (NT) {
         case 1: res = yl_dwh_resident<1>(p, lds); break;
@@ -1194,45 +1249,60 @@ hipError_t yl_launch_conv(const YlConvP& p0, int tile_hint, hipStream_t st) {
       int gx = res / gy;
       if (gx < 8) gx = 8;
       gx &= ~7;
-      if (gx > (wtiles + 3) / 4) gx = (int)((wtiles + 3) / 4);
+      if (gx > wtotal) gx = (int)wtotal;
+      gx = yl_partition_blocks(m, tiles, gx);
       dim3 grid(gx, gy);
       bool ok = false;
       switch (NT) {
-        case 1: ok = yl_dwh_go<1>(p, grid, lds, st); break;
-        case 2: ok = yl_dwh_go<2>(p, grid, lds, st); break;
-        case 3: ok = yl_dwh_go<3>(p, grid, lds, st); break;
-        case 4: ok = yl_dwh_go<4>(p, grid, lds, st); break;
-        case 6: ok = yl_dwh_go<6>(p, grid, lds, st); break;
-        default: ok = yl_dwh_go<8>(p, grid, lds, st); break;
+        case 1: ok = yl_dwh_go<1>(m, grid, lds, st); break;
+        case 2: ok = yl_dwh_go<2>(m, grid, lds, st); break;
+        case 3: ok = yl_dwh_go<3>(m, grid, lds, st); break;
+        case 4: ok = yl_dwh_go<4>(m, grid, lds, st); break;
+        case 6: ok = yl_dwh_go<6>(m, grid, lds, st); break;
+        default: ok = yl_dwh_go<8>(m, grid, lds, st); break;
       }
       if (ok) return hipGetLastError();
     }
   }
+  long Mtot = 0;
+  for (int k = 0; k < n; ++k) Mtot += m.p[k].M;
   int MT = 2;
-  const long tiles2 = ((long)p.M + 127) / 128;
+  const long tiles2 = (Mtot + 127) / 128;
   if (tile_hint == 1 || (tile_hint == 0 && tiles2 * gy < 2 * YL_NUM_CU)) MT = 1;
   if (p.dw_k > 0) MT = 1;           // depthwise prologue: one m-tile per wave (register budget -> occupancy)
-  p.ntiles = (int)(((long)p.M + 64 * MT - 1) / (64 * MT));
   // LDS weight chunk: whole K if it fits, else stream 48 KiB chunks
   const size_t step_bytes = (size_t)NT * 1024;
   size_t extra = p.dw_k > 0 ? (((size_t)(p.dw_k * p.dw_k + 1) * p.Cin * sizeof(float) + 15) & ~(size_t)15) : 0;
   if (p.N & 3) extra += (size_t)4 * MT * 16 * p.N * sizeof(float);     // store staging (head rows)
   if (extra + step_bytes > YL_CONV_LDS_MAX) return hipErrorInvalidValue;
   const size_t budget = YL_CONV_LDS_MAX - extra;
-  if ((size_t)p.TK * step_bytes <= budget) p.CH = p.TK;                // whole K resident
-  else p.CH = (int)((budget < 48 * 1024 ? budget : 48 * 1024) / step_bytes);   // stream K in chunks
-  const size_t lds = (size_t)p.CH * step_bytes + extra;
+  int CH;
+  if ((size_t)p.TK * step_bytes <= budget) CH = p.TK;                  // whole K resident
+  else CH = (int)((budget < 48 * 1024 ? budget : 48 * 1024) / step_bytes);   // stream K in chunks
+  const size_t lds = (size_t)CH * step_bytes + extra;
   const int mode = p.dw_k == 3 ? YL_CM_DW3 : p.dw_k == 5 ? YL_CM_DW5 : p.dw_k > 0 ? YL_CM_DWPRO
                    : ((p.k == 1 && p.stride == 1) ? YL_CM_PW : YL_CM_KXK);
+  long tiles[4], ttotal = 0;
+  for (int k = 0; k < n; ++k) {
+    m.p[k].CH = CH;
+    m.p[k].ntiles = (int)(((long)m.p[k].M + 64 * MT - 1) / (64 * MT));
+    tiles[k] = m.p[k].ntiles;
+    ttotal += tiles[k];
+  }
   const int res = (MT == 2) ? yl_conv_resident_nt<2>(NT, mode, lds) : yl_conv_resident_nt<1>(NT, mode, lds);
   int gx = res / gy;
   if (gx < 8) gx = 8;
   gx &= ~7;                         // multiple of 8: N-chunks of one M tile land on the same XCD/L2
-  if (gx > p.ntiles) gx = p.ntiles;
+  if (gx > ttotal) gx = (int)ttotal;
+  gx = yl_partition_blocks(m, tiles, gx);
   dim3 grid(gx, gy);
-  if (MT == 2) yl_conv_go_nt<2>(p, NT, mode, grid, lds, st);
-  else yl_conv_go_nt<1>(p, NT, mode, grid, lds, st);
+  if (MT == 2) yl_conv_go_nt<2>(m, NT, mode, grid, lds, st);
+  else yl_conv_go_nt<1>(m, NT, mode, grid, lds, st);
   return hipGetLastError();
+}
+
+hipError_t yl_launch_conv(const YlConvP& p, int tile_hint, hipStream_t st) {
+  return yl_launch_conv_multi(&p, 1, tile_hint, st);
 }
 
 hipError_t yl_launch_stem(const YlConvP& p0, hipStream_t st) {

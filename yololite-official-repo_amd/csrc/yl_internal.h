@@ -94,6 +94,18 @@ struct YlConvP {
   int dec_mode, dec_center, dec_wh;
   int dec_raw;           // also write the raw rows
   float dec_stride, dec_hi;
+  // level-batched launches (YlConvMulti): this problem owns blocks [blk0, blk0 + nblk) of grid.x; nblk == 0
+  // means the whole grid (single-problem launch)
+  int blk0, nblk;
+};
+
+// Up to 4 independent convolutions of identical kernel configuration in ONE launch (the FPN smooth blocks,
+// head trunks and head outputs of all pyramid levels): every block serves one problem, the grid is split in
+// proportion to the tile counts.  The coarse levels (20x20, 40x40: latency-bound on their own, 5 % and 19 % of
+// the tiles) ride along with the 80x80 level instead of paying their own launches.
+struct YlConvMulti {
+  int n;
+  YlConvP p[4];
 };
 
 // launchers implemented in the .hip files
@@ -109,6 +121,7 @@ hipError_t yl_post_init();   // one-time function attributes (large dynamic LDS)
 
 hipError_t yl_launch_stem(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv(const YlConvP& p, int tile_hint, hipStream_t st);
+hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStream_t st);   // n <= 4, same config
 hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_stemblock(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init();
@@ -117,6 +130,7 @@ hipError_t yl_conv_init();
 bool yl_uib_supported(int c1, int cmid, int n, int dk);
 // bf16-MFMA builds of yl_conv.hip / yl_stemblock.hip (compiled a second time with -DYL_BF16=1, see yl_dev.h)
 hipError_t yl_launch_conv_bf16(const YlConvP& p, int tile_hint, hipStream_t st);
+hipError_t yl_launch_conv_multi_bf16(const YlConvP* ps, int n, int tile_hint, hipStream_t st);
 hipError_t yl_conv_init_bf16();
 hipError_t yl_launch_stemblock_bf16(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init_bf16();

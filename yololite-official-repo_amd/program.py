@@ -497,19 +497,25 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     for n_, (slot, ch, red) in zip(pyr, feats):
         prog.feature_slots["c" + n_[1]] = slot
 
+    def smooth_step(x, key, i):
+        """layer i of a smooth block: CPU arch [dw3 -> pw -> BN -> ReLU] (model_v2.py:23-39); GPU arch
+        [conv3 -> BN -> SiLU] (model_v2.py:15-22)."""
+        if cpu_arch:
+            p = f"{key}.block."
+            return b.conv(x, f"{p}{4 * i + 1}", f"{p}{4 * i + 2}", 1e-5, "relu", F_,
+                          dw=dict(conv=f"{p}{4 * i}", act="none", k=3, s=1))
+        return b.conv(x, f"{key}.{3 * i}", f"{key}.{3 * i + 1}", 1e-5, "silu", F_, k=3)
+
     def smooth(x, key):
-        """smooth block: CPU arch d x [dw3 -> pw -> BN -> ReLU] (model_v2.py:23-39); GPU arch
-        d x [conv3 -> BN -> SiLU] (model_v2.py:15-22)."""
         for i in range(d):
-            if cpu_arch:
-                p = f"{key}.block."
-                x = b.conv(x, f"{p}{4 * i + 1}", f"{p}{4 * i + 2}", 1e-5, "relu", F_,
-                           dw=dict(conv=f"{p}{4 * i}", act="none", k=3, s=1))
-            else:
-                x = b.conv(x, f"{key}.{3 * i}", f"{key}.{3 * i + 1}", 1e-5, "silu", F_, k=3)
+            x = smooth_step(x, key, i)
         return x
 
-    # top-down pass, P5 first (model_v2.py:359-361)
+    # top-down pass, P5 first (model_v2.py:359-361): every level's lateral adds the SMOOTHED coarser level, so
+    # lateral / smooth form one dependent chain.  The heads below are emitted LEVEL-BATCHED (trunk layer t of
+    # every level side by side, then the output convs side by side): the executor launches such runs of
+    # independent, identically shaped layers as ONE kernel (YlConvMulti), so the 20x20 / 40x40 heads ride along
+    # with the 80x80 head.
     P = {}
     prev = None
     for n_ in reversed(pyr):
@@ -540,31 +546,36 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
         prog.proto_slot = b.conv(y, "proto.cv3.0", "proto.cv3.1", 1e-5, "silu", NM, k=1)
         prog.num_masks = NM
 
-    # heads (model_v2.py:42-53,340-350): trunk, then box/obj/cls 1x1 convs fused into ONE GEMM per anchor
-    for li, n_ in enumerate(levels):
-        k = n_[1]
-        x = P[n_]
-        A = amap[n_]
-        for t in range(head_depth):
-            p = f"head{k}.trunk.{t}.block."
-            x = b.conv(x, p + "1", p + "2", 1e-5, "relu", F_, dw=dict(conv=p + "0", act="none", k=3, s=1))
-        hs = b.dims(x)[0]
-        wbox, bbox_ = b.get(f"head{k}.out.box.weight", (4 * A, F_, 1, 1)), b.get(f"head{k}.out.box.bias", (4 * A,))
-        wobj, bobj = b.get(f"head{k}.out.obj.weight", (A, F_, 1, 1)), b.get(f"head{k}.out.obj.bias", (A,))
-        wcls, bcls = b.get(f"head{k}.out.cls.weight", (A * C, F_, 1, 1)), b.get(f"head{k}.out.cls.bias", (A * C,))
-        if seg:
-            wmc, bmc = b.get(f"head{k}.out.mc.weight", (A * NM, F_, 1, 1)), b.get(f"head{k}.out.mc.bias", (A * NM,))
-        for a in range(A):                                  # conv channels are anchor-major (view(B,A,4,S,S))
+    # heads (model_v2.py:42-53,340-350): trunk, then box/obj/cls 1x1 convs fused into ONE GEMM per anchor;
+    # level-batched emission (see above): trunk layer t of every level, then output conv a of every level
+    X = {n_: P[n_] for n_ in levels}
+    for t in range(head_depth):
+        for n_ in levels:
+            p = f"head{n_[1]}.trunk.{t}.block."
+            X[n_] = b.conv(X[n_], p + "1", p + "2", 1e-5, "relu", F_, dw=dict(conv=p + "0", act="none", k=3, s=1))
+    Amax = max(amap[n_] for n_ in levels)
+    for a in range(Amax):
+        for li, n_ in enumerate(levels):
+            k = n_[1]
+            A = amap[n_]
+            if a >= A:
+                continue
+            wbox, bbox_ = b.get(f"head{k}.out.box.weight", (4 * A, F_, 1, 1)), b.get(f"head{k}.out.box.bias", (4 * A,))
+            wobj, bobj = b.get(f"head{k}.out.obj.weight", (A, F_, 1, 1)), b.get(f"head{k}.out.obj.bias", (A,))
+            wcls, bcls = b.get(f"head{k}.out.cls.weight", (A * C, F_, 1, 1)), b.get(f"head{k}.out.cls.bias", (A * C,))
+            # conv channels are anchor-major (view(B,A,4,S,S))
             w = np.concatenate([wbox[4 * a:4 * a + 4], wobj[a:a + 1], wcls[C * a:C * (a + 1)]], 0)
             bb = np.concatenate([bbox_[4 * a:4 * a + 4], bobj[a:a + 1], bcls[C * a:C * (a + 1)]], 0)
             if seg:
+                wmc, bmc = b.get(f"head{k}.out.mc.weight", (A * NM, F_, 1, 1)), b.get(f"head{k}.out.mc.bias", (A * NM,))
                 w = np.concatenate([w, wmc[NM * a:NM * (a + 1)]], 0)
                 bb = np.concatenate([bb, bmc[NM * a:NM * (a + 1)]], 0)
-            b.conv(x, None, None, 0.0, "none", 5 + C + NM, head_level=li,
+            b.conv(X[n_], None, None, 0.0, "none", 5 + C + NM, head_level=li,
                    wb=(np.ascontiguousarray(w, np.float32), np.ascontiguousarray(bb, np.float32)),
                    name=f"head{k}.out[a={a}]")
-        prog.level_size.append(hs)
-        prog.level_anchors.append(A)
+    for n_ in levels:
+        prog.level_size.append(b.dims(X[n_])[0])
+        prog.level_anchors.append(amap[n_])
     reds = [r for (_, _, r) in feats]
     prog.strides = reds + ([reds[-1] * 2] if use_p6 else [])
     return prog
