@@ -80,3 +80,22 @@ def test_bank_capacity_overflow_is_reported():
     bank.update(torch.from_numpy(d).cuda(), torch.tensor([20], dtype=torch.int32).cuda())
     n, over = bank.stats()
     assert n[0] == 8 and over[0] == 12
+
+
+def test_c_abi_argument_errors():
+    """negative yl_status instead of crashes for bad arguments (tracker and evaluation entry points)."""
+    import ctypes as C
+    from yololite_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.yl_track_create(0, 0, 16, 0.3, 15, 2, 1, C.byref(h)) == -1            # no streams
+    assert lib.yl_track_create(0, 1, 100000, 0.3, 15, 2, 1, C.byref(h)) == -1       # capacity beyond the LDS plan
+    assert lib.yl_track_create(0, 2, 16, 0.3, 15, 2, 1, C.byref(h)) == 0
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    assert lib.yl_track_update(h, None, cnt.data_ptr(), 8, None, None, None, None, None, None) == -1   # NULL outputs
+    assert lib.yl_track_reset(h, 5, None) == -1                                       # stream index out of range
+    lib.yl_track_destroy(h)
+    assert lib.yl_eval_match(None, None, None, None, 0, 0, 0.5, None, None, None, None) == 0           # empty: nothing to do
+    assert lib.yl_eval_match(None, None, None, None, 3, 0, 0.5, None, None, None, None) == -1          # keys without offsets
+    assert lib.yl_eval_sweep(None, None, None, 0, None, 0, None, None, None) == -1
+    assert lib.yl_eval_confusion(None, None, None, None, None, None, 0, 0, 0, 0.5, None, None, None) == -1

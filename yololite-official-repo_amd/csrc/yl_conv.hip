@@ -349,8 +349,11 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
   const int bx = p.nblk ? (int)blockIdx.x - p.blk0 : (int)blockIdx.x;               \
   const int gx = p.nblk ? p.nblk : (int)gridDim.x;
 
+#ifndef YL_PW_WAVES
+#define YL_PW_WAVES 3
+#endif
 template <int NT, int MT, int MODE>
-__global__ __launch_bounds__(256, 3) void yl_conv_mfma_kernel(YlConvMulti mp) {
+__global__ __launch_bounds__(256, (NT * MT <= 6 && MODE <= 1) ? YL_PW_WAVES : 3) void yl_conv_mfma_kernel(YlConvMulti mp) {
   YL_SELECT_PROBLEM(mp)
   extern __shared__ __attribute__((aligned(16))) float yl_wlds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
