@@ -61,6 +61,9 @@ struct yl_ctx {
   int nms_gP = 0;
   // options
   int opt_graph = 0, opt_tile_m = 0, opt_streams = 2;
+  int opt_hybrid = 0;        // (off: measured -0.5 % at B=64) full-batch launches for the high-resolution layers, batch chunks on the internal streams only
+                             // for the run of low-resolution (<= 1/16) layers, see plan_segments()
+  int small_lo = 0, small_hi = 0;   // that run: layers [small_lo, small_hi)
   int opt_batch_levels = 1;  // runs of independent, identically shaped layers (FPN smooth / head trunk / head out of all
                              // levels) go out as ONE launch (YlConvMulti)
   int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
@@ -82,7 +85,7 @@ struct yl_ctx {
   // hipGraph cache: up to YL_GRAPH_SLOTS jobs (a serving loop alternates between a few input / output buffers,
   // e.g. the two slots of the pipelined all-gather), least recently used evicted
   struct GraphEntry {
-    hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};   // one graph per batch chunk
+    std::vector<hipGraphExec_t> execs;   // one graph per (segment, chunk) piece, in launch order
     int n = 0;
     std::vector<unsigned char> key;
     unsigned long long stamp = 0;
@@ -188,8 +191,8 @@ void free_post_ws(yl_ctx* c) {
 
 void drop_graph(yl_ctx* c) {
   for (auto& g : c->graphs)
-    for (int i = 0; i < 4; ++i)
-      if (g.exec[i]) hipGraphExecDestroy(g.exec[i]);
+    for (auto e : g.execs)
+      if (e) hipGraphExecDestroy(e);
   c->graphs.clear();
 }
 
@@ -308,7 +311,8 @@ bool can_fuse_decode(const yl_ctx* c) {
 
 yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* level_out, hipStream_t st,
                      hipEvent_t* evs /*nullable: num_layers+1 events*/, int chunk = 0,
-                     const yl_post_cfg* fuse = nullptr /*non-null: head outputs decode in their epilogue*/) {
+                     const yl_post_cfg* fuse = nullptr /*non-null: head outputs decode in their epilogue*/,
+                     int lo = 0, int hi = -1 /*layer range [lo, hi), -1 = to the end*/) {
   if (evs) HIPCHK(c, hipEventRecord(evs[0], st));
   // two lanes (see yl_ctx::lane): lane-1 layers go to the chunk's side stream; an event edge is inserted
   // wherever a layer reads a slot produced on the other lane, and the side stream is joined at the end.
@@ -347,12 +351,13 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
            e.res_slot < 0 && a.up_slot < 0 && e.up_slot < 0 && (a.head_level >= 0) == (e.head_level >= 0) &&
            (a.cout + 15) / 16 <= 8;
   };
-  for (size_t i = 0; i < c->layers.size();) {
+  const size_t lend = hi < 0 ? c->layers.size() : (size_t)hi;
+  for (size_t i = (size_t)lo; i < lend;) {
     const yl_layer& d = c->layers[i].d;
     // ---- level-batched run starting at i (not under per-layer timing, not with side lanes)
     size_t gend = i + 1;
     if (!evs && !lanes && c->opt_batch_levels && d.op == YL_OP_CONV) {
-      while (gend < c->layers.size() && gend - i < 4 && same_shape(i, gend)) {
+      while (gend < lend && gend - i < 4 && same_shape(i, gend)) {
         bool dep = false;
         for (size_t q = i; q < gend; ++q)
           if (c->layers[q].d.head_level < 0 && c->layers[q].d.out_slot == c->layers[gend].d.in_slot) dep = true;
@@ -416,6 +421,25 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
 // lane assignment from the slot graph: a layer goes to lane 1 iff everything it feeds ends in head outputs of
 // levels >= 1 only (the finest level's chain, the backbone, the top-down laterals and the prototype branch stay
 // on lane 0)
+// the longest run of consecutive layers whose input AND output grids are <= 1/16 of the image (the 40x40 / 20x20
+// stages of the backbone and the coarse part of the top-down pass): the part of the network that is chunked over
+// the internal streams by the hybrid plan
+void assign_small_run(yl_ctx* c) {
+  const int lim = c->img_size / 16;
+  int best_lo = 0, best_hi = 0, lo = -1;
+  const int n = (int)c->layers.size();
+  for (int i = 0; i <= n; ++i) {
+    const bool small = i < n && c->layers[i].d.op == YL_OP_CONV && c->layers[i].in_h <= lim && c->layers[i].out_h <= lim &&
+                       c->layers[i].d.head_level < 0;
+    if (small && lo < 0) lo = i;
+    if (!small && lo >= 0) {
+      if (i - lo > best_hi - best_lo) { best_lo = lo; best_hi = i; }
+      lo = -1;
+    }
+  }
+  c->small_lo = best_lo; c->small_hi = best_hi;
+}
+
 void assign_lanes(yl_ctx* c) {
   const size_t n = c->layers.size();
   c->lane.assign(n, 0);
@@ -492,94 +516,135 @@ struct Job {
   int* keep_idx = nullptr;
 };
 
-yl_status run_chunk(yl_ctx* c, const Job& j, int b0, int bn, hipStream_t st, int chunk) {
+// A job runs as a sequence of SEGMENTS: layer range [lo, hi), either as one full-batch piece on the caller's
+// stream or as one piece per batch chunk on the internal streams (fork/join); the last segment carries the
+// post-processing.  Plans:
+//   plain    [0, L) chunked, post per chunk                      (1 segment; n == 1: a single piece)
+//   hybrid   [0, lo) full | [lo, hi) chunked | [hi, L) full + post
+// hybrid: the high-resolution layers (stem block, 160^2 / 80^2 stages, the 80^2 neck / heads) fill the machine on
+// their own -- their grids are persistent and occupancy-sized, so a half-batch launch of another chunk cannot
+// overlap them, it only queues behind them -- while the run of <= 1/16-resolution layers is latency-bound with a
+// few hundred tiles: those runs of the two chunks interleave on two streams.
+struct Seg { int lo, hi; bool chunked, post; };
+
+int plan_segments(const yl_ctx* c, const Job& j, int n, Seg* segs) {
+  const int L = (int)c->layers.size();
+  if (!j.x) { segs[0] = {0, 0, n > 1, true}; return 1; }
+  if (n > 1 && c->opt_hybrid && !c->opt_lanes && c->small_hi - c->small_lo >= 6) {
+    int k = 0;
+    if (c->small_lo > 0) segs[k++] = {0, c->small_lo, false, false};
+    segs[k++] = {c->small_lo, c->small_hi, true, false};
+    segs[k++] = {c->small_hi, L, false, j.cfg != nullptr};
+    return k;
+  }
+  segs[0] = {0, L, n > 1, j.cfg != nullptr};
+  return 1;
+}
+
+// one piece: layers [lo, hi) of images [b0, b0 + bn), then (last segment) post-processing of those images
+yl_status run_piece(yl_ctx* c, const Job& j, const Seg& sg, int b0, int bn, hipStream_t st, int chunk) {
   yl_status s = YL_OK;
   const bool fused = j.x && j.cfg && can_fuse_decode(c);
-  if (j.x) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr, chunk, fused ? j.cfg : nullptr);
-  if (s == YL_OK && j.cfg) s = do_post(c, j.outs, b0, bn, j.cfg, j.dets, j.counts, j.keep_idx, st, fused);
+  if (j.x && sg.hi > sg.lo) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr, chunk, fused ? j.cfg : nullptr, sg.lo, sg.hi);
+  if (s == YL_OK && sg.post && j.cfg) s = do_post(c, j.outs, b0, bn, j.cfg, j.dets, j.counts, j.keep_idx, st, fused);
   return s;
 }
 
-// enqueue a job on `st`, split into chunks over the internal worker streams (fork/join with events; the
-// same call sequence is legal inside a stream capture, where it becomes parallel graph branches)
-yl_status enqueue(yl_ctx* c, const Job& j, hipStream_t st) {
+yl_status ensure_streams(yl_ctx* c) {
+  for (int i = 0; i < 4; ++i) {
+    if (i > 0 && !c->work[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));
+    if (i > 0 && !c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    if (!c->side[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+    if (!c->ev_la[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_la[i], hipEventDisableTiming));
+    if (!c->ev_lb[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lb[i], hipEventDisableTiming));
+  }
+  if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  return YL_OK;
+}
+
+// Walk the plan.  `piece(seg, chunk, b0, bn, stream)` either enqueues the piece's kernels (eager) or launches its
+// captured graph; chunked segments are forked over the internal streams and joined back on `st`.
+template <typename F>
+yl_status walk_plan(yl_ctx* c, const Job& j, hipStream_t st, int n, const Seg* segs, int nseg, F&& piece) {
+  const int base = j.B / n, rem = j.B % n;
+  for (int g = 0; g < nseg; ++g) {
+    if (!segs[g].chunked || n == 1) {
+      yl_status s = piece(g, 0, 0, j.B, st);
+      if (s != YL_OK) return s;
+      continue;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_fork, st));
+    int b0 = 0;
+    for (int i = 0; i < n; ++i) {
+      const int bn = base + (i < rem ? 1 : 0);
+      hipStream_t ws = (i == 0) ? st : c->work[i];
+      if (i > 0) HIPCHK(c, hipStreamWaitEvent(ws, c->ev_fork, 0));
+      yl_status s = piece(g, i, b0, bn, ws);
+      if (s != YL_OK) return s;
+      if (i > 0) {
+        HIPCHK(c, hipEventRecord(c->ev_join[i], ws));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
+      }
+      b0 += bn;
+    }
+  }
+  return YL_OK;
+}
+
+// run a job eagerly, or by replaying cached hipGraphs of exactly this job (one graph per piece: capturing several
+// chunks plus side lanes into ONE graph -- 4 streams -- crashed hipGraphInstantiate on ROCm 7.2)
+yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = true) {
   int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
   if (j.B < 4 * n) n = 1;
-  if (n == 1) return run_chunk(c, j, 0, j.B, st, 0);
-  if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  for (int i = 1; i < n; ++i) {
-    if (!c->work[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));
-    if (!c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-  }
-  HIPCHK(c, hipEventRecord(c->ev_fork, st));
-  yl_status s = YL_OK;
-  const int base = j.B / n, rem = j.B % n;
-  int b0 = 0;
-  for (int i = 0; i < n; ++i) {
-    const int bn = base + (i < rem ? 1 : 0);
-    hipStream_t ws = (i == 0) ? st : c->work[i];
-    if (i > 0) HIPCHK(c, hipStreamWaitEvent(ws, c->ev_fork, 0));
-    if (s == YL_OK) s = run_chunk(c, j, b0, bn, ws, i);
-    if (i > 0) {
-      HIPCHK(c, hipEventRecord(c->ev_join[i], ws));
-      HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
-    }
-    b0 += bn;
-  }
-  return s;
-}
-
-// run a job eagerly or by replaying a cached hipGraph of exactly this job
-yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
-  if (!c->opt_graph) return enqueue(c, j, st);
+  Seg segs[3];
+  const int nseg = plan_segments(c, j, n, segs);
+  yl_status s = ensure_streams(c);
+  if (s != YL_OK) return s;
+  if (!c->opt_graph || !allow_graph)
+    return walk_plan(c, j, st, n, segs, nseg, [&](int g, int i, int b0, int bn, hipStream_t ws) -> yl_status {
+      return run_piece(c, j, segs[g], b0, bn, ws, i);
+    });
   std::vector<unsigned char> key(sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), 0);
   memcpy(key.data(), &j, sizeof(Job));
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
-  const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10) | (c->opt_batch_levels << 11);
+  const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10) |
+                     (c->opt_batch_levels << 11) | (c->opt_hybrid << 12);
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
   memset(key.data() + offsetof(Job, cfg), 0, sizeof(void*));
-  // chunk plan (same split as enqueue).  Every chunk is captured into its OWN graph (main + side lane = two
-  // captured streams each) and the chunk graphs are launched on the chunk streams with an eager fork/join:
-  // capturing all chunks and their side lanes into one graph (4 streams) crashes hipGraphInstantiate on ROCm 7.2.
-  int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
-  if (j.B < 4 * n) n = 1;
-  const int base = j.B / n, rem = j.B % n;
   yl_ctx::GraphEntry* ge = nullptr;
   for (auto& g : c->graphs)
     if (g.key == key) { ge = &g; break; }
   if (!ge) {
-    // every internal stream / event the captures and the launch will touch exists BEFORE capturing
-    for (int i = 0; i < 4; ++i) {
-      if (i > 0 && !c->work[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));
-      if (i > 0 && !c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-      if (!c->side[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-      if (!c->ev_la[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_la[i], hipEventDisableTiming));
-      if (!c->ev_lb[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lb[i], hipEventDisableTiming));
-    }
-    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     yl_ctx::GraphEntry fresh;
     hipStream_t cs;
     HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    yl_status s = YL_OK;
     hipError_t e = hipSuccess;
-    int b0 = 0;
-    for (int i = 0; i < n && s == YL_OK && e == hipSuccess; ++i) {
-      const int bn = base + (i < rem ? 1 : 0);
-      hipGraph_t g = nullptr;
-      e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-      if (e != hipSuccess) break;
-      s = run_chunk(c, j, b0, bn, cs, i);
-      e = hipStreamEndCapture(cs, &g);
-      if (s == YL_OK && e == hipSuccess) e = hipGraphInstantiate(&fresh.exec[i], g, nullptr, nullptr, 0);
-      if (g) hipGraphDestroy(g);
-      b0 += bn;
+    // capture every piece in plan order (walk_plan's fork/join calls are NOT issued here: pieces are independent
+    // captures on the scratch stream)
+    const int base = j.B / n, rem = j.B % n;
+    for (int g = 0; g < nseg && s == YL_OK && e == hipSuccess; ++g) {
+      const int pieces = (segs[g].chunked && n > 1) ? n : 1;
+      int b0 = 0;
+      for (int i = 0; i < pieces && s == YL_OK && e == hipSuccess; ++i) {
+        const int bn = pieces == 1 ? j.B : base + (i < rem ? 1 : 0);
+        hipGraph_t gr = nullptr;
+        hipGraphExec_t ex = nullptr;
+        e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) break;
+        s = run_piece(c, j, segs[g], b0, bn, cs, i);
+        e = hipStreamEndCapture(cs, &gr);
+        if (s == YL_OK && e == hipSuccess) e = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+        if (gr) hipGraphDestroy(gr);
+        fresh.execs.push_back(ex);
+        b0 += bn;
+      }
     }
     hipStreamDestroy(cs);
     if (s != YL_OK || e != hipSuccess) {
-      for (int i = 0; i < 4; ++i)
-        if (fresh.exec[i]) hipGraphExecDestroy(fresh.exec[i]);
+      for (auto ex : fresh.execs)
+        if (ex) hipGraphExecDestroy(ex);
       if (s != YL_OK) return s;
       HIPCHK(c, e);
     }
@@ -589,27 +654,21 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st) {
       size_t v = 0;
       for (size_t i = 1; i < c->graphs.size(); ++i)
         if (c->graphs[i].stamp < c->graphs[v].stamp) v = i;
-      for (int i = 0; i < 4; ++i)
-        if (c->graphs[v].exec[i]) hipGraphExecDestroy(c->graphs[v].exec[i]);
+      for (auto ex : c->graphs[v].execs)
+        if (ex) hipGraphExecDestroy(ex);
       c->graphs.erase(c->graphs.begin() + v);
     }
     c->graphs.push_back(fresh);
     ge = &c->graphs.back();
   }
   ge->stamp = ++c->graph_clock;
-  if (ge->n == 1) {
-    HIPCHK(c, hipGraphLaunch(ge->exec[0], st));
+  size_t at = 0;
+  std::vector<size_t> first(nseg);
+  for (int g = 0; g < nseg; ++g) { first[g] = at; at += (segs[g].chunked && n > 1) ? n : 1; }
+  return walk_plan(c, j, st, n, segs, nseg, [&](int g, int i, int, int, hipStream_t ws) -> yl_status {
+    HIPCHK(c, hipGraphLaunch(ge->execs[first[g] + i], ws));
     return YL_OK;
-  }
-  HIPCHK(c, hipEventRecord(c->ev_fork, st));
-  for (int i = 1; i < ge->n; ++i) {
-    HIPCHK(c, hipStreamWaitEvent(c->work[i], c->ev_fork, 0));
-    HIPCHK(c, hipGraphLaunch(ge->exec[i], c->work[i]));
-    HIPCHK(c, hipEventRecord(c->ev_join[i], c->work[i]));
-  }
-  HIPCHK(c, hipGraphLaunch(ge->exec[0], st));
-  for (int i = 1; i < ge->n; ++i) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
-  return YL_OK;
+  });
 }
 
 }  // namespace
@@ -853,6 +912,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       return fail(c, YL_ERR_INVALID, "num_masks > 0 needs proto_slot with num_masks channels");
   }
   assign_lanes(c);
+  assign_small_run(c);
   return YL_OK;
 }
 
@@ -860,6 +920,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "hybrid")) { c->opt_hybrid = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "batch_levels")) { c->opt_batch_levels = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "fuse_decode")) { c->opt_fuse_decode = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "lanes")) { c->opt_lanes = value ? 1 : 0; drop_graph(c); return YL_OK; }
@@ -945,7 +1006,7 @@ yl_status yl_postprocess(yl_ctx* c, const float* const* levels, int32_t B, const
   Job j;
   j.B = B; j.cfg = cfg; j.dets = dets; j.counts = counts; j.keep_idx = keep_idx;
   for (int l = 0; l < c->L; ++l) j.outs[l] = const_cast<float*>(levels[l]);
-  return enqueue(c, j, (hipStream_t)stream);
+  return submit(c, j, (hipStream_t)stream, false);
 }
 
 yl_status yl_predict(yl_ctx* c, const float* x, int32_t B, const yl_post_cfg* cfg, float* dets, int32_t* counts,

@@ -17,6 +17,7 @@ nearest-upsample-add / activation epilogues, one GEMM for the three head output 
 from __future__ import annotations
 
 import math
+import zlib
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -134,13 +135,14 @@ class SynthStateDict(dict):
 
     def __init__(self, seed: int = 0, num_classes: int = 80, head_noise: float = 0.5):
         super().__init__()
-        self.rng = np.random.RandomState(seed)
+        self.seed = int(seed)
         self.C, self.head_noise = num_classes, head_noise
 
     def make(self, key: str, shape):
         if key in self:
             return
-        r = self.rng
+        # one generator per key: the values do not depend on the order in which the builder asks for them
+        r = np.random.RandomState((zlib.crc32(key.encode()) ^ (self.seed * 2654435761)) & 0x7FFFFFFF)
         if ".out." in key:
             if key.endswith(".weight"):
                 v = r.randn(*shape) * (math.sqrt(1.0 / shape[1]) * (1.0 + self.head_noise))
