@@ -124,7 +124,7 @@ def test_bf16_mfma_mode(name, B, S):
     tensors).  Not the parity path: the bound is 3e-2 of the level's largest logit (bf16 has 8 mantissa
     bits; ~60 layers) and the detections of the fp32 run are reproduced to within a few percent."""
     meta = zoo_meta(name, 80, S)
-    sd = synth_state_dict(meta, seed=0, head_noise=2.0)
+    sd = synth_state_dict(meta, seed={"edge_n": 2, "yololite_m": 10}[name], head_noise=2.0)
     x = _x(B, S)
     with torch.no_grad():
         ref = _oracle_for(meta, sd)(x)
@@ -140,11 +140,12 @@ def test_bf16_mfma_mode(name, B, S):
         assert err <= 3e-2 * r.abs().max().item() + 1e-3, (name, err, r.abs().max().item())
         differs |= not torch.equal(o, q)
     assert differs                                              # the mode really switched kernels
-    d16, c16 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
+    d16, c16 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.1, 0.5, per_class_cap=300, max_out=300)
     c16 = c16.cpu().numpy().copy()
     ctx.set_option("mfma_bf16", 0)
-    d32, c32 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
+    d32, c32 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.1, 0.5, per_class_cap=300, max_out=300)
     c32 = c32.cpu().numpy()
+    assert c32.sum() > 50
     assert np.all(np.abs(c16 - c32) <= 0.1 * np.maximum(c32, 10))
     for o, q in zip(m(x.to(DEV)), f32):                         # and back: bitwise the fp32 path again
         assert torch.equal(o, q)
@@ -154,13 +155,14 @@ def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
     """side-stream lane for the coarse-level neck/head layers + one hipGraph per batch chunk: same bits as the
     single-stream eager path (scheduling must not change results)."""
     meta = zoo_meta("edge_n", 80, 320)
-    sd = synth_state_dict(meta, seed=0, head_noise=2.0)
+    sd = synth_state_dict(meta, seed=2, head_noise=2.0)
     m = _hip_for(meta, sd)
     ctx = m._ctx_for(320)
     x = _x(16, 320).to(DEV)
     ctx.set_option("graph", 0); ctx.set_option("streams", 1); ctx.set_option("lanes", 0)
     d0, c0 = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
     d0, c0 = d0.clone(), c0.clone()
+    assert int(c0.sum()) > 100                      # the comparison below must not be about empty results
     ctx.set_option("batch_levels", 0)
     d0b, c0b = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
     assert torch.equal(c0b, c0)
