@@ -9,7 +9,7 @@ the packed detections per step).
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the whole hot path over one batch that is already resident in HBM:
-yl_predict (42 fused conv launches + decode + NMS) [+ all-gather].  Synthetic data, seeded
+yl_predict (36 fused conv launches per batch chunk, decode inside the head-output convs, NMS) [+ all-gather].  Synthetic data, seeded
 synthetic weights (no checkpoints exist in this environment).  Prints ONE JSON line on rank 0.
 """
 import argparse
