@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--seed", type=int, default=-1, help="synthetic weight seed (-1: per-model default chosen so that the "
                     "model DOES detect at conf 0.4 -- most seeds give no detections at all: edge_n 2 (~2000 survivors in 10 "
                     "classes, ~1250 detections / image), edge_m 9 (~665), yololite_m 10 (~210))")
+    ap.add_argument("--nms-groups", type=int, default=4, help="NMS workgroups per image (classes split mod G)")
     ap.add_argument("--hybrid", type=int, default=0, help="full-batch launches for the high-resolution layers, chunks only for the low-resolution run")
     ap.add_argument("--batch-levels", type=int, default=1, help="smooth / head layers of all pyramid levels as one launch")
     ap.add_argument("--fuse-decode", type=int, default=1, help="decode inside the head-output conv epilogue")
@@ -255,6 +256,7 @@ def main():
     ctx.set_option("fuse_decode", args.fuse_decode)
     ctx.set_option("batch_levels", args.batch_levels)
     ctx.set_option("hybrid", args.hybrid)
+    ctx.set_option("nms_groups", args.nms_groups)
     x = synth_images(B, S, seed=1234 + rank).to(dev)
     max_out = 300                                        # packed result rows per image
     gat = None

@@ -36,6 +36,7 @@ struct Slot {
 }  // namespace
 
 #define YL_GRAPH_SLOTS 4
+#define YL_NMS_GROUPS 4
 struct yl_ctx {
   int device = 0;
   int img_size = 0, in_ch = 3, C = 0, L = 0, N = 0, E = 0, NM = 0, proto_slot = -1;
@@ -50,6 +51,8 @@ struct yl_ctx {
   float* ws_scores = nullptr;
   int* ws_cls = nullptr;
   int* ws_clsws = nullptr;
+  int* ws_kept_list = nullptr;               // [B][YL_NMS_GROUPS][N] class-group split of the NMS kernel
+  int* ws_done = nullptr;                    // [B] arrival counters (zero between launches)
   unsigned long long* ws_gkeys = nullptr;
   int gP = 0;
   float* ws_tmp_dets = nullptr;
@@ -61,6 +64,7 @@ struct yl_ctx {
   int nms_gP = 0;
   // options
   int opt_graph = 0, opt_tile_m = 0, opt_streams = 2;
+  int opt_nms_groups = YL_NMS_GROUPS;   // workgroups per image in the NMS kernel (1 = single)
   int opt_hybrid = 0;        // (off: measured -0.5 % at B=64) full-batch launches for the high-resolution layers, batch chunks on the internal streams only
                              // for the run of low-resolution (<= 1/16) layers, see plan_segments()
   int small_lo = 0, small_hi = 0;   // that run: layers [small_lo, small_hi)
@@ -183,6 +187,8 @@ void pack_stem_rows(const float* w, int cout, std::vector<float>& out) {
 
 void free_post_ws(yl_ctx* c) {
   hipFree(c->ws_boxes); hipFree(c->ws_scores); hipFree(c->ws_cls); hipFree(c->ws_clsws);
+  hipFree(c->ws_kept_list); hipFree(c->ws_done);
+  c->ws_kept_list = nullptr; c->ws_done = nullptr;
   hipFree(c->ws_gkeys); hipFree(c->ws_tmp_dets); hipFree(c->ws_tmp_idx);
   c->ws_boxes = nullptr; c->ws_scores = nullptr; c->ws_cls = nullptr; c->ws_clsws = nullptr;
   c->ws_gkeys = nullptr; c->ws_tmp_dets = nullptr; c->ws_tmp_idx = nullptr;
@@ -230,6 +236,9 @@ yl_status ensure_post(yl_ctx* c, int B) {
   if (c->gP > YL_LDS_KEYS_MAX) HIPCHK(c, hipMalloc((void**)&c->ws_gkeys, (size_t)B * c->gP * 8));
   HIPCHK(c, hipMalloc((void**)&c->ws_tmp_dets, n * 6 * sizeof(float)));
   HIPCHK(c, hipMalloc((void**)&c->ws_tmp_idx, n * sizeof(int)));
+  HIPCHK(c, hipMalloc((void**)&c->ws_kept_list, n * YL_NMS_GROUPS * sizeof(int)));
+  HIPCHK(c, hipMalloc((void**)&c->ws_done, (size_t)B * sizeof(int)));
+  HIPCHK(c, hipMemset(c->ws_done, 0, (size_t)B * sizeof(int)));
   c->post_cap_batch = B;
   return YL_OK;
 }
@@ -502,6 +511,11 @@ yl_status do_post(yl_ctx* c, const float* const* levels_all, int b0, int B, cons
   np.keep_idx = keep_idx ? keep_idx + (size_t)b0 * cfg->max_out : nullptr;
   np.backmap = cfg->backmap_dev ? cfg->backmap_dev + (size_t)b0 * 5 : nullptr;
   np.tmp_dets = c->ws_tmp_dets + o * 6; np.tmp_idx = c->ws_tmp_idx + o;
+  // several workgroups per image (classes split mod G) unless the fallback's global top-k needs the whole kept
+  // set in one workgroup, or survivors could exceed the LDS key capacity
+  np.G = (c->opt_nms_groups > 1 && np.topk == 0 && c->C > 1 && c->N <= YL_LDS_KEYS_MAX) ? c->opt_nms_groups : 1;
+  np.kept_list = c->ws_kept_list + o * YL_NMS_GROUPS;
+  np.done = c->ws_done + b0;
   HIPCHK(c, yl_launch_nms(np, B, st));
   return YL_OK;
 }
@@ -608,7 +622,7 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = tru
   memcpy(key.data(), &j, sizeof(Job));
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
   const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10) |
-                     (c->opt_batch_levels << 11) | (c->opt_hybrid << 12);
+                     (c->opt_batch_levels << 11) | (c->opt_hybrid << 12) | (c->opt_nms_groups << 13);
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
@@ -920,6 +934,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "nms_groups")) { c->opt_nms_groups = value < 1 ? 1 : (value > YL_NMS_GROUPS ? YL_NMS_GROUPS : value); drop_graph(c); return YL_OK; }
   if (!strcmp(name, "hybrid")) { c->opt_hybrid = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "batch_levels")) { c->opt_batch_levels = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "fuse_decode")) { c->opt_fuse_decode = value ? 1 : 0; drop_graph(c); return YL_OK; }

@@ -556,14 +556,16 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   int* ws_kept = ws_end + C;
   int* ws_off = ws_kept + C;
   u32* k32 = (u32*)keys;
+  const int G = p.G > 1 ? p.G : 1, g = G > 1 ? (int)blockIdx.y : 0;     // my class group: c % G == g
 
   YL_STAMP(1);
   if (tid == 0) s_misc[1] = 0;
-  for (int c = tid; c < C; c += blockDim.x) { ws_start[c] = -1; ws_end[c] = 0; ws_kept[c] = 0; ws_off[c] = 0; }
+  for (int c = tid; c < C; c += blockDim.x)
+    if (G == 1 || c % G == g) { ws_start[c] = -1; ws_end[c] = 0; ws_kept[c] = 0; ws_off[c] = 0; }
   __syncthreads();
   for (int n = tid; n < N; n += blockDim.x) {
     const float sc = scores[n];
-    if (sc > p.conf_thr) {
+    if (sc > p.conf_thr && (G == 1 || cls[n] % G == g)) {
       const int slot = atomicAdd(&s_misc[1], 1);
       const u64 c = cls ? (u64)cls[n] : 0ull;
       keys[slot] = (c << 52) | ((u64)yl_desc_bits(sc) << 20) | (u64)n;
@@ -606,6 +608,7 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   if (tid < 130) reinterpret_cast<u64*>(s_misc + 256)[tid] = 0ull;   // OR scratch of the cooperative pass
   __syncthreads();
   for (int c = wave; c < C; c += nwaves) {
+    if (G > 1 && c % G != g) continue;
     const int s = ws_start[c];
     if (s < 0) continue;
     const int e = ws_end[c];
@@ -633,6 +636,61 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   }
   __syncthreads();
   YL_STAMP(5);
+
+  if (G > 1) {
+    // ---- class-group split: publish my classes' kept candidates, then the LAST group of the image merges
+    int* klist = p.kept_list + ((size_t)b * G + g) * N;
+    for (int c = wave; c < C; c += nwaves) {
+      if (c % G != g) continue;
+      const int s = ws_start[c];
+      if (s < 0) continue;
+      const int nk = ws_kept[c];
+      for (int k = lane; k < nk; k += 64) klist[s + k] = (int)k32[2 * k32[2 * (s + k) + 1]];
+    }
+    __threadfence();                                          // my lists and per-class counters: visible device-wide
+    __syncthreads();
+    if (tid == 0) s_misc[3] = __hip_atomic_fetch_add(&p.done[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_misc[3] != G - 1) return;
+    __threadfence();
+    if (tid == 0) p.done[b] = 0;                              // ready for the next launch
+    // exclusive scan of the kept counts over ALL classes (wave 0), as in the single-group path
+    if (wave == 0) {
+      int running = 0;
+      for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        const int v = (c < C) ? __hip_atomic_load(&ws_kept[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d);
+          if (lane >= d) incl += t;
+        }
+        if (c < C) ws_off[c] = running + incl - v;
+        running += __shfl(incl, 63);
+      }
+      if (lane == 0) s_misc[2] = running;
+    }
+    __syncthreads();
+    const int total = s_misc[2];
+    float* dst = p.dets + (size_t)b * p.max_out * 6;
+    int* dst_idx = p.keep_idx ? p.keep_idx + (size_t)b * p.max_out : nullptr;
+    for (int c = wave; c < C; c += nwaves) {
+      const int nk = __hip_atomic_load(&ws_kept[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nk <= 0) continue;
+      const int s = __hip_atomic_load(&ws_start[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int off = ws_off[c];
+      const int* src = p.kept_list + ((size_t)b * G + (c % G)) * N + s;
+      for (int k = lane; k < nk; k += 64) {
+        const int orow = off + k;
+        if (orow >= p.max_out) continue;
+        const int idx = __hip_atomic_load(&src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        yl_write_det(p, b, dst, dst_idx, orow, boxes[idx], scores[idx], c, idx, true);
+      }
+    }
+    if (tid == 0) p.counts[b] = total;
+    return;
+  }
 
   // -- output offsets: exclusive scan of the kept counts over classes (wave 0)
   if (wave == 0) {
@@ -706,13 +764,16 @@ __global__ __launch_bounds__(1024) void yl_nms_kernel(YlNmsP p) {
   YL_STAMP(0);
   if (tid == 0) s_misc[0] = 0;
   __syncthreads();
+  const int G = p.G > 1 ? p.G : 1, g = G > 1 ? (int)blockIdx.y : 0;
+  const int* clsb = p.cls ? p.cls + (size_t)b * p.N : nullptr;
   int local = 0;
-  for (int n = tid; n < p.N; n += blockDim.x) local += (scores[n] > p.conf_thr) ? 1 : 0;
+  for (int n = tid; n < p.N; n += blockDim.x)
+    local += (scores[n] > p.conf_thr && (G == 1 || clsb[n] % G == g)) ? 1 : 0;
   for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
   if ((tid & 63) == 0 && local) atomicAdd(&s_misc[0], local);
   __syncthreads();
   const int nsurv = s_misc[0];
-  if (nsurv == 0) {
+  if (nsurv == 0 && G == 1) {
     if (tid == 0) p.counts[b] = 0;
     return;
   }
@@ -807,6 +868,6 @@ hipError_t yl_launch_decode_only(const YlLevels& lv, int B, int center_mode, int
 hipError_t yl_launch_nms(const YlNmsP& p, int B, hipStream_t st) {
   const size_t lds = (size_t)p.lds_cap * 8 + YL_NMS_SCRATCH;
   if ((int)lds > g_nms_lds_max && lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(yl_nms_kernel, dim3(B), dim3(1024), lds, st, p);
+  hipLaunchKernelGGL(yl_nms_kernel, dim3(B, p.G > 1 ? p.G : 1), dim3(1024), lds, st, p);
   return hipGetLastError();
 }
