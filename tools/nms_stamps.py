@@ -10,13 +10,13 @@ from yololite_amd.program import synth_state_dict, zoo_meta
 from bench import synth_images
 lib = _lib.load()
 meta = zoo_meta("edge_n", 80, 640)
-m = ya.build_model_from_meta(meta); m.load_state_dict(synth_state_dict(meta, seed=int(os.environ.get('YL_SEED', '4')), head_noise=2.0)); m.to("cuda:0")
+m = ya.build_model_from_meta(meta); m.load_state_dict(synth_state_dict(meta, seed=int(os.environ.get('YL_SEED', '2')), head_noise=2.0)); m.to("cuda:0")
 ctx = m._ctx_for(640)
 x = synth_images(64, 640).cuda()
 for _ in range(1):
     ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 64)()
 lib.yl_debug_nms_stamps.argtypes = [C.c_void_p]
 assert lib.yl_debug_nms_stamps(buf) == 0
 t = np.array(buf[:7], dtype=np.float64)
@@ -25,6 +25,10 @@ print("survivors", buf[7], "kept", buf[8])
 for i, n in enumerate(names):
     print(f"{n:14s} {(t[i + 1] - t[i]) / 100.0:8.2f} us")
 print(f"{'total':14s} {(t[6] - t[0]) / 100.0:8.2f} us")
+for gy in range(4):
+    q = np.array(buf[16 * gy:16 * gy + 16], dtype=np.float64)
+    if q[0] == 0: continue
+    print(f"group {gy}: survivors {int(q[7])}  hist+assign {(q[1]-q[0])/100:.1f}  compact {(q[2]-q[1])/100:.1f}  sort {(q[3]-q[2])/100:.1f}  prep {(q[4]-q[3])/100:.1f}  segments {(q[5]-q[4])/100:.1f}  publish {(q[6]-q[5])/100:.1f}  merge {max(q[9]-q[6],0)/100:.1f}  | total {(max(q[6],q[9])-q[0])/100:.1f} us")
 tb = (C.c_ulonglong * 128)()
 if hasattr(lib, "yl_debug_nms_tstamps"):
     lib.yl_debug_nms_tstamps.argtypes = [C.c_void_p]

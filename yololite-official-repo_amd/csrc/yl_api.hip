@@ -513,7 +513,7 @@ yl_status do_post(yl_ctx* c, const float* const* levels_all, int b0, int B, cons
   np.tmp_dets = c->ws_tmp_dets + o * 6; np.tmp_idx = c->ws_tmp_idx + o;
   // several workgroups per image (classes split mod G) unless the fallback's global top-k needs the whole kept
   // set in one workgroup, or survivors could exceed the LDS key capacity
-  np.G = (c->opt_nms_groups > 1 && np.topk == 0 && c->C > 1 && c->N <= YL_LDS_KEYS_MAX) ? c->opt_nms_groups : 1;
+  np.G = (c->opt_nms_groups > 1 && np.topk == 0 && c->C > 1 && c->C <= 256 && c->N <= YL_LDS_KEYS_MAX) ? c->opt_nms_groups : 1;
   np.kept_list = c->ws_kept_list + o * YL_NMS_GROUPS;
   np.done = c->ws_done + b0;
   HIPCHK(c, yl_launch_nms(np, B, st));

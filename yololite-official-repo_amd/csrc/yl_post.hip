@@ -218,12 +218,12 @@ __device__ __forceinline__ float4 yl_shfl4(const float4& v, int src) {
 #ifdef YL_NMS_STAMP
 // profiling aid (variant builds only, tools/build_variant.sh ... -DYL_NMS_STAMP): wall-clock ticks (100 MHz) at the
 // phase boundaries of block 0
-__device__ unsigned long long yl_nms_stamps[16];
+__device__ unsigned long long yl_nms_stamps[64];     // [workgroup of image 0 (blockIdx.y)][16]
 __device__ unsigned long long yl_nms_tstamps[128];
 __device__ int yl_nms_tcount;
-#define YL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) yl_nms_stamps[i] = wall_clock64(); } while (0)
+#define YL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) yl_nms_stamps[(blockIdx.y & 3) * 16 + (i)] = wall_clock64(); } while (0)
 extern "C" int yl_debug_nms_stamps(unsigned long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_nms_stamps), sizeof(unsigned long long) * 16);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_nms_stamps), sizeof(unsigned long long) * 64);
 }
 extern "C" int yl_debug_nms_tstamps(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_nms_tstamps), sizeof(unsigned long long) * 128);
@@ -291,8 +291,9 @@ __device__ __forceinline__ bool yl_tile_resolve(const float4& bj, float aj, bool
 #define YL_NMS_BIG 64
 #endif
 #define YL_NMS_BIGQ 200
-#define YL_NMS_SCRATCH 2304          // bytes of LDS behind the keys: ints [0..3] counters, [8..209] big-class queue,
-                                     // byte 1024..2063: 2 x 65 u64 OR scratch of the cooperative pass
+#define YL_NMS_SCRATCH 2560          // bytes of LDS behind the keys: ints [0..3] counters, [8..209] big-class queue,
+                                     // byte 1024..2063: 2 x 65 u64 OR scratch of the cooperative pass,
+                                     // byte 2304..2559: class -> workgroup owner table (class-group split, C <= 256)
 
 // Bitonic sort of P = KPT * 1024 keys held in LDS by a 1024-thread workgroup, KPT keys per thread in
 // REGISTERS (thread t owns positions KPT*t .. KPT*t+KPT-1).  Of the log2(P)*(log2(P)+1)/2 compare-exchange
@@ -545,7 +546,7 @@ __device__ __forceinline__ void yl_write_det(const YlNmsP& p, int b, float* dst,
 // fallback so that each gets address-space-specific code after inlining.
 template <bool LDS_KEYS, bool SBOX>
 __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, int nsurv, int b, int* s_misc,
-                                           float4* sbox) {
+                                           float4* sbox, const unsigned char* owner /*LDS [C], nullptr if G == 1*/) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int N = p.N, C = p.C;
   const float4* boxes = p.boxes + (size_t)b * N;
@@ -556,16 +557,16 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   int* ws_kept = ws_end + C;
   int* ws_off = ws_kept + C;
   u32* k32 = (u32*)keys;
-  const int G = p.G > 1 ? p.G : 1, g = G > 1 ? (int)blockIdx.y : 0;     // my class group: c % G == g
+  const int G = p.G > 1 ? p.G : 1, g = G > 1 ? (int)blockIdx.y : 0;     // my class group: owner[c] == g
 
   YL_STAMP(1);
   if (tid == 0) s_misc[1] = 0;
   for (int c = tid; c < C; c += blockDim.x)
-    if (G == 1 || c % G == g) { ws_start[c] = -1; ws_end[c] = 0; ws_kept[c] = 0; ws_off[c] = 0; }
+    if (G == 1 || owner[c] == g) { ws_start[c] = -1; ws_end[c] = 0; ws_kept[c] = 0; ws_off[c] = 0; }
   __syncthreads();
   for (int n = tid; n < N; n += blockDim.x) {
     const float sc = scores[n];
-    if (sc > p.conf_thr && (G == 1 || cls[n] % G == g)) {
+    if (sc > p.conf_thr && (G == 1 || owner[cls[n]] == g)) {
       const int slot = atomicAdd(&s_misc[1], 1);
       const u64 c = cls ? (u64)cls[n] : 0ull;
       keys[slot] = (c << 52) | ((u64)yl_desc_bits(sc) << 20) | (u64)n;
@@ -608,7 +609,7 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   if (tid < 130) reinterpret_cast<u64*>(s_misc + 256)[tid] = 0ull;   // OR scratch of the cooperative pass
   __syncthreads();
   for (int c = wave; c < C; c += nwaves) {
-    if (G > 1 && c % G != g) continue;
+    if (G > 1 && owner[c] != g) continue;
     const int s = ws_start[c];
     if (s < 0) continue;
     const int e = ws_end[c];
@@ -641,7 +642,7 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
     // ---- class-group split: publish my classes' kept candidates, then the LAST group of the image merges
     int* klist = p.kept_list + ((size_t)b * G + g) * N;
     for (int c = wave; c < C; c += nwaves) {
-      if (c % G != g) continue;
+      if (owner[c] != g) continue;
       const int s = ws_start[c];
       if (s < 0) continue;
       const int nk = ws_kept[c];
@@ -651,6 +652,10 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
     __syncthreads();
     if (tid == 0) s_misc[3] = __hip_atomic_fetch_add(&p.done[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    YL_STAMP(6);
+#ifdef YL_NMS_STAMP
+    if (blockIdx.x == 0 && tid == 0) yl_nms_stamps[(blockIdx.y & 3) * 16 + 7] = (unsigned long long)nsurv;
+#endif
     if (s_misc[3] != G - 1) return;
     __threadfence();
     if (tid == 0) p.done[b] = 0;                              // ready for the next launch
@@ -680,7 +685,7 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
       if (nk <= 0) continue;
       const int s = __hip_atomic_load(&ws_start[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int off = ws_off[c];
-      const int* src = p.kept_list + ((size_t)b * G + (c % G)) * N + s;
+      const int* src = p.kept_list + ((size_t)b * G + owner[c]) * N + s;
       for (int k = lane; k < nk; k += 64) {
         const int orow = off + k;
         if (orow >= p.max_out) continue;
@@ -689,6 +694,7 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
       }
     }
     if (tid == 0) p.counts[b] = total;
+    YL_STAMP(9);
     return;
   }
 
@@ -766,26 +772,77 @@ __global__ __launch_bounds__(1024) void yl_nms_kernel(YlNmsP p) {
   __syncthreads();
   const int G = p.G > 1 ? p.G : 1, g = G > 1 ? (int)blockIdx.y : 0;
   const int* clsb = p.cls ? p.cls + (size_t)b * p.N : nullptr;
-  int local = 0;
-  for (int n = tid; n < p.N; n += blockDim.x)
-    local += (scores[n] > p.conf_thr && (G == 1 || clsb[n] % G == g)) ? 1 : 0;
-  for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
-  if ((tid & 63) == 0 && local) atomicAdd(&s_misc[0], local);
-  __syncthreads();
-  const int nsurv = s_misc[0];
-  if (nsurv == 0 && G == 1) {
-    if (tid == 0) p.counts[b] = 0;
-    return;
+  unsigned char* owner = nullptr;
+  int nsurv;
+  if (G > 1) {
+    // ---- class-group split: histogram of the survivors per class (every group of the image computes the same
+    // one), then a deterministic longest-processing-time assignment of the classes to the G workgroups: classes
+    // with more than 64 survivors, largest first, go to the least loaded group (load = survivors^2 / 64 ~ pair
+    // tests); the rest are dealt out mod G.  The histogram also yields this group's survivor count.
+    owner = reinterpret_cast<unsigned char*>(s_misc) + 2304;
+    int* hist = reinterpret_cast<int*>(lkeys);                 // [C] (key area is free until the compaction)
+    int* big = hist + p.C;                                     // [<= C] (count << 12 | class) in rank order
+    for (int c = tid; c < p.C; c += blockDim.x) hist[c] = 0;
+    if (tid == 0) s_misc[1] = 0;
+    __syncthreads();
+    for (int n = tid; n < p.N; n += blockDim.x)
+      if (scores[n] > p.conf_thr) atomicAdd(&hist[clsb[n]], 1);
+    __syncthreads();
+    // rank of every big class in (count desc, class asc) order, computed in parallel: identical in all G workgroups
+    for (int c = tid; c < p.C; c += blockDim.x) {
+      owner[c] = (unsigned char)(c % G);
+      const int hc = hist[c];
+      if (hc > 64) {
+        int rank = 0;
+        for (int q = 0; q < p.C; ++q) {
+          const int hq = hist[q];
+          rank += (hq > 64 && (hq > hc || (hq == hc && q < c))) ? 1 : 0;
+        }
+        big[rank] = (hc << 12) | c;
+        atomicAdd(&s_misc[1], 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int nb = s_misc[1];
+      long load[4] = {0, 0, 0, 0};
+      for (int i = 0; i < nb; ++i) {
+        int q = 0;
+        for (int t = 1; t < G; ++t) if (load[t] < load[q]) q = t;
+        const long cnt = big[i] >> 12;
+        load[q] += cnt * cnt;
+        owner[big[i] & 4095] = (unsigned char)q;
+      }
+    }
+    __syncthreads();
+    int local = 0;
+    for (int c = tid; c < p.C; c += blockDim.x) local += (owner[c] == g) ? hist[c] : 0;
+    for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
+    if ((tid & 63) == 0 && local) atomicAdd(&s_misc[0], local);
+    __syncthreads();
+    nsurv = s_misc[0];
+    __syncthreads();                                            // hist / big (key area) are dead from here on
+  } else {
+    int local = 0;
+    for (int n = tid; n < p.N; n += blockDim.x) local += (scores[n] > p.conf_thr) ? 1 : 0;
+    for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
+    if ((tid & 63) == 0 && local) atomicAdd(&s_misc[0], local);
+    __syncthreads();
+    nsurv = s_misc[0];
+    if (nsurv == 0) {
+      if (tid == 0) p.counts[b] = 0;
+      return;
+    }
   }
   int P = 64;
   while (P < nsurv) P <<= 1;
   // LDS: [lds_cap keys][4 ints]; the key slots beyond P are free -> survivors' boxes in sorted order
   float4* sbox = reinterpret_cast<float4*>(lkeys + P);
   if (P <= p.lds_cap) {
-    if ((size_t)P * 8 + (size_t)nsurv * 16 <= (size_t)p.lds_cap * 8) yl_nms_run<true, true>(p, lkeys, P, nsurv, b, s_misc, sbox);
-    else yl_nms_run<true, false>(p, lkeys, P, nsurv, b, s_misc, nullptr);
+    if ((size_t)P * 8 + (size_t)nsurv * 16 <= (size_t)p.lds_cap * 8) yl_nms_run<true, true>(p, lkeys, P, nsurv, b, s_misc, sbox, owner);
+    else yl_nms_run<true, false>(p, lkeys, P, nsurv, b, s_misc, nullptr, owner);
   } else {
-    yl_nms_run<false, false>(p, p.gkeys + (size_t)b * p.gP, P, nsurv, b, s_misc, nullptr);
+    yl_nms_run<false, false>(p, p.gkeys + (size_t)b * p.gP, P, nsurv, b, s_misc, nullptr, owner);
   }
 }
 
