@@ -13,7 +13,7 @@ meta = zoo_meta("edge_n", 80, 640)
 m = ya.build_model_from_meta(meta); m.load_state_dict(synth_state_dict(meta, seed=int(os.environ.get('YL_SEED', '2')), head_noise=2.0)); m.to("cuda:0")
 ctx = m._ctx_for(640)
 x = synth_images(64, 640).cuda()
-for _ in range(1):
+for _ in range(4):
     ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=300)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 64)()

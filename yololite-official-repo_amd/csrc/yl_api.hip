@@ -52,7 +52,7 @@ struct yl_ctx {
   int* ws_cls = nullptr;
   int* ws_clsws = nullptr;
   int* ws_kept_list = nullptr;               // [B][YL_NMS_GROUPS][N] class-group split of the NMS kernel
-  int* ws_done = nullptr;                    // [B] arrival counters (zero between launches)
+  int* ws_done = nullptr;                    // [B][256 bytes] class -> NMS workgroup table
   unsigned long long* ws_gkeys = nullptr;
   int gP = 0;
   float* ws_tmp_dets = nullptr;
@@ -237,8 +237,7 @@ yl_status ensure_post(yl_ctx* c, int B) {
   HIPCHK(c, hipMalloc((void**)&c->ws_tmp_dets, n * 6 * sizeof(float)));
   HIPCHK(c, hipMalloc((void**)&c->ws_tmp_idx, n * sizeof(int)));
   HIPCHK(c, hipMalloc((void**)&c->ws_kept_list, n * YL_NMS_GROUPS * sizeof(int)));
-  HIPCHK(c, hipMalloc((void**)&c->ws_done, (size_t)B * sizeof(int)));
-  HIPCHK(c, hipMemset(c->ws_done, 0, (size_t)B * sizeof(int)));
+  HIPCHK(c, hipMalloc((void**)&c->ws_done, (size_t)B * 256));        // class -> NMS workgroup table per image
   c->post_cap_batch = B;
   return YL_OK;
 }
@@ -515,7 +514,7 @@ yl_status do_post(yl_ctx* c, const float* const* levels_all, int b0, int B, cons
   // set in one workgroup, or survivors could exceed the LDS key capacity
   np.G = (c->opt_nms_groups > 1 && np.topk == 0 && c->C > 1 && c->C <= 256 && c->N <= YL_LDS_KEYS_MAX) ? c->opt_nms_groups : 1;
   np.kept_list = c->ws_kept_list + o * YL_NMS_GROUPS;
-  np.done = c->ws_done + b0;
+  np.done = c->ws_done + (size_t)b0 * 64;                              // 256 bytes per image
   HIPCHK(c, yl_launch_nms(np, B, st));
   return YL_OK;
 }

@@ -46,11 +46,11 @@ struct YlNmsP {
   const float* backmap;  // [B][5] or nullptr
   float* tmp_dets;       // [B][N][6]  (fallback top-k staging) or nullptr
   int* tmp_idx;          // [B][N]
-  // class-group split: G workgroups per image (grid.y), group g owns the classes c % G == g; the last group to
-  // finish an image merges the per-class kept lists into the ordered output.  G == 1: one workgroup does it all.
+  // class-group split: G workgroups per image (grid.y), group g owns the classes c % G == g; a small merge kernel
+  // (next in the stream) turns the per-class kept lists into the ordered output.  G == 1: one workgroup does it all.
   int G;
   int* kept_list;        // [B][G][N] candidate indices of the kept boxes, class segments at their sorted positions
-  int* done;             // [B] arrival counters, zero between launches
+  int* done;             // [B][64 ints = 256 bytes]: class -> group table written by group 0 for the merge kernel
 };
 
 // ---- conv layer parameters (one struct for all conv kernels) -----------------------------------

@@ -564,10 +564,18 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   for (int c = tid; c < C; c += blockDim.x)
     if (G == 1 || owner[c] == g) { ws_start[c] = -1; ws_end[c] = 0; ws_kept[c] = 0; ws_off[c] = 0; }
   __syncthreads();
-  for (int n = tid; n < N; n += blockDim.x) {
-    const float sc = scores[n];
-    if (sc > p.conf_thr && (G == 1 || owner[cls[n]] == g)) {
-      const int slot = atomicAdd(&s_misc[1], 1);
+  for (int n0 = 0; n0 < N; n0 += blockDim.x) {                // wave-aggregated slot allocation (order is irrelevant:
+    const int n = n0 + tid;                                    // the keys are sorted next)
+    const float sc = n < N ? scores[n] : -INFINITY;
+    const bool act = n < N && sc > p.conf_thr && (G == 1 || owner[cls[n]] == g);
+    const u64 m = __ballot(act);
+    if (m == 0ull) continue;
+    int base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&s_misc[1], __popcll(m));
+    base = __builtin_amdgcn_readlane(base, leader);
+    if (act) {
+      const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
       const u64 c = cls ? (u64)cls[n] : 0ull;
       keys[slot] = (c << 52) | ((u64)yl_desc_bits(sc) << 20) | (u64)n;
     }
@@ -639,7 +647,7 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
   YL_STAMP(5);
 
   if (G > 1) {
-    // ---- class-group split: publish my classes' kept candidates, then the LAST group of the image merges
+    // ---- class-group split: publish my classes' kept candidates (per-class start / count are already in cls_ws)
     int* klist = p.kept_list + ((size_t)b * G + g) * N;
     for (int c = wave; c < C; c += nwaves) {
       if (owner[c] != g) continue;
@@ -648,53 +656,16 @@ __device__ __forceinline__ void yl_nms_run(const YlNmsP& p, u64* keys, int P, in
       const int nk = ws_kept[c];
       for (int k = lane; k < nk; k += 64) klist[s + k] = (int)k32[2 * k32[2 * (s + k) + 1]];
     }
-    __threadfence();                                          // my lists and per-class counters: visible device-wide
-    __syncthreads();
-    if (tid == 0) s_misc[3] = __hip_atomic_fetch_add(&p.done[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    // group 0 also leaves the class -> group table for the merge kernel (yl_nms_merge_kernel, next in the stream:
+    // the kernel boundary orders these plain stores, no device-scope fences or arrival counters needed)
+    if (g == 0) {
+      unsigned char* ow = reinterpret_cast<unsigned char*>(p.done) + (size_t)b * 256;
+      for (int c = tid; c < C; c += blockDim.x) ow[c] = owner[c];
+    }
     YL_STAMP(6);
 #ifdef YL_NMS_STAMP
     if (blockIdx.x == 0 && tid == 0) yl_nms_stamps[(blockIdx.y & 3) * 16 + 7] = (unsigned long long)nsurv;
 #endif
-    if (s_misc[3] != G - 1) return;
-    __threadfence();
-    if (tid == 0) p.done[b] = 0;                              // ready for the next launch
-    // exclusive scan of the kept counts over ALL classes (wave 0), as in the single-group path
-    if (wave == 0) {
-      int running = 0;
-      for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + lane;
-        const int v = (c < C) ? __hip_atomic_load(&ws_kept[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        int incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int t = __shfl_up(incl, d);
-          if (lane >= d) incl += t;
-        }
-        if (c < C) ws_off[c] = running + incl - v;
-        running += __shfl(incl, 63);
-      }
-      if (lane == 0) s_misc[2] = running;
-    }
-    __syncthreads();
-    const int total = s_misc[2];
-    float* dst = p.dets + (size_t)b * p.max_out * 6;
-    int* dst_idx = p.keep_idx ? p.keep_idx + (size_t)b * p.max_out : nullptr;
-    for (int c = wave; c < C; c += nwaves) {
-      const int nk = __hip_atomic_load(&ws_kept[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (nk <= 0) continue;
-      const int s = __hip_atomic_load(&ws_start[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int off = ws_off[c];
-      const int* src = p.kept_list + ((size_t)b * G + owner[c]) * N + s;
-      for (int k = lane; k < nk; k += 64) {
-        const int orow = off + k;
-        if (orow >= p.max_out) continue;
-        const int idx = __hip_atomic_load(&src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        yl_write_det(p, b, dst, dst_idx, orow, boxes[idx], scores[idx], c, idx, true);
-      }
-    }
-    if (tid == 0) p.counts[b] = total;
-    YL_STAMP(9);
     return;
   }
 
@@ -785,8 +756,19 @@ __global__ __launch_bounds__(1024) void yl_nms_kernel(YlNmsP p) {
     for (int c = tid; c < p.C; c += blockDim.x) hist[c] = 0;
     if (tid == 0) s_misc[1] = 0;
     __syncthreads();
-    for (int n = tid; n < p.N; n += blockDim.x)
-      if (scores[n] > p.conf_thr) atomicAdd(&hist[clsb[n]], 1);
+    for (int n0 = 0; n0 < p.N; n0 += blockDim.x) {             // wave-aggregated: one LDS atomic per (wave, class)
+      const int n = n0 + tid;
+      const bool act = n < p.N && scores[n] > p.conf_thr;
+      const int cn = act ? clsb[n] : -1;
+      u64 rem = __ballot(act);
+      while (rem) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const int c0 = __builtin_amdgcn_readlane(cn, leader);
+        const u64 m = __ballot(cn == c0);
+        if ((tid & 63) == leader) atomicAdd(&hist[c0], __popcll(m));
+        rem &= ~m;
+      }
+    }
     __syncthreads();
     // rank of every big class in (count desc, class asc) order, computed in parallel: identical in all G workgroups
     for (int c = tid; c < p.C; c += blockDim.x) {
@@ -844,6 +826,52 @@ __global__ __launch_bounds__(1024) void yl_nms_kernel(YlNmsP p) {
   } else {
     yl_nms_run<false, false>(p, p.gkeys + (size_t)b * p.gP, P, nsurv, b, s_misc, nullptr, owner);
   }
+}
+
+// Second half of the class-group split: one 256-thread workgroup per image turns the per-class kept lists the G
+// NMS workgroups left behind into the ordered output (class ascending, score descending inside a class).
+__global__ __launch_bounds__(256) void yl_nms_merge_kernel(YlNmsP p) {
+  __shared__ int s_total;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int N = p.N, C = p.C, G = p.G;
+  const float4* boxes = p.boxes + (size_t)b * N;
+  const float* scores = p.scores + (size_t)b * N;
+  int* ws_start = p.cls_ws + (size_t)b * 4 * C;
+  int* ws_kept = ws_start + 2 * C;
+  int* ws_off = ws_kept + C;
+  const unsigned char* owner = reinterpret_cast<const unsigned char*>(p.done) + (size_t)b * 256;
+  if (wave == 0) {
+    int running = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      const int v = (c < C) ? ws_kept[c] : 0;
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (c < C) ws_off[c] = running + incl - v;
+      running += __shfl(incl, 63);
+    }
+    if (lane == 0) s_total = running;
+  }
+  __syncthreads();
+  float* dst = p.dets + (size_t)b * p.max_out * 6;
+  int* dst_idx = p.keep_idx ? p.keep_idx + (size_t)b * p.max_out : nullptr;
+  for (int c = wave; c < C; c += nwaves) {
+    const int nk = ws_kept[c];
+    if (nk <= 0) continue;
+    const int off = ws_off[c];
+    const int* src = p.kept_list + ((size_t)b * G + owner[c]) * N + ws_start[c];
+    for (int k = lane; k < nk; k += 64) {
+      const int orow = off + k;
+      if (orow >= p.max_out) continue;
+      const int idx = src[k];
+      yl_write_det(p, b, dst, dst_idx, orow, boxes[idx], scores[idx], c, idx, true);
+    }
+  }
+  if (tid == 0) p.counts[b] = s_total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -926,5 +954,6 @@ hipError_t yl_launch_nms(const YlNmsP& p, int B, hipStream_t st) {
   const size_t lds = (size_t)p.lds_cap * 8 + YL_NMS_SCRATCH;
   if ((int)lds > g_nms_lds_max && lds > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(yl_nms_kernel, dim3(B, p.G > 1 ? p.G : 1), dim3(1024), lds, st, p);
+  if (p.G > 1) hipLaunchKernelGGL(yl_nms_merge_kernel, dim3(B), dim3(256), 0, st, p);
   return hipGetLastError();
 }
