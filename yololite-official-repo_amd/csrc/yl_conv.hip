@@ -368,13 +368,12 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 && MODE <= 1) ? YL_PW_WAVES : 3)
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
 
-  auto load_chunk = [&](int c0, int c1) {
+  auto load_chunk = [&](int c0, int c1) {          // asynchronous (yl_glds16): complete at the next barrier
     for (int t = c0 + wave; t < c1; t += 4) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        if (nt < ntc) w = wg[((size_t)t * p.NTtot + nt0 + nt) * 64 + lane];
-        wl[((t - c0) * NT + nt) * 64 + lane] = w;
+        if (nt < ntc) yl_glds16(wg + ((size_t)t * p.NTtot + nt0 + nt) * 64 + lane, wl + ((t - c0) * NT + nt) * 64);
+        else wl[((t - c0) * NT + nt) * 64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};     // padding n-tiles of the last chunk
       }
     }
   };
@@ -394,8 +393,9 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 && MODE <= 1) ? YL_PW_WAVES : 3)
   const bool bias0 = false;
   if (DWM) {
     const int nw = p.dw_k * p.dw_k * p.Cin;
-    for (int i = tid; i < nw; i += 256) dwl[i] = p.dw_w[i];
-    for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = p.dw_b ? p.dw_b[i] : 0.0f;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, p.Cin, tid, 256);
+    else for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = 0.0f;
   }
   if (single) load_chunk(0, TK);
   bool need_sync = single || DWM;     // first LDS read happens after the first activation loads are in flight
@@ -617,24 +617,25 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
   };
   f32x4 stg[NSLOT];
   int tile = bx * 4 + wave;
-#if YL_DWH_XTILE
-  if (tile < ntiles) {                  // software pipeline over (tile, channel block): prime with (tile0, 0);
-    tile_geom(tile);                    // its loads fly under the weight fill below
+  bool primed = false;
+  if (tile < ntiles) {                  // the first tile's first halo stage is requested BEFORE the weight fill and
+    tile_geom(tile);                    // the barrier: both fetches are in flight together
     stage_load(0, stg);
+    primed = true;
   }
-#endif
   for (int t = wave; t < KB; t += 4) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (nt < ntc) w = wg[((size_t)t * p.NTtot + nt0 + nt) * 64 + lane];
-      wl[(t * NT + nt) * 64 + lane] = w;
+      if (nt < ntc) yl_glds16(wg + ((size_t)t * p.NTtot + nt0 + nt) * 64 + lane, wl + (t * NT + nt) * 64);
+      else wl[(t * NT + nt) * 64 + lane] = w;
     }
   }
   {
     const int nw = DK * DK * p.Cin;
-    for (int i = tid; i < nw; i += 256) dwl[i] = p.dw_w[i];
-    for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = p.dw_b ? p.dw_b[i] : 0.0f;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, p.Cin, tid, 256);
+    else for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = 0.0f;
   }
   __syncthreads();
 #if YL_DWH_XTILE
@@ -659,8 +660,11 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
       if (pre_add && n < p.N) acc[0][nt] = yl_ld4(p.res + px[0].lin * p.N + n);
     }
 #if !YL_DWH_XTILE
-    tile_geom(tile);
-    stage_load(0, stg);
+    if (!primed) {
+      tile_geom(tile);
+      stage_load(0, stg);
+    }
+    primed = false;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // previous tile's halo reads are complete
     stage_store(stg);
 #endif
@@ -762,8 +766,9 @@ __global__ __launch_bounds__(256) void yl_uib_kernel(YlConvP p) {
   }
   {
     const int nw = DK * DK * p.Cin;
-    for (int i = tid; i < nw; i += 256) dwl[i] = p.dw_w[i];
-    for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = p.dw_b ? p.dw_b[i] : 0.0f;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, p.Cin, tid, 256);
+    else for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = 0.0f;
     for (int i = tid; i < KB * 16; i += 256) b2l[i] = p.b2[i];
   }
   __syncthreads();

@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #endif
   {
     const f32x4* g2 = reinterpret_cast<const f32x4*>(p.w2p);
-    for (int i = tid; i < 9 * KB1 * NT2 * 64; i += 256) w2l[i] = g2[i];
+    for (int r = wave; r < 9 * KB1 * NT2; r += 4) yl_glds16(g2 + r * 64 + lane, w2l + r * 64);   // async, see yl_dev.h
     if (NT3 > 0) {
       const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
-      for (int i = tid; i < NT2 * NT3 * 64; i += 256) w3l[i] = g3[i];
+      for (int r = wave; r < NT2 * NT3; r += 4) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
     }
   }
   __syncthreads();
