@@ -36,6 +36,11 @@
 #define yl_uib_supported yl_uib_supported_bf16
 #define yl_uib_lds_bytes yl_uib_lds_bytes_bf16
 #endif
+#include <stdio.h>
+#include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "yl_internal.h"
 #include <math.h>
 
@@ -1033,9 +1038,18 @@ static hipError_t yl_conv_attr_nt() {
 // block that has to queue behind another one re-stages the whole weight chunk into LDS for nothing
 template <typename K>
 static int yl_resident_blocks(K kernel, size_t lds) {
+  // the occupancy query costs the host ~10 us: asked once per (kernel, LDS size), then served from a small cache
+  // (eager launches of the 20-70 us layers were host-bound otherwise; graph replays never come here)
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, int> cache;
+  const std::pair<const void*, size_t> key((const void*)kernel, lds);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, 256, lds) != hipSuccess || nb < 1) nb = 1;
   if (nb > 4) nb = 4;
+  cache[key] = nb * YL_NUM_CU;
   return nb * YL_NUM_CU;
 }
 
