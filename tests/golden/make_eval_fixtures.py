@@ -24,7 +24,7 @@ sys.dont_write_bytecode = True
 import numpy as np
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("YL_FIXTURE_OUT") or os.path.dirname(os.path.abspath(__file__))
 
 
 def install_stubs():

@@ -36,7 +36,9 @@ import torch
 
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+# YL_FIXTURE_OUT: write somewhere else (tests/test_oracle_golden.py re-runs the recipe into a temp dir and
+# compares with the committed files)
+OUT = os.environ.get("YL_FIXTURE_OUT") or os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from oracle import backbones as obb          # noqa: E402
@@ -106,7 +108,11 @@ def main():
     from scripts.model import model_v2 as ref_model
     from scripts.helpers import utils_ms as ref_decode
     from scripts.helpers import helpers as ref_helpers
-    import tools.infer as ref_infer
+    # by file path: `import tools.infer` would resolve to THIS repository's tools/ package (sys.path[0] = REPO)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_tools_infer", os.path.join(REF, "tools", "infer.py"))
+    ref_infer = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_infer)
 
     # ---------------------------------------------------------------- A. neck + head + layout
     cases = [

@@ -17,7 +17,7 @@ os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
 sys.dont_write_bytecode = True
 import numpy as np
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("YL_FIXTURE_OUT") or os.path.dirname(os.path.abspath(__file__))
 
 
 def scene(seed, n_obj, n_frames, n_cls, miss=0.1, clutter=0.5, appear_late=True):

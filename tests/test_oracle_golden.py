@@ -244,3 +244,32 @@ def test_tracker_oracle_matches_reference(golden_dir, case):
     with open(os.path.join(golden_dir, "tracker.json")) as f:
         rec = json.load(f)[case]
     check_tracker_sequence(otrack.SortOracle, rec, box_tol=0.0)       # same numpy calls: bit-exact here
+
+
+# --------------------------------------------------------------------------- the fixture recipe itself
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
+@pytest.mark.parametrize("script", ["make_fixtures.py", "make_eval_fixtures.py", "make_tracker_fixtures.py"])
+def test_fixture_recipe_regenerates_committed_files(golden_dir, tmp_path, script):
+    """The committed generators, run against /root/reference, reproduce the committed fixtures: arrays bit for
+    bit (npz members; the zip container carries timestamps), JSON files byte for byte."""
+    import subprocess
+    import sys
+    env = dict(os.environ, YL_FIXTURE_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    root = os.path.dirname(os.path.dirname(golden_dir))
+    r = subprocess.run([sys.executable, os.path.join(golden_dir, script)], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    made = sorted(os.listdir(tmp_path))
+    assert made, "the generator wrote nothing"
+    for fn in made:
+        new, old = os.path.join(tmp_path, fn), os.path.join(golden_dir, fn)
+        assert os.path.exists(old), f"{fn} is generated but not committed"
+        if fn.endswith(".npz"):
+            a, b = np.load(new), np.load(old)
+            assert sorted(a.files) == sorted(b.files)
+            for k in a.files:
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, k
+                assert a[k].tobytes() == b[k].tobytes(), f"{fn}:{k} differs from the committed fixture"
+        else:
+            with open(new, "rb") as f1, open(old, "rb") as f2:
+                assert f1.read() == f2.read(), f"{fn} differs from the committed fixture"
