@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 1
+#define YL_ABI_VERSION 2
 #define YL_MAX_LEVELS 8
 
 typedef struct yl_ctx yl_ctx;
@@ -140,6 +140,11 @@ typedef struct {
   int32_t center_mode;        /* YL_CENTER_*                                                      */
   int32_t wh_mode;            /* YL_WH_*                                                          */
   const float* backmap_dev;   /* optional [B][5] = padx,pady,scale,w0,h0 (tools/infer.py:508-516) */
+  int32_t fallback_nms;       /* YL_POST_FALLBACK only: the primitive behind nms() (tools/infer.py:134-152).
+                                 YL_NMS_TORCHVISION (0, default) = what nms() runs when torchvision imports (a normal
+                                 reference install); YL_NMS_GREEDY = its pure-torch loop (IoU + 1e-6, keep <= thr),
+                                 taken when the import fails -- the situation in which tools/infer.py itself reaches
+                                 decode_anchorfree_like_train (utils_ms.py:4 imports torchvision too)            */
 } yl_post_cfg;
 
 /* ---- lifetime ---------------------------------------------------------------------------------
@@ -293,6 +298,9 @@ yl_status yl_track_reset(yl_tracker* t, int32_t stream_index, void* stream);
 yl_status yl_track_update(yl_tracker* t, const float* dets_dev, const int32_t* counts_dev, int32_t max_out,
                           int32_t* out_id_dev, float* out_box_dev, int32_t* out_cls_dev, float* out_score_dev,
                           int32_t* out_count_dev, void* stream);
+/* Grows the per-stream capacity to new_max_tracks (<= 4096), keeping every stream's state; synchronises the
+ * device.  The output tensors of yl_track_update must then have the new row length.  No-op when not larger. */
+yl_status yl_track_grow(yl_tracker* t, int32_t new_max_tracks);
 /* synchronises the device; host arrays [num_streams] (either may be NULL) */
 yl_status yl_track_stats(yl_tracker* t, int32_t* ntracks_host, int32_t* overflow_host);
 

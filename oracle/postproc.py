@@ -251,9 +251,12 @@ def pipeline_eval(levels, img_size: int, conf_th: float = 0.001, iou_th: float =
 
 @torch.no_grad()
 def pipeline_fallback(levels, img_size: int, conf_th: float = 0.35, iou_th: float = 0.60, topk: int = 300,
-                      center_mode: str = "v8", wh_mode: str = "softplus") -> Dict[str, List[np.ndarray]]:
+                      center_mode: str = "v8", wh_mode: str = "softplus", nms_impl: str = "fallback") -> Dict[str, List[np.ndarray]]:
     """tools/infer.py:247-389: score (C==1 -> obj*cls), `> conf`, min-side >= 2 px on the
-    pre-clamp size, clamp, per-class greedy NMS (cap 300), global top-k by score."""
+    pre-clamp size, clamp, per-class NMS through nms() (cap 300), global top-k by score.
+    nms_impl: "fallback" = the pure-torch greedy loop of nms() (:139-149; what runs when torchvision is absent,
+    the only situation in which the reference's CLI reaches this function), "torchvision" = nms() with the
+    import succeeding (:136-137)."""
     lv = list(levels) if isinstance(levels, (list, tuple)) else [levels]
     out = {"boxes": [], "scores": [], "classes": []}
     hi = img_size - 1
@@ -270,7 +273,7 @@ def pipeline_fallback(levels, img_size: int, conf_th: float = 0.35, iou_th: floa
         m = (sc > conf_th) & (pw >= 2.0) & (ph >= 2.0)
         x, y, w, h = px[m], py[m], pw[m], ph[m]
         xyxy = torch.stack([x - w * 0.5, y - h * 0.5, x + w * 0.5, y + h * 0.5], 1).clamp(0, hi)
-        bb, ss, cc = _per_class(xyxy.numpy().reshape(-1, 4), sc[m].numpy(), ci[m].numpy(), iou_th, 300, "fallback")
+        bb, ss, cc = _per_class(xyxy.numpy().reshape(-1, 4), sc[m].numpy(), ci[m].numpy(), iou_th, 300, nms_impl)
         if ss.size > topk:
             top = _stable_desc_order(ss)[:topk]
             bb, ss, cc = bb[top], ss[top], cc[top]

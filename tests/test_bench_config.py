@@ -1,0 +1,195 @@
+"""Parity tests of the BENCHMARKED configuration itself (bench.build_workload: the model, weights and inputs of
+`python bench.py`) and of the other full-size BASELINE configs, run with `pytest -m gpu` on the MI355X box:
+
+  config 2  edge_n 640x640 B=64, yl_predict + hipGraph + 2 streams + level-batched heads + fused decode
+            == eager / 1 stream (bitwise), sampled images == oracle.pipeline_main(oracle forward) under the
+            north_star tolerances (class ids equal, boxes equal after integer rounding, scores within 1e-4),
+            nothing dropped by the packed-row capacity
+  config 3  yololite_m 640x640 B=32        } determinism + batch invariance at full size (bitwise) and sampled
+  config 4  edge_m + seg head 640x640 B=32 } images against the oracle
+  config 1  edge_n 640x640 batch 1 through tools/infer.py (the CLI), detections == oracle flow
+
+The oracle (CPU, fp32) runs only on the sampled images: ~0.1-3 s per image at these sizes."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bench                                   # the benchmark's own workload builder
+import yololite_amd as ya                      # noqa: F401
+from yololite_amd import _lib
+from oracle import model as omodel
+from oracle import postproc as opost
+
+DEV = "cuda:0"
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _oracle(meta, sd):
+    m = omodel.build_from_meta(meta).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    return m
+
+
+def _rows(dets, counts, b):
+    k = int(counts[b])
+    r = dets[b, :k].cpu().numpy()
+    return r[:, :4], r[:, 4], r[:, 5].astype(np.int64)
+
+
+def _assert_boxes_equal_after_rounding(got, exp):
+    """north_star: box coordinates equal after integer rounding.  A coordinate whose fraction sits within 2e-3 of
+    .5 may round either way under the ~1e-5 px fp32 drift of two different summation orders: for those (and only
+    those) the raw values must agree to 1e-3 px instead."""
+    got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
+    assert got.shape == exp.shape
+    bad = np.rint(got) != np.rint(exp)
+    if bad.any():
+        frac = np.abs(exp[bad] - np.floor(exp[bad]) - 0.5)
+        assert (frac < 2e-3).all() and (np.abs(got[bad] - exp[bad]) < 1e-3).all(), (got[bad], exp[bad])
+    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-3)
+
+
+def _assert_north_star(got, exp, b):
+    gb, gs, gc = got
+    assert gc.tolist() == exp["classes"][b].tolist(), "class ids / order differ"
+    np.testing.assert_allclose(gs, exp["scores"][b], rtol=0, atol=1e-4)
+    _assert_boxes_equal_after_rounding(gb, exp["boxes"][b])
+
+
+def _score_tensor(levels, C=80):
+    raw = torch.cat([l.reshape(l.shape[0], -1, l.shape[-1])[..., :5 + C] for l in levels], 1)
+    return torch.sigmoid(raw[..., 4]) * torch.sigmoid(raw[..., 5:]).max(-1).values
+
+
+def _safe_images(scores, boxes_unused, conf, cand, need=3):
+    """images whose candidate scores all keep >= 2e-5 distance from `conf` (fp32 drift of the forward pass is ~1e-6
+    relative: such an image cannot flip a threshold decision)"""
+    ok = [b for b in cand if float((scores[b] - conf).abs().min()) > 2e-5]
+    assert len(ok) >= need, "no sampled image is clear of the confidence threshold"
+    return ok[:need]
+
+
+def test_bench_configuration_edge_n_b64_parity():
+    wl = bench.build_workload("edge_n", 640, 64, seed=1, dev=DEV)
+    ctx, x, meta, sd = wl["ctx"], wl["x"], wl["meta"], wl["sd"]
+    mo = bench.MAX_OUT
+    # ---- reference schedule: eager, one stream, per-level launches, decode kernel
+    for k, v in (("graph", 0), ("streams", 1), ("batch_levels", 0), ("fuse_decode", 0)):
+        ctx.set_option(k, v)
+    d0, c0 = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
+    d0, c0 = d0.clone(), c0.clone()
+    cn = c0.cpu().numpy()
+    assert cn.min() >= 50 and cn.max() <= mo, (cn.min(), cn.max())          # every image detects, nothing dropped
+    ncls = [len(np.unique(_rows(d0, c0, b)[2])) for b in range(64)]
+    assert np.mean(ncls) >= 40, np.mean(ncls)
+    # ---- the bench schedule (bench.py defaults): hipGraph replay, 2 streams, level-batched heads, fused decode
+    for k, v in (("graph", 1), ("streams", 2), ("batch_levels", 1), ("fuse_decode", 1)):
+        ctx.set_option(k, v)
+    for rep in range(3):                                                     # capture, then two replays
+        d1, c1 = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
+        assert torch.equal(c1, c0), rep
+        for b in range(64):
+            assert torch.equal(d1[b, :cn[b]], d0[b, :cn[b]]), (rep, b)
+    # ---- sampled images against the oracle end to end (oracle forward -> oracle pipeline)
+    orc = _oracle(meta, sd)
+    cand = [0, 21, 37, 50, 63]
+    with torch.no_grad():
+        ref_lv = orc(x[cand].cpu())
+    sel = _safe_images(_score_tensor(ref_lv), None, 0.4, range(len(cand)))
+    exp = opost.pipeline_main(ref_lv, 640, 0.4, 0.5, 300)
+    for i in sel:
+        _assert_north_star(_rows(d1, c1, cand[i]), exp, i)
+    # raw head tensors of the same images: decoded scores within the 1e-4 bar everywhere (not only on survivors)
+    lv = wl["model"](x[cand])
+    got_s, ref_s = _score_tensor([t.cpu() for t in lv]), _score_tensor(ref_lv)
+    assert float((got_s - ref_s).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("name,seg", [("yololite_m", False), ("edge_m", True)])
+def test_full_size_configs_3_and_4(name, seg):
+    """BASELINE configs 3 / 4 at 640x640 B=32: bitwise determinism and batch invariance of the raw levels, the
+    bench schedule against the eager one, sampled images against the oracle (detections; masks for config 4)."""
+    wl = bench.build_workload(name, 640, 32, seed=1, seg=seg, dev=DEV)
+    ctx, x, meta, sd, model = wl["ctx"], wl["x"], wl["meta"], wl["sd"], wl["model"]
+    a = model(x)
+    b = model(x)
+    la, lb = (a[0], b[0]) if seg else (a, b)
+    for u, v in zip(la, lb):
+        assert torch.equal(u, v)
+    if seg:
+        assert torch.equal(a[1], b[1])
+    for i in (0, 17, 31):
+        one = model(x[i:i + 1])
+        lo = one[0] if seg else one
+        for u, v in zip(la, lo):
+            assert torch.equal(u[i:i + 1], v), i
+    mo = bench.MAX_OUT
+    ctx.set_option("graph", 0); ctx.set_option("streams", 1)
+    d0, c0, i0 = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo, want_idx=True)
+    d0, c0, i0 = d0.clone(), c0.clone(), i0.clone()
+    cn = c0.cpu().numpy()
+    assert cn.min() >= 20 and cn.max() <= mo, (cn.min(), cn.max())
+    ctx.set_option("graph", 1); ctx.set_option("streams", 2)
+    for rep in range(2):
+        d1, c1 = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
+        assert torch.equal(c1, c0)
+        for bb in range(32):
+            assert torch.equal(d1[bb, :cn[bb]], d0[bb, :cn[bb]]), (rep, bb)
+    orc = _oracle(meta, sd)
+    cand = [0, 13, 31]
+    with torch.no_grad():
+        ref = orc(x[cand].cpu())
+    ref_lv, ref_pr = (ref if seg else (ref, None))
+    det_lv = [t[..., :85] for t in ref_lv]
+    sel = _safe_images(_score_tensor(det_lv), None, 0.4, range(len(cand)), need=2)
+    exp = opost.pipeline_main(det_lv, 640, 0.4, 0.5, 300)
+    for i in sel:
+        _assert_north_star(_rows(d1, c1, cand[i]), exp, i)
+    got_s = _score_tensor([t[cand].cpu() for t in la])
+    assert float((got_s - _score_tensor(det_lv)).abs().max()) <= 1e-4
+
+
+def test_config1_edge_n_640_batch1_through_cli(tmp_path):
+    """BASELINE config 1: edge_n 640x640, batch 1, the tools/infer.py flow (checkpoint file -> letterbox ->
+    forward -> decode -> per-class NMS -> back-map -> JSON) against the oracle's restatement of the same flow."""
+    from PIL import Image
+    from oracle import preproc as opre
+    wl = bench.build_workload("edge_n", 640, 1, seed=1, dev=DEV)
+    meta, sd = dict(wl["meta"]), wl["sd"]
+    meta["names"] = [f"c{i}" for i in range(80)]
+    ck = str(tmp_path / "edge_n.pt")
+    torch.save({"state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}, "meta": meta}, ck)
+    rng = np.random.RandomState(3)
+    imgs = {"frame_a": rng.randint(0, 256, size=(480, 640, 3)).astype(np.uint8),       # letterboxed (pad top/bottom)
+            "frame_b": rng.randint(0, 256, size=(640, 640, 3)).astype(np.uint8)}       # identity resize
+    (tmp_path / "imgs").mkdir()
+    for n, im in imgs.items():
+        Image.fromarray(im[..., ::-1]).save(str(tmp_path / "imgs" / f"{n}.png"))       # files are RGB; arrays are BGR
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "infer.py"), "--weights", ck, "--img_dir",
+                        str(tmp_path / "imgs"), "--img_size", "640"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    orc = _oracle(meta, sd)
+    checked = 0
+    for n, im in imgs.items():
+        with open(tmp_path / "runs" / "infer" / "1" / "json" / f"{n}.json") as f:
+            dets = json.load(f)["detections"]
+        xx, (padx, pady, scale, w0, h0) = opre.preprocess(im, 640)
+        with torch.no_grad():
+            lv = orc(torch.from_numpy(xx[None]))
+        if float((_score_tensor(lv) - 0.4).abs().min()) <= 2e-5:
+            continue
+        exp = opost.pipeline_main(lv, 640, 0.4, 0.5, 300)
+        eb = opost.backmap(exp["boxes"][0], padx, pady, scale, w0, h0)
+        assert len(dets) >= 20
+        assert [d["class_id"] for d in dets] == exp["classes"][0].tolist()
+        np.testing.assert_allclose([d["score"] for d in dets], exp["scores"][0], rtol=0, atol=1e-4)
+        _assert_boxes_equal_after_rounding([d["bbox_xyxy"] for d in dets], eb)
+        checked += 1
+    assert checked >= 1

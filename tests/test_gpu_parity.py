@@ -2,9 +2,9 @@
 inputs.  Run on the MI355X box with `pytest -m gpu`.
 
 Tolerances (north_star): class ids and box coordinates equal after integer rounding, scores within
-1e-4 (fp32).  Raw head tensors: |err| <= 2e-3 absolute on logits of magnitude ~10 after 63 fp32 layers
-(measured ~1e-5; the bound only has to catch wrong arithmetic, not rounding).  NMS on identical inputs
-is bit-exact (integer index work)."""
+1e-4 (fp32).  Raw head tensors: |err| <= 2e-4 absolute on the logits (a bound that implies 1e-4 on the
+scores; measured ~1e-5 after 63 fp32 layers), and the decoded scores themselves within 1e-4 on the zoo
+models.  NMS on identical inputs is bit-exact (integer index work)."""
 import json
 import os
 
@@ -43,13 +43,19 @@ def _x(B, S, seed=1234):
     return torch.from_numpy(np.ascontiguousarray(im.transpose(0, 3, 1, 2)))
 
 
-def _cmp_levels(outs, ref, atol=1e-4, rtol=1e-4):
-    """max |err| <= atol + rtol * max|ref| per level (fp32 drift over ~60 layers is ~1e-6 relative)."""
+def _cmp_levels(outs, ref, atol=2e-4, rtol=2e-6, C=None):
+    """Raw head logits: max |err| <= 2e-4 (+ 2e-6 * max|ref|: two ulps of the largest logit) per level.  A logit
+    error of 2e-4 moves a sigmoid by at most 5e-5 and a score = sigmoid(obj) * sigmoid(cls) by at most 1e-4 -- the
+    north_star bar -- which is ALSO asserted directly on the decoded scores when the row layout is known (C)."""
     for l, (o, r) in enumerate(zip(outs, ref)):
         assert tuple(o.shape) == tuple(r.shape)
         err = (o.cpu() - r).abs().max().item()
         bound = atol + rtol * r.abs().max().item()
         assert err <= bound, f"level {l}: max abs err {err} > {bound}"
+        if C is not None and C > 1:
+            sc = lambda t: torch.sigmoid(t[..., 4]) * torch.sigmoid(t[..., 5:5 + C]).max(-1).values
+            serr = (sc(o.cpu()) - sc(r)).abs().max().item()
+            assert serr <= 1e-4, f"level {l}: score error {serr} > 1e-4"
 
 
 # ------------------------------------------------------------------------------------------ forward
@@ -115,7 +121,7 @@ def test_forward_zoo_models(name, B, S, uib):
     with torch.no_grad():
         ref = _oracle_for(meta, sd)(x)
     outs = _hip_for(meta, sd, fuse_uib=uib)(x.to(DEV))
-    _cmp_levels(outs, ref)
+    _cmp_levels(outs, ref, C=80)
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_n", 2, 320), ("yololite_m", 1, 256)])
@@ -267,7 +273,7 @@ def test_pipelines_on_golden_levels(golden_dir, idx):
         assert [x["category_id"] for x in d] == rc.tolist()
         np.testing.assert_allclose([x["score"] for x in d], rs, atol=1e-5)
         np.testing.assert_allclose(np.asarray([x["bbox"] for x in d]).reshape(-1, 4), rb, atol=1e-3)
-    fb = ya.decode_anchorfree_like_train(dl, c["img"], conf_th=c["conf"], iou_th=c["iou"], topk=300)
+    fb = ya.decode_anchorfree_like_train(dl, c["img"], conf_th=c["conf"], iou_th=c["iou"], topk=300, nms_impl="greedy")
     for b in range(c["B"]):
         rb, rs, rc = (z[f"{c['tag']}/fallback/{b}/{k}"] for k in ("boxes", "scores", "classes"))
         assert fb["boxes"][b].shape == rb.shape
@@ -278,7 +284,7 @@ def test_pipelines_on_golden_levels(golden_dir, idx):
             _match(fb["boxes"][b].cpu().numpy(), fb["scores"][b].cpu().numpy(), fb["classes"][b].cpu().numpy(), rb, rs, rc)
 
 
-@pytest.mark.parametrize("mode", ["main", "eval", "fallback_topk"])
+@pytest.mark.parametrize("mode", ["main", "eval", "fallback_topk", "fallback_tv"])
 def test_pipelines_full_size_vs_oracle(mode):
     """N = 8400 candidates, C = 80, raw head ~ N(0,2) (SURVEY 8d stress input): hundreds of survivors at
     conf 0.4, thousands at 0.001."""
@@ -297,8 +303,9 @@ def test_pipelines_full_size_vs_oracle(mode):
         got = {"boxes": [r[:, :4] for r in rows], "scores": [r[:, 4] for r in rows],
                "classes": [r[:, 5].astype(np.int64) for r in rows]}
     else:
-        exp = opost.pipeline_fallback(lv, 640, 0.3, 0.6, topk=100)
-        fb = ya.decode_anchorfree_like_train(dl, 640, 0.3, 0.6, topk=100)
+        impl = "greedy" if mode == "fallback_topk" else "torchvision"       # nms() without / with torchvision
+        exp = opost.pipeline_fallback(lv, 640, 0.3, 0.6, topk=100, nms_impl="fallback" if impl == "greedy" else impl)
+        fb = ya.decode_anchorfree_like_train(dl, 640, 0.3, 0.6, topk=100, nms_impl=impl)
         got = {k: [t.cpu().numpy() for t in fb[k]] for k in fb}
     for b in range(2):
         assert len(exp["scores"][b]) > 50
@@ -350,6 +357,34 @@ def test_predict_fused_equals_forward_plus_postprocess_and_graph():
         for b in range(4):
             assert torch.equal(d1[b, :int(c1[b])], d3[b, :int(c3[b])])
     ctx.set_option("graph", 0)
+
+
+def test_cached_graph_survives_post_workspace_growth():
+    """forward(B=16) sizes the activations only; predict(B=4) captures a graph with the post workspaces of a
+    4-image batch baked in; predict(B=16) reallocates those workspaces WITHOUT growing the activations; the next
+    predict(B=4) must not replay the stale graph (it did: use-after-free of the freed workspaces)."""
+    meta = zoo_meta("edge_n", 80, 320)
+    sd = synth_state_dict(meta, seed=1, head_noise=2.0)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(320)
+    x = _x(16, 320).to(DEV)
+    ctx.set_option("graph", 0)
+    ref, cref = ctx.predict(x[:4], _lib.POST_MAIN, 0.02, 0.5, 300)
+    ref, cref = ref.clone(), cref.clone()
+    m2 = _hip_for(meta, sd)
+    c2 = m2._ctx_for(320)
+    c2.set_option("graph", 1)
+    c2.forward(x)
+    d, c = c2.predict(x[:4], _lib.POST_MAIN, 0.02, 0.5, 300)
+    assert torch.equal(c, cref)
+    junk = c2.predict(x, _lib.POST_MAIN, 0.02, 0.5, 300)
+    filler = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]     # reuse the freed blocks
+    for _ in range(2):
+        d, c = c2.predict(x[:4], _lib.POST_MAIN, 0.02, 0.5, 300)
+        assert torch.equal(c, cref) and int(c.min()) > 0
+        for b in range(4):
+            assert torch.equal(d[b, :int(c[b])], ref[b, :int(cref[b])])
+    del junk, filler
 
 
 @pytest.mark.parametrize("idx", range(len(TINY)))

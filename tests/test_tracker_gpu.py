@@ -82,6 +82,21 @@ def test_bank_capacity_overflow_is_reported():
     assert n[0] == 8 and over[0] == 12
 
 
+def test_single_stream_mirror_grows_instead_of_losing_tracks(golden_dir):
+    """The reference's track list is unbounded; KalmanSortTracker starts this run with a bank of 4 tracks and must
+    grow it (yl_track_grow keeps the state) through the 25-object crowd sequence of the reference fixture."""
+    with open(os.path.join(golden_dir, "tracker.json")) as f:
+        rec = json.load(f)["crowd"]
+    made = []
+
+    def small(**kw):
+        t = KalmanSortTracker(max_tracks=4, **kw)
+        made.append(t)
+        return t
+    check_tracker_sequence(small, rec, box_tol=BOX_TOL)
+    assert made and made[0]._bank.T > 4 and not made[0].stats()[1].any()
+
+
 def test_c_abi_argument_errors():
     """negative yl_status instead of crashes for bad arguments (tracker and evaluation entry points)."""
     import ctypes as C

@@ -28,16 +28,21 @@ if ROOT not in sys.path:
 
 
 def next_run_dir(base: str) -> str:
-    root = Path(base)
-    root.mkdir(parents=True, exist_ok=True)
-    n = 1
+    """runs/<kind>/<n> with the lowest free positive n, created atomically (same observable numbering as
+    /root/reference/tools/infer.py:108-118; concurrent CLI runs cannot share a directory)."""
+    os.makedirs(base, exist_ok=True)
+    taken = {int(e) for e in os.listdir(base) if e.isdigit()}
+    n = 0
     while True:
-        cand = root / str(n)
+        n = next(k for k in range(n + 1, len(taken) + n + 3) if k not in taken)
+        path = os.path.join(base, str(n))
         try:
-            cand.mkdir(parents=False, exist_ok=False)
-            return str(cand.resolve())
-        except FileExistsError:
-            n += 1
+            os.mkdir(path)
+        except FileExistsError:                 # lost a race with another process: it is taken now
+            taken.add(n)
+            n -= 1
+            continue
+        return os.path.realpath(path)
 
 
 def imread_bgr(path: str):

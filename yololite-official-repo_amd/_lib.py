@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # YOLOLITE_HIP_LIB selects another build of the same ABI (kernel A/B runs); default: the in-tree library
 LIB_PATH = os.environ.get("YOLOLITE_HIP_LIB") or os.path.join(_HERE, "libyololite_hip.so")
 
-YL_ABI_VERSION = 1
+YL_ABI_VERSION = 2
 YL_MAX_LEVELS = 8
 YL_OK = 0
 ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
@@ -45,7 +45,8 @@ class yl_model_desc(C.Structure):
 class yl_post_cfg(C.Structure):
     _fields_ = [("mode", C.c_int32), ("conf_thr", C.c_float), ("iou_thr", C.c_float),
                 ("per_class_cap", C.c_int32), ("topk", C.c_int32), ("max_out", C.c_int32),
-                ("center_mode", C.c_int32), ("wh_mode", C.c_int32), ("backmap_dev", C.c_void_p)]
+                ("center_mode", C.c_int32), ("wh_mode", C.c_int32), ("backmap_dev", C.c_void_p),
+                ("fallback_nms", C.c_int32)]
 
 
 # every symbol include/yololite_hip.h declares: (name, restype, argtypes)
@@ -76,6 +77,7 @@ SYMBOLS = [
     ("yl_track_destroy", None, [_vp]),
     ("yl_track_reset", C.c_int32, [_vp, C.c_int32, _vp]),
     ("yl_track_update", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("yl_track_grow", C.c_int32, [_vp, C.c_int32]),
     ("yl_track_stats", C.c_int32, [_vp, _ip, _ip]),
 ]
 

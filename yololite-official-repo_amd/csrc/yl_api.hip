@@ -101,7 +101,8 @@ struct yl_ctx {
 
 namespace {
 
-bool g_inited = false;
+// function attributes (dynamic-LDS opt-ins) are per DEVICE: one flag per device ordinal
+bool g_inited[64] = {false};
 
 yl_status fail(yl_ctx* c, yl_status s, const std::string& msg) {
   if (c) c->err = msg;
@@ -185,7 +186,10 @@ void pack_stem_rows(const float* w, int cout, std::vector<float>& out) {
       }
 }
 
+void drop_graph(yl_ctx* c);
+
 void free_post_ws(yl_ctx* c) {
+  drop_graph(c);                        // cached graphs have the workspace pointers baked in
   hipFree(c->ws_boxes); hipFree(c->ws_scores); hipFree(c->ws_cls); hipFree(c->ws_clsws);
   hipFree(c->ws_kept_list); hipFree(c->ws_done);
   c->ws_kept_list = nullptr; c->ws_done = nullptr;
@@ -478,6 +482,8 @@ yl_status check_cfg(yl_ctx* c, const yl_post_cfg* cfg) {
   if (cfg->max_out <= 0) return fail(c, YL_ERR_INVALID, "max_out must be > 0");
   if (cfg->center_mode < 0 || cfg->center_mode > 1 || cfg->wh_mode < 0 || cfg->wh_mode > 2)
     return fail(c, YL_ERR_INVALID, "bad center/wh mode");
+  if (cfg->fallback_nms != YL_NMS_TORCHVISION && cfg->fallback_nms != YL_NMS_GREEDY)
+    return fail(c, YL_ERR_INVALID, "bad fallback_nms");
   return YL_OK;
 }
 
@@ -499,7 +505,7 @@ yl_status do_post(yl_ctx* c, const float* const* levels_all, int b0, int B, cons
   np.boxes = c->ws_boxes + o; np.scores = c->ws_scores + o; np.cls = c->ws_cls + o;
   np.N = c->N; np.C = c->C > 0 ? c->C : 1;
   np.conf_thr = cfg->conf_thr; np.iou_thr = cfg->iou_thr;
-  np.impl = (cfg->mode == YL_POST_FALLBACK) ? YL_NMS_GREEDY : YL_NMS_TORCHVISION;
+  np.impl = (cfg->mode == YL_POST_FALLBACK && cfg->fallback_nms == YL_NMS_GREEDY) ? YL_NMS_GREEDY : YL_NMS_TORCHVISION;
   np.cap = (cfg->per_class_cap > 0) ? cfg->per_class_cap : INT_MAX;
   np.topk = (cfg->mode == YL_POST_FALLBACK && cfg->topk > 0) ? cfg->topk : 0;
   np.max_out = cfg->max_out;
@@ -738,11 +744,12 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return YL_ERR_HIP;
   if (hipSetDevice(device_id) != hipSuccess) return YL_ERR_HIP;
-  if (!g_inited) {
+  if (device_id >= 64) return YL_ERR_UNSUPPORTED;
+  if (!g_inited[device_id]) {
     if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess || yl_stemblock_init() != hipSuccess ||
         yl_conv_init_bf16() != hipSuccess || yl_stemblock_init_bf16() != hipSuccess)
       return YL_ERR_HIP;
-    g_inited = true;
+    g_inited[device_id] = true;
   }
   yl_ctx* c = new (std::nothrow) yl_ctx();
   if (!c) return YL_ERR_NOMEM;

@@ -376,6 +376,7 @@ void yl_track_destroy(yl_tracker* t) {
 
 yl_status yl_track_reset(yl_tracker* t, int32_t stream_index, void* stream) {
   if (!t || stream_index >= t->S) return YL_ERR_INVALID;
+  if (hipSetDevice(t->device) != hipSuccess) return YL_ERR_HIP;
   hipLaunchKernelGGL(yl_track_reset_kernel, dim3((t->S + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->ntracks,
                      t->next_id, t->overflow, t->S, stream_index);
   return hipGetLastError() == hipSuccess ? YL_OK : YL_ERR_HIP;
@@ -389,12 +390,14 @@ yl_status yl_track_update(yl_tracker* t, const float* dets_dev, const int32_t* c
     return YL_ERR_INVALID;
   const size_t lds = yl_track_lds(t->T, max_out);
   if (lds > 150 * 1024) return YL_ERR_CAPACITY;
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (hipSetDevice(t->device) != hipSuccess) return YL_ERR_HIP;
+  static bool attr_done[64] = {false};                       // the dynamic-LDS opt-in is a per-device attribute
+  if (t->device < 0 || t->device >= 64) return YL_ERR_UNSUPPORTED;
+  if (!attr_done[t->device]) {
     if (hipFuncSetAttribute((const void*)yl_track_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             150 * 1024) != hipSuccess)
       return YL_ERR_HIP;
-    attr_done = true;
+    attr_done[t->device] = true;
   }
   TrackP p;
   p.x0 = t->x[0]; p.P0 = t->P[0]; p.sc0 = t->score[0]; p.m0 = t->meta[0];
@@ -408,8 +411,39 @@ yl_status yl_track_update(yl_tracker* t, const float* dets_dev, const int32_t* c
   return hipGetLastError() == hipSuccess ? YL_OK : YL_ERR_HIP;
 }
 
+// Re-allocates the bank with a larger per-stream capacity and copies every stream's state (synchronises the device).
+// The reference keeps an unbounded python list (tools/tracker.py:166,299-305); the single-stream mirror
+// (tracker.KalmanSortTracker) grows its bank through this call BEFORE an update could overflow.
+yl_status yl_track_grow(yl_tracker* t, int32_t new_max_tracks) {
+  if (!t || new_max_tracks > 4096) return YL_ERR_INVALID;
+  if (new_max_tracks <= t->T) return YL_OK;
+  if (hipSetDevice(t->device) != hipSuccess) return YL_ERR_HIP;
+  if (hipDeviceSynchronize() != hipSuccess) return YL_ERR_HIP;
+  const size_t S = (size_t)t->S, To = (size_t)t->T, Tn = (size_t)new_max_tracks;
+  auto grow = [&](void** ptr, size_t elem_bytes) -> bool {
+    void* nw = nullptr;
+    if (hipMalloc(&nw, S * Tn * elem_bytes) != hipSuccess) return false;
+    if (hipMemset(nw, 0, S * Tn * elem_bytes) != hipSuccess ||
+        hipMemcpy2D(nw, Tn * elem_bytes, *ptr, To * elem_bytes, To * elem_bytes, S, hipMemcpyDeviceToDevice) != hipSuccess) {
+      hipFree(nw);
+      return false;
+    }
+    hipFree(*ptr);
+    *ptr = nw;
+    return true;
+  };
+  for (int k = 0; k < 2; ++k) {
+    if (!grow((void**)&t->x[k], 7 * sizeof(float)) || !grow((void**)&t->P[k], 49 * sizeof(float)) ||
+        !grow((void**)&t->score[k], sizeof(float)) || !grow((void**)&t->meta[k], 5 * sizeof(int)))
+      return YL_ERR_NOMEM;     // arrays already grown keep their (larger) size; T is unchanged, the bank stays valid
+  }
+  t->T = new_max_tracks;
+  return YL_OK;
+}
+
 yl_status yl_track_stats(yl_tracker* t, int32_t* ntracks_host, int32_t* overflow_host) {
   if (!t) return YL_ERR_INVALID;
+  if (hipSetDevice(t->device) != hipSuccess) return YL_ERR_HIP;
   if (hipDeviceSynchronize() != hipSuccess) return YL_ERR_HIP;
   if (ntracks_host && hipMemcpy(ntracks_host, t->ntracks, sizeof(int) * t->S, hipMemcpyDeviceToHost) != hipSuccess)
     return YL_ERR_HIP;

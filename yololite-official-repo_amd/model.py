@@ -161,12 +161,13 @@ class HipContext:
         return {"box": box, "obj": obj, "cls": cls}
 
     def make_cfg(self, mode, conf, iou, per_class_cap, topk, max_out, center_mode="v8", wh_mode="softplus",
-                 backmap: Optional[torch.Tensor] = None):
+                 backmap: Optional[torch.Tensor] = None, fallback_nms: int = _lib.NMS_TORCHVISION):
         cfg = _lib.yl_post_cfg()
         cfg.mode, cfg.conf_thr, cfg.iou_thr = mode, float(conf), float(iou)
         cfg.per_class_cap, cfg.topk, cfg.max_out = int(per_class_cap or 0), int(topk or 0), int(max_out)
         cfg.center_mode, cfg.wh_mode = _lib.CENTER[center_mode], _lib.WH[wh_mode]
         cfg.backmap_dev = backmap.data_ptr() if backmap is not None else None
+        cfg.fallback_nms = int(fallback_nms)
         return cfg
 
     def default_max_out(self, mode, per_class_cap, topk):
@@ -177,7 +178,7 @@ class HipContext:
         return self.N
 
     def postprocess(self, levels, mode, conf, iou, per_class_cap=300, topk=0, max_out=None, center_mode="v8",
-                    wh_mode="softplus", backmap=None, want_idx=False):
+                    wh_mode="softplus", backmap=None, want_idx=False, fallback_nms: int = _lib.NMS_TORCHVISION):
         """Returns dets [B,max_out,6] (x1,y1,x2,y2,score,class), counts [B] (int32, device) and
         optionally the candidate index of every detection."""
         lv = self._check_levels(levels)
@@ -186,7 +187,7 @@ class HipContext:
             max_out = self.default_max_out(mode, per_class_cap, topk)
         if backmap is not None:
             backmap = backmap.to(device=self.device, dtype=torch.float32).contiguous()
-        cfg = self.make_cfg(mode, conf, iou, per_class_cap, topk, max_out, center_mode, wh_mode, backmap)
+        cfg = self.make_cfg(mode, conf, iou, per_class_cap, topk, max_out, center_mode, wh_mode, backmap, fallback_nms)
         dets = torch.empty((B, max_out, 6), device=self.device, dtype=torch.float32)
         counts = torch.empty((B,), device=self.device, dtype=torch.int32)
         idx = torch.empty((B, max_out), device=self.device, dtype=torch.int32) if want_idx else None
@@ -216,14 +217,15 @@ class HipContext:
         return out
 
     def predict(self, x: torch.Tensor, mode, conf, iou, per_class_cap=300, topk=0, max_out=None, backmap=None,
-                out: Optional[tuple] = None, want_idx: bool = False, center_mode="v8", wh_mode="softplus"):
+                out: Optional[tuple] = None, want_idx: bool = False, center_mode="v8", wh_mode="softplus",
+                fallback_nms: int = _lib.NMS_TORCHVISION):
         """Fused forward + post-processing on the context's own level buffers (no raw output copy)."""
         B = x.shape[0]
         if max_out is None:
             max_out = self.default_max_out(mode, per_class_cap, topk)
         if backmap is not None:
             backmap = backmap.to(device=self.device, dtype=torch.float32).contiguous()
-        cfg = self.make_cfg(mode, conf, iou, per_class_cap, topk, max_out, center_mode, wh_mode, backmap)
+        cfg = self.make_cfg(mode, conf, iou, per_class_cap, topk, max_out, center_mode, wh_mode, backmap, fallback_nms)
         if out is None:
             dets = torch.empty((B, max_out, 6), device=self.device, dtype=torch.float32)
             counts = torch.empty((B,), device=self.device, dtype=torch.int32)

@@ -58,12 +58,17 @@ def _split(dets: torch.Tensor, counts: torch.Tensor, max_out: int):
 
 @torch.no_grad()
 def decode_anchorfree_like_train(preds, img_size: int, conf_th: float = 0.35, iou_th: float = 0.60, topk: int = 300,
-                                 center_mode: str = "v8", wh_mode: str = "softplus") -> Dict[str, List[torch.Tensor]]:
+                                 center_mode: str = "v8", wh_mode: str = "softplus",
+                                 nms_impl: str = "torchvision") -> Dict[str, List[torch.Tensor]]:
+    """nms_impl: the primitive behind the reference's nms() (tools/infer.py:134-152) -- "torchvision" (what it
+    runs in an install that has torchvision) or "greedy" (its pure-torch loop, IoU + 1e-6, taken when the import
+    fails; the reference's CLI only reaches this function in that situation)."""
     lv = _levels_list(preds)
     ctx = context_for(lv, img_size)
     max_out = ctx.default_max_out(_lib.POST_FALLBACK, 300, topk)
     dets, counts = ctx.postprocess(lv, _lib.POST_FALLBACK, conf_th, iou_th, per_class_cap=300, topk=topk,
-                                   max_out=max_out, center_mode=center_mode, wh_mode=wh_mode)
+                                   max_out=max_out, center_mode=center_mode, wh_mode=wh_mode,
+                                   fallback_nms=_lib.NMS_TORCHVISION if nms_impl == "torchvision" else _lib.NMS_GREEDY)
     rows = _split(dets, counts, max_out)
     dev = lv[0].device
     return {"boxes": [torch.from_numpy(r[:, :4].copy()).to(dev) for r in rows],

@@ -169,6 +169,51 @@ def synth_state_dict(meta: dict, seed: int = 0, head_noise: float = 0.5) -> Dict
     return dict(sd)
 
 
+# target (mean, std) of the raw head outputs after calibrate_head(): objectness fires on ~3 % of the candidates at
+# conf 0.4, every class is equally likely to carry a candidate's maximum (80 iid rows: max ~ mean + 2.4 std -> a
+# class confidence of ~0.9), boxes are ~3 strides wide so that neighbouring survivors overlap around the NMS
+# threshold
+HEAD_TARGETS = {"obj": (-3.8, 2.0), "cls": (-4.0, 2.5), "tx": (0.0, 1.0), "ty": (0.0, 1.0), "tw": (3.0, 0.7),
+                "th": (3.0, 0.7), "mc": (0.0, 1.0)}
+
+
+def calibrate_head(state_dict: Dict[str, np.ndarray], meta: dict, levels: Sequence[np.ndarray],
+                   targets: Optional[dict] = None) -> Dict[str, np.ndarray]:
+    """Synthetic weights have no training behind them: with the init biases of model_v2.py:7-14 a random model
+    detects nothing, and noise on ONE objectness row / a few class rows makes it fire everywhere or nowhere, in a
+    handful of classes (the head inputs are post-ReLU with seed-dependent channel means).  This gives the head
+    the statistics of a model that detects -- for EVERY seed -- by an exact re-parametrisation of the output
+    convs: `levels` are the raw head outputs [B,A,S,S,5+C(+NM)] of any forward pass with `state_dict` (HIP or
+    oracle) on representative inputs; every output row e of every level gets  w' = w*s/sd_e,
+    b' = (b - mean_e)*s/sd_e + t  so that its logits have mean t and std s (HEAD_TARGETS) on those inputs.
+    Returns a new state_dict (same keys); both the HIP model and the oracle then load the SAME weights."""
+    tg = dict(HEAD_TARGETS, **(targets or {}))
+    cfg = meta.get("config", {}) or {}
+    tcfg, mcfg = cfg.get("training", {}) or {}, cfg.get("model", {}) or {}
+    names = (["2"] if tcfg.get("use_p2") else []) + ["3", "4", "5"] + (["6"] if tcfg.get("use_p6") else [])
+    C = int(meta.get("num_classes") or mcfg.get("num_classes") or 80)
+    NM = int(mcfg.get("num_masks", 32)) if mcfg.get("seg") else 0
+    out = {k: np.array(v, copy=True) for k, v in state_dict.items()}
+    assert len(levels) == len(names)
+    for k, lv in zip(names, levels):
+        lv = np.asarray(lv, np.float64)
+        A, E = lv.shape[1], lv.shape[-1]
+        assert E == 5 + C + NM
+        mu = lv.transpose(1, 4, 0, 2, 3).reshape(A, E, -1).mean(-1)
+        sd_ = lv.transpose(1, 4, 0, 2, 3).reshape(A, E, -1).std(-1) + 1e-12
+        for a in range(A):
+            rows = [("box", 4 * a + j, j, tg[n]) for j, n in enumerate(("tx", "ty", "tw", "th"))]
+            rows += [("obj", a, 4, tg["obj"])]
+            rows += [("cls", C * a + c, 5 + c, tg["cls"]) for c in range(C)]
+            rows += [("mc", NM * a + q, 5 + C + q, tg["mc"]) for q in range(NM)]
+            for conv, r, e, (t, s) in rows:
+                w, b = out[f"head{k}.out.{conv}.weight"], out[f"head{k}.out.{conv}.bias"]
+                g = s / sd_[a, e]
+                b[r] = np.float32((np.float64(b[r]) - mu[a, e]) * g + t)
+                w[r] = (w[r].astype(np.float64) * g).astype(np.float32)
+    return out
+
+
 def make_meta(arch: str, backbone: str, num_classes: int = 80, img_size: int = 640, fpn_channels: int = 128,
               depth_multiple: float = 1.0, width_multiple: float = 1.0, head_depth: int = 1, use_p6: bool = False,
               use_p2: bool = False, anchors: int = 1, names=None, seg: bool = False, num_masks: int = 32,

@@ -34,6 +34,9 @@ class TrackerBank:
         _lib.check(self.lib.yl_track_create(idx, self.S, self.T, float(iou_threshold), int(max_age), int(min_hits),
                                             int(bool(match_by_class)), C.byref(h)), what="yl_track_create")
         self._h = h
+        self._alloc_outputs()
+
+    def _alloc_outputs(self):
         dev = self.device
         self.out_id = torch.zeros((self.S, self.T), dtype=torch.int32, device=dev)
         self.out_cls = torch.zeros((self.S, self.T), dtype=torch.int32, device=dev)
@@ -64,7 +67,16 @@ class TrackerBank:
                                             self.out_count.data_ptr(), self._stream()), what="yl_track_update")
         return self.out_id, self.out_box, self.out_cls, self.out_score, self.out_count
 
+    def grow(self, max_tracks: int):
+        """larger per-stream capacity, state kept (yl_track_grow; synchronises the device)."""
+        if int(max_tracks) > self.T:
+            _lib.check(self.lib.yl_track_grow(self._h, int(max_tracks)), what="yl_track_grow")
+            self.T = int(max_tracks)
+            self._alloc_outputs()
+
     def stats(self):
+        """(tracks alive, tracks LOST to the capacity limit) per stream -- the bank drops new tracks beyond
+        `max_tracks` (the reference's list is unbounded); a non-zero second array means results have diverged."""
         n = (C.c_int32 * self.S)()
         o = (C.c_int32 * self.S)()
         _lib.check(self.lib.yl_track_stats(self._h, n, o), what="yl_track_stats")
@@ -72,7 +84,9 @@ class TrackerBank:
 
 
 class KalmanSortTracker:
-    """Single-stream drop-in for tools/tracker.py:157-326 (same constructor, update(), reset())."""
+    """Single-stream drop-in for tools/tracker.py:157-326 (same constructor, update(), reset()).  The reference's
+    track list is unbounded; the device bank has a capacity, so update() grows it (x2, up to 4096 tracks) whenever
+    tracks alive + detections of the frame could exceed it, and raises if the device still reports lost tracks."""
 
     def __init__(self, iou_threshold: float = 0.3, max_age: int = 15, min_hits: int = 2, match_by_class: bool = True,
                  device="cuda:0", max_tracks: int = 512):
@@ -82,6 +96,10 @@ class KalmanSortTracker:
 
     def reset(self):
         self._bank.reset(-1)
+        self._alive = 0
+
+    def stats(self):
+        return self._bank.stats()
 
     def update(self, boxes, scores, classes):
         n = 0 if boxes is None else len(boxes)
@@ -91,9 +109,19 @@ class KalmanSortTracker:
         d = np.zeros((1, max(n, 1), 6), np.float32)
         d[0, :n, :4], d[0, :n, 4], d[0, :n, 5] = b, s, c
         dev = self._bank.device
+        self._alive = getattr(self, "_alive", 0)
+        if self._alive + n > self._bank.T:                  # every detection may open a track (tracker.py:299-305)
+            need = self._alive + n
+            if need > 4096:
+                raise _lib.YoloLiteHipError(f"KalmanSortTracker: {need} tracks exceed the device bank limit (4096)")
+            self._bank.grow(min(4096, max(2 * self._bank.T, need)))
         ids, box, cls, sc, cnt = self._bank.update(torch.from_numpy(d).to(dev),
                                                    torch.tensor([n], dtype=torch.int32, device=dev))
         k = int(cnt[0].item())
+        alive, lost = self._bank.stats()
+        self._alive = int(alive[0])
+        if int(lost[0]):
+            raise _lib.YoloLiteHipError(f"KalmanSortTracker: {int(lost[0])} tracks lost to the bank capacity")
         ids, box, cls, sc = ids[0, :k].cpu().numpy(), box[0, :k].cpu().numpy(), cls[0, :k].cpu().numpy(), \
             sc[0, :k].cpu().numpy()
         return [{"track_id": int(ids[i]), "bbox": box[i].astype(np.float32), "cls": int(cls[i]),
