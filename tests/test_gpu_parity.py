@@ -186,6 +186,24 @@ def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
     ctx.set_option("lanes", 0); ctx.set_option("batch_levels", 1)
 
 
+@pytest.mark.parametrize("name,B,S", [("edge_n", 3, 320), ("edge_n", 2, 640), ("edge_m", 2, 320), ("yololite_m", 1, 256)])
+def test_dwc_kernel_is_bitwise_the_halo_kernel(name, B, S):
+    """depthwise -> 1x1 layers: the block-cooperative kernel (yl_convc.hip: K split for the depthwise phase, N split
+    with register-resident weights for the GEMM) sums every output's k blocks in the same order as the
+    wave-per-tile halo kernel -> identical bits ("tile_m" 4 switches the cooperative kernel off)."""
+    meta = zoo_meta(name, 80, S)
+    sd = synth_state_dict(meta, seed=4)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    x = _x(B, S, seed=11).to(DEV)
+    a = [t.clone() for t in m(x)]
+    ctx.set_option("tile_m", 4)
+    b = m(x)
+    ctx.set_option("tile_m", 0)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 def test_forward_batch_invariance_and_determinism_full_size():
     """BASELINE config 2 (edge_n 640x640 B=64): bitwise repeatable, and image i of the batch equals the
     same image run alone (size-independent property; the oracle is too slow at this size)."""

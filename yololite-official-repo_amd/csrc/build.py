@@ -17,6 +17,8 @@ UNITS = [   # (source, extra flags, object name)
     ("yl_api.hip", [], "yl_api.o"),
     ("yl_conv.hip", [], "yl_conv.o"),
     ("yl_stemblock.hip", [], "yl_stemblock.o"),
+    ("yl_convc.hip", [], "yl_convc.o"),
+    ("yl_convc.hip", ["-DYL_BF16=1"], "yl_convc_bf16.o"),
     # bf16-MFMA inference mode: the same two units compiled again under distinct symbol names (yl_dev.h)
     ("yl_conv.hip", ["-DYL_BF16=1"], "yl_conv_bf16.o"),
     ("yl_stemblock.hip", ["-DYL_BF16=1"], "yl_stemblock_bf16.o"),
@@ -28,7 +30,7 @@ UNITS = [   # (source, extra flags, object name)
     # tracker: float32 scalar arithmetic of the reference's bbox conversions / IoU, op by op
     ("yl_track.hip", ["-ffp-contract=off"], "yl_track.o"),
 ]
-DEPS = ["yl_internal.h", "yl_dev.h", os.path.join("..", "..", "include", "yololite_hip.h")]
+DEPS = ["yl_internal.h", "yl_dev.h", "yl_epi.h", "yl_decode.h", os.path.join("..", "..", "include", "yololite_hip.h")]
 
 
 def _hipcc():

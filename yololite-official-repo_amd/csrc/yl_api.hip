@@ -747,7 +747,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   if (device_id >= 64) return YL_ERR_UNSUPPORTED;
   if (!g_inited[device_id]) {
     if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess || yl_stemblock_init() != hipSuccess ||
-        yl_conv_init_bf16() != hipSuccess || yl_stemblock_init_bf16() != hipSuccess)
+        yl_conv_init_bf16() != hipSuccess || yl_stemblock_init_bf16() != hipSuccess || yl_convc_init() != hipSuccess ||
+        yl_convc_init_bf16() != hipSuccess)
       return YL_ERR_HIP;
     g_inited[device_id] = true;
   }

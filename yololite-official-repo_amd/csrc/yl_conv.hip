@@ -35,6 +35,7 @@
 #define yl_conv_init yl_conv_init_bf16
 #define yl_uib_supported yl_uib_supported_bf16
 #define yl_uib_lds_bytes yl_uib_lds_bytes_bf16
+#define yl_launch_conv_dwc yl_launch_conv_dwc_bf16
 #endif
 #include <stdio.h>
 #include <stdlib.h>
@@ -46,6 +47,7 @@
 
 #include "yl_dev.h"
 #include "yl_decode.h"
+#include "yl_epi.h"
 
 enum { YL_CM_PW = 0, YL_CM_KXK = 1, YL_CM_DWPRO = 2, YL_CM_DW3 = 3, YL_CM_DW5 = 5 };
 
@@ -53,24 +55,7 @@ enum { YL_CM_PW = 0, YL_CM_KXK = 1, YL_CM_DWPRO = 2, YL_CM_DW3 = 3, YL_CM_DW5 = 
 // B-operand fetch: 4 consecutive input channels [c, c+4) of the lane's pixel for tap (ky,kx).
 // Branch-free: addresses are clamped into the tensor and out-of-range values are zeroed by a select,
 // so the hot loop stays straight-line code (loads issue early, MFMAs back to back).
-struct YlPix {
-  int b, oy, ox;     // output pixel (clamped to a valid pixel for address generation)
-  bool valid;        // false for the padding lanes of the last tile (never stored)
-  size_t lin;        // linear output pixel index (clamped)
-};
-
-// ReLU-family activations as a clamp with wave-uniform bounds; SiLU behind a uniform branch
-__device__ __forceinline__ f32x4 yl_actc(f32x4 v, int act, float lo, float hi) {
-  if (act == YL_ACT_SILU) return yl_act4(v, YL_ACT_SILU);
-  return yl_clamp4(v, lo, hi);
-}
-
-__device__ __forceinline__ f32x4 yl_sel4(bool keep, f32x4 v) {
-  f32x4 r;
-  r.x = keep ? v.x : 0.f; r.y = keep ? v.y : 0.f; r.z = keep ? v.z : 0.f; r.w = keep ? v.w : 0.f;
-  return r;
-}
-
+// (YlPix and the float4 epilogues live in yl_epi.h, shared with yl_convc.hip.)
 template <int MODE>
 __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int ky, int kx, int c,
                                           const float* dwl /*LDS: [taps][Cin] weights then [Cin] bias*/) {
@@ -161,52 +146,6 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
     const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
     s = yl_actc(s, p.dw_act, dlo, dhi);
     return yl_sel4(cin_ok, s);
-  }
-}
-
-// ---- epilogues.  Lane holds channels n..n+3 (n = ntile*16 + 4*kq) of pixel px[mt].
-// ReLU-family activations are a branch-free clamp to [lo,hi] (lo=-inf/0, hi=6/+inf).
-// add_bias = false: the accumulators were initialised with the bias (no residual pre-add in the way)
-template <int NT, int MT>
-__device__ __forceinline__ void yl_epi_fast(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT], int nt0,
-                                            int kq, float lo, float hi, bool add_bias) {
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    if (!px[mt].valid) continue;
-    float* orow = p.out + px[mt].lin * p.N;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = (nt0 + nt) * 16 + 4 * kq;
-      f32x4 v = acc[mt][nt];
-      if (add_bias) v += yl_ld4(p.bias + n);
-      v = yl_clamp4(v, lo, hi);
-      if (n < p.N) *reinterpret_cast<f32x4*>(orow + n) = v;
-    }
-  }
-}
-
-template <int NT, int MT>
-__device__ __forceinline__ void yl_epi_generic(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT],
-                                               int nt0, int kq) {
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    if (!px[mt].valid) continue;
-    const size_t obase = px[mt].lin * p.N;
-    size_t up_off = 0;
-    if (p.up) {
-      const int uy = (px[mt].oy * p.UH) / p.OH, ux = (px[mt].ox * p.UW) / p.OW;
-      up_off = (((size_t)px[mt].b * p.UH + uy) * p.UW + ux) * p.N;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = (nt0 + nt) * 16 + 4 * kq;
-      if (n >= p.N) continue;
-      f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
-      v = yl_act4(v, p.act);
-      if (p.res) v += yl_ld4(p.res + obase + n);
-      if (p.up) v += yl_ld4(p.up + up_off + n);
-      *reinterpret_cast<f32x4*>(p.out + obase + n) = v;
-    }
   }
 }
 
@@ -1248,6 +1187,11 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   for (int k = 0; k < n; ++k)
     halo = halo && (m.p[k].OH & 3) == 0 && (m.p[k].OW & 3) == 0 &&
            (size_t)m.p[k].B * m.p[k].H * m.p[k].W * m.p[k].Cin * 4 < ((size_t)1 << 31);
+  if (halo && tile_hint != 4) {
+    // block-cooperative kernel (yl_convc.hip): 4 waves per 4x4-pixel tile, 1x1 weights resident in registers
+    const hipError_t ec = yl_launch_conv_dwc(m, st);
+    if (ec != hipErrorNotSupported) return ec;
+  }
   if (halo) {
     const int HP = 3 * p.dw_stride + p.dw_k;
     const int PITCHF = ((HP * 16 + 7) / 64) * 64 + 56;

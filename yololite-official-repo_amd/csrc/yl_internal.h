@@ -133,6 +133,11 @@ hipError_t yl_stemblock_init();
 bool yl_stemblock_supported(int c1, int c2, int c3);
 hipError_t yl_conv_init();
 bool yl_uib_supported(int c1, int cmid, int n, int dk);
+// block-cooperative depthwise -> 1x1 kernel (yl_convc.hip); hipErrorNotSupported = shape outside its limits
+hipError_t yl_launch_conv_dwc(YlConvMulti& m, hipStream_t st);
+hipError_t yl_launch_conv_dwc_bf16(YlConvMulti& m, hipStream_t st);
+hipError_t yl_convc_init();
+hipError_t yl_convc_init_bf16();
 // bf16-MFMA builds of yl_conv.hip / yl_stemblock.hip (compiled a second time with -DYL_BF16=1, see yl_dev.h)
 hipError_t yl_launch_conv_bf16(const YlConvP& p, int tile_hint, hipStream_t st);
 hipError_t yl_launch_conv_multi_bf16(const YlConvP* ps, int n, int tile_hint, hipStream_t st);
