@@ -187,21 +187,23 @@ def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_n", 3, 320), ("edge_n", 2, 640), ("edge_m", 2, 320), ("yololite_m", 1, 256)])
-def test_dwc_kernel_is_bitwise_the_halo_kernel(name, B, S):
-    """depthwise -> 1x1 layers: the block-cooperative kernel (yl_convc.hip: K split for the depthwise phase, N split
-    with register-resident weights for the GEMM) sums every output's k blocks in the same order as the
-    wave-per-tile halo kernel -> identical bits ("tile_m" 4 switches the cooperative kernel off)."""
+def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
+    """Alternative kernels of yl_convc.hip sum every output's k blocks in the same order as the kernels they replace
+    -> identical bits.  "tile_m" 6: wave-autonomous 1x1 kernel (default for plain 1x1 layers) OFF; 7: producer /
+    consumer depthwise -> 1x1 kernel (opt-in) ON, with YL_DWC_ALL=1 on every layer shape it supports."""
+    os.environ["YL_DWC_ALL"] = "1"
     meta = zoo_meta(name, 80, S)
     sd = synth_state_dict(meta, seed=4)
     m = _hip_for(meta, sd)
     ctx = m._ctx_for(S)
     x = _x(B, S, seed=11).to(DEV)
     a = [t.clone() for t in m(x)]
-    ctx.set_option("tile_m", 4)
-    b = m(x)
-    ctx.set_option("tile_m", 0)
-    for u, v in zip(a, b):
-        assert torch.equal(u, v)
+    for hint in (6, 7):
+        ctx.set_option("tile_m", hint)
+        b = m(x)
+        ctx.set_option("tile_m", 0)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), hint
 
 
 def test_forward_batch_invariance_and_determinism_full_size():

@@ -36,6 +36,7 @@
 #define yl_uib_supported yl_uib_supported_bf16
 #define yl_uib_lds_bytes yl_uib_lds_bytes_bf16
 #define yl_launch_conv_dwc yl_launch_conv_dwc_bf16
+#define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
 #endif
 #include <stdio.h>
 #include <stdlib.h>
@@ -1181,14 +1182,26 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
     if (n != 1 || gy != 1 || (p.OH & 3) || (p.OW & 3) || p.dw_stride != 1) return hipErrorInvalidValue;
     return yl_uib_dispatch(p, yl_uib_lds_bytes(p.Cin, NT, p.dw_k), st, false, NT, p.dw_k, (p.C1 + 15) / 16);
   }
+  // plain 1x1 layers (N % 4 == 0, single problem): wave-autonomous kernel (yl_convc.hip) -- every wave an independent
+  // 16/32-pixel x <= 4 n-tile item with operands straight from L1/L2, thousands of waves at 8 per SIMD, no LDS
+  // weight prologue, no barrier.  Measured against the persistent LDS kernel (edge_n, B = 64, eager, us): 48->96
+  // @40x40 31 -> 26, 64->256 @20x20 28 -> 23, 64->480 @20x20 45 -> 35, 48->32 @80x80 40 -> 34, lateral3 32->96
+  // @80x80 99 -> 81.  Same k order and epilogues: bit-identical results.  tile_hint 6 switches it off.
+  if (n == 1 && p.dw_k == 0 && p.k == 1 && p.stride == 1 && tile_hint != 6) {
+    const hipError_t ep = yl_launch_conv_pwt(p, st);
+    if (ep != hipErrorNotSupported) return ep;
+  }
   // depthwise prologue with LDS-staged halo tiles (4x4 output pixels per wave)
   bool halo = p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.N & 3) == 0 &&
               tile_hint != 3;
   for (int k = 0; k < n; ++k)
     halo = halo && (m.p[k].OH & 3) == 0 && (m.p[k].OW & 3) == 0 &&
            (size_t)m.p[k].B * m.p[k].H * m.p[k].W * m.p[k].Cin * 4 < ((size_t)1 << 31);
-  if (halo && tile_hint != 4) {
-    // block-cooperative kernel (yl_convc.hip): 4 waves per 4x4-pixel tile, 1x1 weights resident in registers
+  if (halo && tile_hint == 7) {
+    // producer / consumer kernel (yl_convc.hip: 4 depthwise waves + 4 GEMM waves per workgroup, 1x1 weights resident
+    // in registers).  OPT-IN (tile_hint 7): faster in isolation on the K >= 192 layers (28 vs 38 us, 44 vs 50 us at
+    // 20x20, B = 64) but 0.5 % slower in the two-stream pipeline (31.10 k vs 31.27 k images/s): its workgroups
+    // hold ~100-130 KB of LDS and 8 waves per CU, which keeps the other chunk's kernels off those CUs.
     const hipError_t ec = yl_launch_conv_dwc(m, st);
     if (ec != hipErrorNotSupported) return ec;
   }

@@ -20,7 +20,7 @@
 //                      tile -- and it runs the k loop over the shared B fragments, then the epilogue.
 // The serial chain per tile is 4x shorter, 4x as many waves are resident per tile, and because every output
 // still sums its k blocks in ascending order the results are BIT-IDENTICAL to yl_conv_dwh_kernel / the generic
-// conv kernel (tests/test_gpu_parity.py: test_dwc_kernel_is_bitwise_the_halo_kernel).
+// conv kernel (tests/test_gpu_parity.py: test_convc_kernels_are_bitwise_the_kernels_they_replace).
 //
 // Limits (launcher falls back to yl_conv_dwh_kernel otherwise): OH, OW multiples of 4, N % 4 == 0,
 // NTW = ceil(ceil(N/16)/4) <= 5 and ceil(Cin/16) <= KBMAX(NTW) (the register budget of the resident weights).
@@ -28,7 +28,10 @@
 #define yl_conv_dwc_kernel yl_conv_dwc_kernel_bf16
 #define yl_launch_conv_dwc yl_launch_conv_dwc_bf16
 #define yl_convc_init yl_convc_init_bf16
+#define yl_conv_pwt_kernel yl_conv_pwt_kernel_bf16
+#define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
 #endif
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -37,6 +40,22 @@
 #include "yl_epi.h"
 
 #define YL_DWC_LDS_MAX (150 * 1024)
+
+// profiling aid (variant builds only: tools/build_variant.sh stamp yl_convc.hip -DYL_DWC_STAMP=<Cin>): shader-clock
+// stamps of the launches whose Cin matches, [block][wave][32], read back by tools/dwc_stamps.py
+#ifdef YL_DWC_STAMP
+__device__ unsigned long long yl_dwc_stamps[1024 * 8 * 32];
+#define DWC_STAMP(i)                                                                                             \
+  do {                                                                                                           \
+    if (p.Cin == YL_DWC_STAMP && lane == 0 && blockIdx.x < 1024 && (i) < 32)                                     \
+      yl_dwc_stamps[((size_t)blockIdx.x * 8 + wave) * 32 + (i)] = __builtin_readcyclecounter();                 \
+  } while (0)
+extern "C" int yl_debug_dwc_stamps(void* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_dwc_stamps), sizeof(yl_dwc_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define DWC_STAMP(i) do {} while (0)
+#endif
 
 template <int NTW>
 struct YlDwcCfg {
@@ -52,183 +71,421 @@ struct YlDwcCfg {
   const int bx = p.nblk ? (int)blockIdx.x - p.blk0 : (int)blockIdx.x;               \
   const int gx = p.nblk ? p.nblk : (int)gridDim.x;
 
+// patch row pitch in floats (32 channels per pixel): HP pixels + padding chosen so that the 16 lanes of every
+// ds_read_b128 service group -- (row py, pixel pair xh, channel half) combinations -- hit 16 distinct 16-byte slots
+template <int DK, int DS>
+struct YlDwcGeo {
+  static constexpr int HP = 3 * DS + DK;
+  static constexpr int PITCH = DS == 1 ? HP * 32 + ((HP * 128) % 256 == 128 ? 0 : 32) : HP * 32 + 16;
+  static constexpr int HALF_F = HP * PITCH;                    // floats of one half patch (32 channels)
+  static constexpr int RI = (HP + 7) / 8;                      // LDS-DMA instructions per patch row (8 pixels x 128 B each)
+  static constexpr int NDMA = HP * RI;                         // instructions per half patch
+};
+
 template <int DK, int DS, int NTW>
-__global__ __launch_bounds__(256, 2) void yl_conv_dwc_kernel(YlConvMulti mp, int dbuf) {
+__global__ __launch_bounds__(512, 2) void yl_conv_dwc_kernel(YlConvMulti mp) {
   YL_SELECT_PROBLEM_C(mp)
+  using G = YlDwcGeo<DK, DS>;
   constexpr int KBMAX = YlDwcCfg<NTW>::KBMAX;
-  constexpr int HP = 3 * DS + DK;                         // halo edge in pixels
-  constexpr int PITCHF = ((HP * 16 + 7) / 64) * 64 + 56;  // see yl_conv_dwh_kernel: conflict-free tap reads
-  constexpr int HF4 = HP * HP * 4;                        // float4 elements of one halo patch (16 channels)
-  constexpr int NSLOT = (HF4 + 63) / 64;
+  constexpr int HP = G::HP, PITCH = G::PITCH, NR = DS + DK;     // NR: patch columns a lane reads per tap row
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kq = lane >> 4, pl = lane & 15;
+  const bool producer = wave < 4;
   const int KB = p.KB;
-  // LDS carve: [2 or 1][KB][64] float4 B fragments | [DK*DK][Cin] taps, [Cin] bias | 4 halo regions
+  const int NG = (KB + 3) >> 2;                                 // 64-channel groups
+  // LDS carve: [2][KB][64] float4 B fragments | [DK*DK][Cin] taps, [Cin] bias | one half patch per producer wave
   f32x4* bbuf = reinterpret_cast<f32x4*>(yl_clds);
-  float* dwl = yl_clds + (size_t)(dbuf ? 2 : 1) * KB * 256;
-  float* halo = dwl + (((size_t)(DK * DK + 1) * p.Cin + 3) & ~(size_t)3) + wave * (HP * PITCHF);
-  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
-  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
-  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
-  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
-
-  const int tw = p.OW >> 2, th = p.OH >> 2;
+  float* dwl = yl_clds + (size_t)2 * KB * 256;
+  float* halo0 = dwl + (((size_t)(DK * DK + 1) * p.Cin + 3) & ~(size_t)3);
+  // every parameter the loops need, read ONCE: `p` points into the kernel-argument segment (problem selected at
+  // run time), and the compiler re-reads such fields with s_load + s_waitcnt lgkmcnt(0) wherever it runs short of
+  // SGPRs -- inside the tap / copy loops that was most of their time
+  const int Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N, NTtot = p.NTtot, dw_act = p.dw_act;
+  const int pad_t = p.dw_pad_t, pad_l = p.dw_pad_l;
+  const float* const xin = p.x;
+  const long zdelta = p.zeros - p.x;                            // float offset of the zero buffer from the input tensor
+  const int tw = OW >> 2, th = OH >> 2;
   const int tiles_img = tw * th;
   const int ntiles = p.B * tiles_img;
+  // Tiles of this workgroup: t0, t0 + tstride, ... (nmine of them), tile = (image * th + tile row) * tw + tile column.
+  // XCD-aware when the grid allows it (gx % 8 == 0 and, in a level-batched launch, the problem starts at a multiple
+  // of 8): workgroup b runs on XCD b % 8 (observed dispatch order; a different placement changes speed only), and
+  // XCD x owns the contiguous band [x*U/8, (x+1)*U/8) of the U = B * th tile rows -- whole images for B % 8 == 0, the
+  // SAME images in every layer, so the halo overlap of neighbouring tiles and the producer layer's output are found
+  // in this XCD's L2 instead of crossing the fabric from another XCD's.
+  int t0, tstride, nmine;
+  if ((gx & 7) == 0 && ((int)blockIdx.x & 7) == (bx & 7)) {
+    const int U = p.B * th, x = bx & 7, j = bx >> 3, nj = gx >> 3;
+    const int r0 = (int)(((long)U * x) >> 3), r1 = (int)(((long)U * (x + 1)) >> 3);
+    const int cnt = (r1 - r0) * tw;
+    t0 = r0 * tw + j; tstride = nj;
+    nmine = j < cnt ? (cnt - 1 - j) / nj + 1 : 0;
+  } else {
+    t0 = bx; tstride = gx;
+    nmine = bx < ntiles ? (ntiles - 1 - bx) / gx + 1 : 0;
+  }
 
-  // lane constants of the halo staging (as yl_conv_dwh_kernel)
-  int s_lo[NSLOT];
-  bool s_ok[NSLOT];
-#pragma unroll
-  for (int j = 0; j < NSLOT; ++j) {
-    const int e = j * 64 + lane;
-    s_ok[j] = e < HF4;
-    const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
-    const int hr = hp / HP, hc = hp - hr * HP;
-    s_lo[j] = hr * PITCHF + hc * 16 + quad * 4;
+  DWC_STAMP(0);
+  {                                                              // depthwise taps + bias -> LDS (asynchronous)
+    const int nw = DK * DK * Cin;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, 512);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cin, tid, 512);
+    else for (int i = tid; i < Cin; i += 512) dwl[nw + i] = 0.0f;
   }
-  const int rbase = ((pl >> 2) * DS) * PITCHF + ((pl & 3) * DS) * 16 + 4 * kq;
-  constexpr unsigned OOB = 0x80000000u;
-  unsigned goff[NSLOT];
-  auto tile_geom = [&](int tile) {
-    const int b = tile / tiles_img;
-    const int trem = tile - b * tiles_img;
-    const int tyi = trem / tw, txi = trem - tyi * tw;
-    const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * txi * DS - p.dw_pad_l;
-#pragma unroll
-    for (int j = 0; j < NSLOT; ++j) {
-      const int e = j * 64 + lane;
-      const int hp = (e < HF4 ? e : 0) >> 2;
-      const int hr = hp / HP, hc = hp - hr * HP;
-      const int iy = iy0 + hr, ix = ix0 + hc;
-      const bool in = e < HF4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      goff[j] = in ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.Cin + (lane & 3) * 4) * 4) : OOB;
-    }
-  };
-  auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
-    const bool cok = kb * 16 + (lane & 3) * 4 < p.Cin;
-#pragma unroll
-    for (int j = 0; j < NSLOT; ++j) {
-      const unsigned off = cok ? goff[j] + (unsigned)kb * 64u : OOB;
-      r[j] = yl_ld4(off < OOB ? p.x + (off >> 2) : p.zeros);
-    }
-  };
-  auto stage_store = [&](const f32x4 (&r)[NSLOT]) {
-#pragma unroll
-    for (int j = 0; j < NSLOT; ++j)
-      if (s_ok[j]) *reinterpret_cast<f32x4*>(halo + s_lo[j]) = r[j];
-  };
 
-  // ---- once per workgroup: first halo request, depthwise taps -> LDS (asynchronous), this wave's 1x1 weights -> registers
-  f32x4 stg[NSLOT];
-  int tile = bx;
-  const bool p1 = wave < KB;                               // this wave has phase-1 work at all
-  if (tile < ntiles && p1) {
-    tile_geom(tile);
-    stage_load(wave, stg);
-  }
-  {
-    const int nw = DK * DK * p.Cin;
-    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
-    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, p.Cin, tid, 256);
-    else for (int i = tid; i < p.Cin; i += 256) dwl[nw + i] = 0.0f;
-  }
-  const int nt0 = wave * NTW;
-  const bool p2 = nt0 < p.NTtot;                           // this wave owns output channels
-  f32x4 wreg[KBMAX][NTW];
-  {
-    const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
-#pragma unroll
-    for (int kb = 0; kb < KBMAX; ++kb)
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const bool ok = kb < KB && nt0 + nt < p.NTtot;
-        wreg[kb][nt] = ok ? wg[((size_t)kb * p.NTtot + nt0 + nt) * 64 + lane] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-  }
-  const bool pre_add = p.res != nullptr && p.up == nullptr && p.act == YL_ACT_NONE;
-  __syncthreads();                                         // taps are in LDS
-  if (tile < ntiles && p1) stage_store(stg);
-
-  int cur = 0;
-  for (; tile < ntiles; tile += gx) {
-    const int ntile = tile + gx;
-    f32x4* bb = bbuf + (size_t)cur * KB * 64;
-    // ---- phase 1: depthwise on this wave's channel blocks -> shared B fragments
-    for (int kb = wave; kb < KB; kb += 4) {
-      const bool more = kb + 4 < KB;
-      const bool nxt = !more && ntile < ntiles;
-      if (more) stage_load(kb + 4, stg);
-      else if (nxt) { tile_geom(ntile); stage_load(wave, stg); }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // halo writes (all lanes) -> tap reads
-      const int c = kb * 16 + 4 * kq;
-      const int cs = c < p.Cin ? c : p.Cin - 4;
-      f32x4 s = yl_ld4(dwl + DK * DK * p.Cin + cs);
-      if (DK == 3) {
-#pragma unroll
-        for (int dy = 0; dy < DK; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < DK; ++dx) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + dx * 16);
-            const f32x4 w = yl_ld4(dwl + (dy * DK + dx) * p.Cin + cs);
-            s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
-            s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
-          }
-      } else {
-#pragma unroll 1
-        for (int dy = 0; dy < DK; ++dy) {
-#pragma unroll
-          for (int dx = 0; dx < DK; ++dx) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + dx * 16);
-            const f32x4 w = yl_ld4(dwl + (dy * DK + dx) * p.Cin + cs);
-            s.x = fmaf(v.x, w.x, s.x); s.y = fmaf(v.y, w.y, s.y);
-            s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
-          }
-        }
-      }
-      // channel tail (c >= Cin): the packed 1x1 weights of those k slots are zero, no select needed
-      bb[kb * 64 + lane] = yl_actc(s, p.dw_act, dlo, dhi);
-      if (more || nxt) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // this block's tap reads are complete
-        stage_store(stg);
-      }
-    }
-    __syncthreads();                                                   // all B fragments of the tile are in LDS
-    // ---- phase 2: this wave's n-tiles over all channel blocks, weights from registers
-    if (p2) {
+  if (producer) {
+    // =================================================================================== depthwise waves
+    // lane = (output row py, pixel pair xh, 4 of the half group's 32 channels): 2 output pixels per lane, NR float4
+    // patch reads + DK tap reads per tap row.  Steps of a tile: (group g = wave, wave + 4, ...) x (half 0, 1).
+    const int py = lane >> 4, xh = (lane >> 3) & 1, c8 = lane & 7;
+    float* hreg = halo0 + wave * G::HALF_F;
+    const float dlo = (dw_act == YL_ACT_RELU || dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+    const float dhi = (dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+    // half patch (32 channels from c0) of a tile: HP rows x RI float4 per lane (lane = (pixel column lane >> 3 [+ 8q],
+    // 4 channels)), fetched into registers one step ahead and written to the wave's LDS patch right before its taps.
+    // (Asynchronous global->LDS copies were measured first: ~150-230 issue cycles per 1-KiB piece on the issuing wave,
+    // 1200-1900 cycles per half patch -- more than the taps themselves; loads + ds_write_b128 cost a fraction.)
+    // Pixels outside the image and channels beyond Cin come from a zero buffer (the depthwise zero padding).
+    f32x4 stg[HP * G::RI];
+    auto load_half = [&](int tile, int c0) {
       const int b = tile / tiles_img;
       const int trem = tile - b * tiles_img;
       const int tyi = trem / tw, txi = trem - tyi * tw;
-      YlPix px[1];
-      px[0].b = b;
-      px[0].oy = 4 * tyi + (pl >> 2);
-      px[0].ox = 4 * txi + (pl & 3);
-      px[0].valid = true;
-      px[0].lin = ((size_t)b * p.OH + px[0].oy) * p.OW + px[0].ox;
-      f32x4 acc[1][NTW];
+      const int iy0 = 4 * tyi * DS - pad_t, ix0 = 4 * txi * DS - pad_l;
+      const int cc = c0 + (lane & 7) * 4;
+      const bool cok = cc < Cin;
+      const long img = (long)b * H * W * Cin + cc;
+      const long zoff = zdelta + (lane & 7) * 4;
+      long coloff[G::RI];
+      bool colok[G::RI];
+#pragma unroll
+      for (int q = 0; q < G::RI; ++q) {
+        const int ix = ix0 + q * 8 + (lane >> 3);
+        colok[q] = cok && ix >= 0 && ix < W && q * 8 + (lane >> 3) < HP;
+        coloff[q] = img + (long)ix * Cin;
+      }
+#pragma unroll
+      for (int r = 0; r < HP; ++r) {
+        const int iy = iy0 + r;                                   // wave-uniform
+        const bool rowok = iy >= 0 && iy < H;
+        const long rowoff = (long)iy * W * Cin;
+#pragma unroll
+        for (int q = 0; q < G::RI; ++q) {
+          const long off = (rowok && colok[q]) ? rowoff + coloff[q] : zoff;     // select, no branch
+          stg[r * G::RI + q] = yl_ld4(xin + off);
+        }
+      }
+    };
+    auto store_half = [&](float* dst) {
+#pragma unroll
+      for (int r = 0; r < HP; ++r)
+#pragma unroll
+        for (int q = 0; q < G::RI; ++q)
+          if (q * 8 + 7 < HP || q * 8 + (lane >> 3) < HP)
+            *reinterpret_cast<f32x4*>(dst + r * PITCH + q * 256 + lane * 4) = stg[r * G::RI + q];
+    };
+    // step stream of this wave: s = 0, 1, ... over (tile index, group, half)
+    const int gcount = NG > wave ? (NG - 1 - wave) / 4 + 1 : 0;   // groups of this wave per tile
+    auto halves_of = [&](int g) { return (4 * g + 2 < KB) ? 2 : 1; };
+    int st_it = 0, st_gi = 0, st_h = 0;                           // the step whose patch is requested NEXT
+    auto step_valid = [&]() { return gcount > 0 && st_it < nmine; };
+    auto step_c0 = [&]() { return (wave + 4 * st_gi) * 64 + st_h * 32; };
+    auto step_advance = [&]() {
+      if (++st_h >= halves_of(wave + 4 * st_gi)) { st_h = 0; if (++st_gi >= gcount) { st_gi = 0; ++st_it; } }
+    };
+    if (step_valid()) { load_half(t0 + st_it * tstride, step_c0()); step_advance(); }
+    __syncthreads();                                              // taps are in LDS (drains the copy queue once)
+    DWC_STAMP(1);
+    for (int it = 0; it <= nmine; ++it) {
+      if (it < nmine) {
+        f32x4* bb = bbuf + (size_t)(it & 1) * KB * 64;
+        for (int gi = 0; gi < gcount; ++gi) {
+          const int g = wave + 4 * gi;
+          const int nh = halves_of(g);
+          for (int h = 0; h < nh; ++h) {
+            if (it == 2 && gi == 0) DWC_STAMP(20 + 5 * h);
+            store_half(hreg);                                       // this step's patch: registers -> LDS (after the
+            if (it == 2 && gi == 0) DWC_STAMP(21 + 5 * h);          // previous step's tap reads, in LDS order)
+            if (step_valid()) { load_half(t0 + st_it * tstride, step_c0()); step_advance(); }   // next step's patch: in flight under the taps
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // patch writes (all lanes) -> tap reads
+            if (it == 2 && gi == 0) DWC_STAMP(22 + 5 * h);
+            const float* hp_ = hreg;
+            const int c = g * 64 + h * 32 + c8 * 4;
+            const int cs = c < Cin ? c : Cin - 4;
+            const float* tapw = dwl + cs;                            // tap t of this lane's 4 channels: tapw[t * Cin]
+            f32x4 o[2];
+            o[0] = o[1] = yl_ld4(tapw + DK * DK * Cin);
+            const float* hrow = hp_ + (size_t)(py * DS) * PITCH + (2 * xh * DS) * 32 + c8 * 4;
+            // tap rows: row dy+1 is read while row dy is multiplied (two rows of registers; unrolling all DK rows
+            // spills for 5x5)
+            f32x4 vn[NR], wn[DK];
+#pragma unroll
+            for (int x = 0; x < NR; ++x) vn[x] = *reinterpret_cast<const f32x4*>(hrow + x * 32);
+#pragma unroll
+            for (int dx = 0; dx < DK; ++dx) wn[dx] = yl_ld4(tapw + dx * Cin);
+#pragma unroll 1
+            for (int dy = 0; dy < DK; ++dy) {
+              f32x4 v[NR], w[DK];
+#pragma unroll
+              for (int x = 0; x < NR; ++x) v[x] = vn[x];
+#pragma unroll
+              for (int dx = 0; dx < DK; ++dx) w[dx] = wn[dx];
+              if (dy + 1 < DK) {
+#pragma unroll
+                for (int x = 0; x < NR; ++x) vn[x] = *reinterpret_cast<const f32x4*>(hrow + (dy + 1) * PITCH + x * 32);
+#pragma unroll
+                for (int dx = 0; dx < DK; ++dx) wn[dx] = yl_ld4(tapw + ((dy + 1) * DK + dx) * Cin);
+              }
+#pragma unroll
+              for (int dx = 0; dx < DK; ++dx)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                  const f32x4 a = v[j * DS + dx];
+                  o[j].x = fmaf(a.x, w[dx].x, o[j].x); o[j].y = fmaf(a.y, w[dx].y, o[j].y);
+                  o[j].z = fmaf(a.z, w[dx].z, o[j].z); o[j].w = fmaf(a.w, w[dx].w, o[j].w);
+                }
+            }
+            // B fragment of channel block kb: lane (kq = c8 & 3, pixel py*4 + 2*xh + j).  Blocks beyond KB (group
+            // tail) are not stored; channels beyond Cin inside a block meet zero 1x1 weights.
+            if (it == 2 && gi == 0) { asm volatile("" :: "v"(o[0].x), "v"(o[1].x)); DWC_STAMP(23 + 5 * h); }
+            const int kb = 4 * g + 2 * h + (c8 >> 2);
+            if (kb < KB) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                bb[kb * 64 + (c8 & 3) * 16 + py * 4 + 2 * xh + j] = yl_actc(o[j], dw_act, dlo, dhi);
+            }
+            if (it == 2 && gi == 0) DWC_STAMP(24 + 5 * h);
+          }
+        }
+      }
+      DWC_STAMP(2 + 2 * it);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // B fragments written; the patch copy stays in flight
+      __builtin_amdgcn_s_barrier();
+      DWC_STAMP(3 + 2 * it);
+    }
+  } else {
+    // =================================================================================== GEMM waves
+    const int cw = wave - 4;
+    const int kq = lane >> 4, pl = lane & 15;
+    const int nt0 = cw * NTW;
+    const bool p2 = nt0 < NTtot;                                   // this wave owns output channels
+    const float* const resp = p.res;
+    float* const outp = p.out;
+    const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+    const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+    f32x4 wreg[KBMAX][NTW], breg[NTW];
+    {
+      const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
+#pragma unroll
+      for (int kb = 0; kb < KBMAX; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const bool ok = kb < KB && nt0 + nt < NTtot;
+          wreg[kb][nt] = ok ? wg[((size_t)kb * NTtot + nt0 + nt) * 64 + lane] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) breg[nt] = yl_ld4(p.bias + (nt0 + nt) * 16 + 4 * kq);   // bias is padded
+    }
+    const bool pre_add = p.res != nullptr && p.up == nullptr && p.act == YL_ACT_NONE;
+    const bool generic = !pre_add && (p.res || p.up || p.act == YL_ACT_SILU);
+    __syncthreads();
+    DWC_STAMP(1);
+    for (int it = 0; it <= nmine; ++it) {
+      if (it >= 1 && p2) {
+        const int tile = t0 + (it - 1) * tstride;
+        const f32x4* bb = bbuf + (size_t)((it - 1) & 1) * KB * 64;
+        const int b = tile / tiles_img;
+        const int trem = tile - b * tiles_img;
+        const int tyi = trem / tw, txi = trem - tyi * tw;
+        YlPix px[1];
+        px[0].b = b;
+        px[0].oy = 4 * tyi + (pl >> 2);
+        px[0].ox = 4 * txi + (pl & 3);
+        px[0].valid = true;
+        px[0].lin = ((size_t)b * OH + px[0].oy) * OW + px[0].ox;
+        f32x4 acc[1][NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int n = (nt0 + nt) * 16 + 4 * kq;
+          acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (pre_add && n < N) acc[0][nt] = yl_ld4(resp + px[0].lin * N + n);
+        }
+        if (it == 3) { asm volatile("" :: "v"(acc[0][0].x)); DWC_STAMP(20); }
+        // B fragments are read PF channel blocks ahead of their MFMAs (one ds_read_b128 each; the depthwise waves
+        // keep the LDS pipe busy, so a read issued one block ahead returned too late)
+        constexpr int PF = KBMAX < 4 ? KBMAX : 4;
+        f32x4 xr[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) xr[i] = bb[(i < KB ? i : 0) * 64 + lane];
+#pragma unroll
+        for (int kb = 0; kb < KBMAX; ++kb) {
+          if (kb < KB) {
+            f32x4 xq[1];
+            xq[0] = xr[kb % PF];
+            if (kb + PF < KBMAX) xr[kb % PF] = bb[(kb + PF < KB ? kb + PF : 0) * 64 + lane];
+            yl_mma_step<NTW, 1>(wreg[kb], xq, acc);
+          }
+        }
+        if (it == 3) { asm volatile("" :: "v"(acc[0][0].x)); DWC_STAMP(21); }
+        if (generic) yl_epi_generic<NTW, 1>(p, acc, px, nt0, kq);
+        else {                                                      // == yl_epi_fast with the bias from registers
+          float* orow = outp + px[0].lin * N;
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            const int n = (nt0 + nt) * 16 + 4 * kq;
+            const f32x4 v = yl_clamp4(acc[0][nt] + breg[nt], lo, hi);
+            if (n < N) *reinterpret_cast<f32x4*>(orow + n) = v;
+          }
+        }
+      }
+      DWC_STAMP(2 + 2 * it);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this tile's B-fragment reads are complete
+      __builtin_amdgcn_s_barrier();
+      DWC_STAMP(3 + 2 * it);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-autonomous 1x1 convolution for launches whose pixel count cannot fill the chip with 4-wave tiles
+// (40x40 / 20x20 / 10x10 grids).  yl_conv_mfma_kernel (yl_conv.hip) is built for streaming many tiles per
+// workgroup: persistent grid, weight image copied to LDS first, a wave walks all n-tiles of its pixels.  At
+// M = 25 600 pixels that is 400 workgroups that spend their life in the weight prologue and one dependent tile:
+// 25-47 us for layers whose MFMA time is 2-5 us.  Here every WAVE is an independent work item -- 16*MT pixels x
+// NTW n-tiles -- with no LDS and no barrier: the A fragments (weights) and B fragments (activations) come straight
+// from global memory (L1/L2-resident: the 4 waves of a workgroup share one pixel group, all workgroups share the
+// weights), ~70 VGPRs, so 6-8 waves per SIMD cover each other's load latency and MFMA dependency chains, and the
+// launch has thousands of waves instead of a few hundred.  Same k order, same epilogues as yl_conv_mfma_kernel:
+// bit-identical results.
+template <int NTW, int MT>
+__global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvP p, int nchunk) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int item = blockIdx.x * 4 + wave;
+  const int mg = item / nchunk, nc = item - mg * nchunk;
+  const int nt0 = nc * NTW;
+  const int Cin = p.Cin, N = p.N, NTtot = p.NTtot, KB = p.KB, M = p.M;
+  if ((long)mg * (MT * 16) >= M) return;
+  const float* const xin = p.x;
+  const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wp);
+  YlPix px[MT];
+  const float* xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    size_t lin = (size_t)mg * (MT * 16) + mt * 16 + pl;
+    px[mt].valid = lin < (size_t)M;
+    if (!px[mt].valid) lin = (size_t)M - 1;
+    px[mt].lin = lin;
+    px[mt].b = 0; px[mt].oy = 0; px[mt].ox = 0;
+    if (p.up) {                                             // only the nearest-upsample-add epilogue needs coordinates
+      const int ohw = p.OH * p.OW;
+      const int b = (int)(lin / ohw);
+      const int rem = (int)(lin - (size_t)b * ohw);
+      px[mt].b = b;
+      px[mt].oy = rem / p.OW;
+      px[mt].ox = rem - px[mt].oy * p.OW;
+    }
+    xrow[mt] = xin + lin * Cin + 4 * kq;
+  }
+  // n-tiles beyond the layer's last one (partial last chunk): read the last tile's weights, never stored
+  int wofs[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) wofs[nt] = ((nt0 + nt < NTtot ? nt0 + nt : NTtot - 1) * 64 + lane);
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // residual / upsample-add without activation: the addends initialise the accumulators (as yl_conv_mfma_kernel)
+  const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE;
+  if (pre_add) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const size_t obase = px[mt].lin * N;
+      size_t up_off = 0;
+      if (p.up) {
+        const int uy = (px[mt].oy * p.UH) / p.OH, ux = (px[mt].ox * p.UW) / p.OW;
+        up_off = (((size_t)px[mt].b * p.UH + uy) * p.UW + ux) * N;
+      }
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const int n = (nt0 + nt) * 16 + 4 * kq;
-        acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (pre_add && n < p.N) acc[0][nt] = yl_ld4(p.res + px[0].lin * p.N + n);
-      }
-      f32x4 xn = bb[lane];
-#pragma unroll
-      for (int kb = 0; kb < KBMAX; ++kb) {
-        if (kb < KB) {
-          f32x4 xq[1];
-          xq[0] = xn;
-          if (kb + 1 < KBMAX && kb + 1 < KB) xn = bb[(kb + 1) * 64 + lane];
-          yl_mma_step<NTW, 1>(wreg[kb], xq, acc);
+        if (n < N) {
+          if (p.res) acc[mt][nt] = yl_ld4(p.res + obase + n);
+          if (p.up) acc[mt][nt] += yl_ld4(p.up + up_off + n);
         }
       }
-      if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NTW, 1>(p, acc, px, nt0, kq);
-      else yl_epi_fast<NTW, 1>(p, acc, px, nt0, kq, lo, hi, true);
     }
-    if (dbuf) cur ^= 1;
-    else __syncthreads();                                              // single buffer: reads done before the next tile's writes
+  }
+  constexpr int UK = 2;
+  const int cin4 = Cin - 4;
+#if defined(YL_PWT_EXP) && YL_PWT_EXP >= 2        // timing experiment: no loads / MFMAs (results WRONG)
+  for (int kb0 = 0; kb0 < 0; kb0 += UK) {
+#else
+  for (int kb0 = 0; kb0 < KB; kb0 += UK) {
+#endif
+    f32x4 a[UK][NTW], bq[UK][MT];
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const int kb = kb0 + u < KB ? kb0 + u : KB - 1;       // odd KB: the tail step re-reads the last block, unused
+      const int c = kb * 16 + 4 * kq;
+      const bool cok = c < Cin;                              // channel tail of the last block: zero activations
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) a[u][nt] = wg[(size_t)kb * NTtot * 64 + wofs[nt]];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bq[u][mt] = yl_ld4(cok ? xrow[mt] + kb * 16 : p.zeros);
+    }
+    (void)cin4;
+#pragma unroll
+    for (int u = 0; u < UK; ++u)
+      if (kb0 + u < KB) yl_mma_step<NTW, MT>(a[u], bq[u], acc);
+  }
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+#if defined(YL_PWT_EXP) && YL_PWT_EXP == 3        // timing experiment: same bytes, every store instruction 1 KiB contiguous (WRONG layout)
+  {
+    float* o = p.out + ((size_t)mg * MT * 16) * N + (size_t)nt0 * 16 * (MT * 16);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) *reinterpret_cast<f32x4*>(o + ((mt * NTW + nt) * 64 + lane) * 4) = acc[mt][nt];
+    return;
+  }
+#endif
+#if defined(YL_PWT_EXP) && YL_PWT_EXP == 1        // timing experiment: no stores (results WRONG)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(acc[mt][nt].x), "v"(acc[mt][nt].y), "v"(acc[mt][nt].z), "v"(acc[mt][nt].w));
+  return;
+#endif
+  if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NTW, MT>(p, acc, px, nt0, kq);
+  else yl_epi_fast<NTW, MT>(p, acc, px, nt0, kq, lo, hi, true);
+}
+
+template <int NTW, int MT>
+static hipError_t pwt_go(const YlConvP& p, int nchunk, hipStream_t st) {
+  const long groups = ((long)p.M + MT * 16 - 1) / (MT * 16);
+  const long items = groups * nchunk;
+  hipLaunchKernelGGL((yl_conv_pwt_kernel<NTW, MT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p, nchunk);
+  return hipGetLastError();
+}
+
+// plain 1x1 stride-1 conv, N % 4 == 0, no depthwise prologue, not a head layer.  hipErrorNotSupported otherwise.
+hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st) {
+  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.in_shift) return hipErrorNotSupported;
+  const int NT = p.NTtot;
+  // n-tiles per wave: as many as 4 (the activations are fetched once per wave), chunks of equal size
+  int ntw = NT <= 4 ? NT : (NT % 4 == 0 ? 4 : (NT % 3 == 0 ? 3 : 4));
+  const int nchunk = (NT + ntw - 1) / ntw;
+  const bool two = p.M >= 65536;                                // two m-tiles per wave halve the weight traffic
+  switch (ntw) {
+    case 1: return two ? pwt_go<1, 2>(p, nchunk, st) : pwt_go<1, 1>(p, nchunk, st);
+    case 2: return two ? pwt_go<2, 2>(p, nchunk, st) : pwt_go<2, 1>(p, nchunk, st);
+    case 3: return two ? pwt_go<3, 2>(p, nchunk, st) : pwt_go<3, 1>(p, nchunk, st);
+    default: return two ? pwt_go<4, 2>(p, nchunk, st) : pwt_go<4, 1>(p, nchunk, st);
   }
 }
 
@@ -244,41 +501,41 @@ int yl_resident_blocks_c(K kernel, size_t lds) {
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, 256, lds) != hipSuccess || nb < 1) nb = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, 512, lds) != hipSuccess || nb < 1) nb = 1;
   if (nb > 4) nb = 4;
   cache[key] = nb * YL_NUM_CU;
   return nb * YL_NUM_CU;
 }
 
 template <int DK, int DS, int NTW>
-hipError_t dwc_one(const YlConvMulti& m, int gx, size_t lds, int dbuf, hipStream_t st, bool attr_only, int* resident) {
+hipError_t dwc_one(const YlConvMulti& m, int gx, size_t lds, hipStream_t st, bool attr_only, int* resident) {
   if (attr_only)
     return hipFuncSetAttribute((const void*)yl_conv_dwc_kernel<DK, DS, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                YL_DWC_LDS_MAX);
   if (resident) { *resident = yl_resident_blocks_c(yl_conv_dwc_kernel<DK, DS, NTW>, lds); return hipSuccess; }
-  hipLaunchKernelGGL((yl_conv_dwc_kernel<DK, DS, NTW>), dim3(gx), dim3(256), lds, st, m, dbuf);
+  hipLaunchKernelGGL((yl_conv_dwc_kernel<DK, DS, NTW>), dim3(gx), dim3(512), lds, st, m);
   return hipGetLastError();
 }
 
 template <int NTW>
-hipError_t dwc_dk(const YlConvMulti& m, int dk, int ds, int gx, size_t lds, int dbuf, hipStream_t st, bool attr_only,
+hipError_t dwc_dk(const YlConvMulti& m, int dk, int ds, int gx, size_t lds, hipStream_t st, bool attr_only,
                   int* resident) {
   hipError_t e = hipSuccess;
-  if (attr_only || (dk == 3 && ds == 1)) { e = dwc_one<3, 1, NTW>(m, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
-  if (attr_only || (dk == 3 && ds == 2)) { e = dwc_one<3, 2, NTW>(m, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
-  if (attr_only || (dk == 5 && ds == 1)) { e = dwc_one<5, 1, NTW>(m, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
-  if (attr_only || (dk == 5 && ds == 2)) { e = dwc_one<5, 2, NTW>(m, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || (dk == 3 && ds == 1)) { e = dwc_one<3, 1, NTW>(m, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || (dk == 3 && ds == 2)) { e = dwc_one<3, 2, NTW>(m, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || (dk == 5 && ds == 1)) { e = dwc_one<5, 1, NTW>(m, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || (dk == 5 && ds == 2)) { e = dwc_one<5, 2, NTW>(m, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
   return attr_only ? hipSuccess : hipErrorInvalidValue;
 }
 
-hipError_t dwc_any(const YlConvMulti& m, int ntw, int dk, int ds, int gx, size_t lds, int dbuf, hipStream_t st,
+hipError_t dwc_any(const YlConvMulti& m, int ntw, int dk, int ds, int gx, size_t lds, hipStream_t st,
                    bool attr_only, int* resident) {
   hipError_t e = hipSuccess;
-  if (attr_only || ntw == 1) { e = dwc_dk<1>(m, dk, ds, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
-  if (attr_only || ntw == 2) { e = dwc_dk<2>(m, dk, ds, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
-  if (attr_only || ntw == 3) { e = dwc_dk<3>(m, dk, ds, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
-  if (attr_only || ntw == 4) { e = dwc_dk<4>(m, dk, ds, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
-  if (attr_only || ntw == 5) { e = dwc_dk<5>(m, dk, ds, gx, lds, dbuf, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || ntw == 1) { e = dwc_dk<1>(m, dk, ds, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || ntw == 2) { e = dwc_dk<2>(m, dk, ds, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || ntw == 3) { e = dwc_dk<3>(m, dk, ds, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || ntw == 4) { e = dwc_dk<4>(m, dk, ds, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
+  if (attr_only || ntw == 5) { e = dwc_dk<5>(m, dk, ds, gx, lds, st, attr_only, resident); if (!attr_only || e != hipSuccess) return e; }
   return attr_only ? hipSuccess : hipErrorInvalidValue;
 }
 
@@ -288,7 +545,7 @@ int kbmax_of(int ntw) { return ntw == 1 ? 18 : ntw == 2 ? 9 : ntw == 3 ? 6 : 4; 
 
 hipError_t yl_convc_init() {
   YlConvMulti m = {};
-  return dwc_any(m, 0, 0, 0, 0, 0, 0, nullptr, true, nullptr);
+  return dwc_any(m, 0, 0, 0, 0, 0, nullptr, true, nullptr);
 }
 
 // n problems of identical configuration (m.p[0..n-1] filled like for yl_conv_dwh_kernel).  Returns
@@ -297,16 +554,18 @@ hipError_t yl_launch_conv_dwc(YlConvMulti& m, hipStream_t st) {
   const YlConvP& p = m.p[0];
   const int ntw = (p.NTtot + 3) / 4;
   if (ntw < 1 || ntw > 5 || p.KB > kbmax_of(ntw) || (p.N & 3)) return hipErrorNotSupported;
+  // Measured per layer (edge_n, B = 64, eager): the producer / consumer split pays where the depthwise phase is
+  // long -- K >= 192 channels on a stride-1 depthwise (28 vs 38 us for 3x3, 44 vs 50 us for 5x5 at 20x20) -- and
+  // loses on the short-K layers, where two or three of the four depthwise waves idle and the per-tile barrier costs
+  // more than the weight prologue it replaces.  YL_DWC_ALL=1 lifts the restriction (A/B runs).
+  static const bool all = getenv("YL_DWC_ALL") != nullptr;
+  if (!all && (p.KB < 12 || p.dw_stride != 1)) return hipErrorNotSupported;
   if (!((p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2))) return hipErrorNotSupported;
   const int HP = 3 * p.dw_stride + p.dw_k;
-  const int PITCHF = ((HP * 16 + 7) / 64) * 64 + 56;
-  const size_t fixed = ((((size_t)(p.dw_k * p.dw_k + 1) * p.Cin + 3) & ~(size_t)3) + (size_t)4 * HP * PITCHF) * 4;
-  const size_t bb = (size_t)p.KB * 1024;
-  // double-buffered B fragments (one barrier per tile) unless that costs a resident workgroup per CU
-  int dbuf = 1;
-  size_t lds = fixed + 2 * bb;
-  const size_t budget = 160 * 1024;
-  if (lds > YL_DWC_LDS_MAX || budget / lds < budget / (fixed + bb) ) { dbuf = 0; lds = fixed + bb; }
+  const int NG = (p.KB + 3) / 4;
+  const int PITCH = p.dw_stride == 1 ? HP * 32 + ((HP * 128) % 256 == 128 ? 0 : 32) : HP * 32 + 16;   // YlDwcGeo
+  const size_t lds = ((size_t)2 * p.KB * 256 + (((size_t)(p.dw_k * p.dw_k + 1) * p.Cin + 3) & ~(size_t)3) +
+                      (size_t)(NG < 4 ? NG : 4) * HP * PITCH) * 4;
   if (lds > YL_DWC_LDS_MAX) return hipErrorNotSupported;
   long tiles[4], total = 0;
   for (int k = 0; k < m.n; ++k) {
@@ -316,26 +575,23 @@ hipError_t yl_launch_conv_dwc(YlConvMulti& m, hipStream_t st) {
     total += tiles[k];
   }
   int res = 0;
-  hipError_t e = dwc_any(m, ntw, p.dw_k, p.dw_stride, 0, lds, dbuf, st, false, &res);
+  hipError_t e = dwc_any(m, ntw, p.dw_k, p.dw_stride, 0, lds, st, false, &res);
   if (e != hipSuccess) return e;
-  // every workgroup gets the same number of tiles (+-1): grid = tiles / rounds
-  long gx = total;
-  if (gx > res) {
-    const long rounds = (total + res - 1) / res;
-    gx = (total + rounds - 1) / rounds;
-  }
+  // grid: a multiple of 8 workgroups (XCD-aware tile bands, see the kernel), at most what is co-resident
+  long gx = (total + 7) & ~7L;
+  if (gx > res) gx = res & ~7L;
+  if (gx < 8) gx = 8;
   if (m.n == 1) { m.p[0].blk0 = 0; m.p[0].nblk = 0; }
   else {
     int at = 0;
     for (int k = 0; k < m.n; ++k) {
-      long nb = (tiles[k] * gx + total / 2) / total;
-      if (nb < 1) nb = 1;
-      if (nb > tiles[k]) nb = tiles[k];
+      long nb = ((tiles[k] * gx + total / 2) / total + 7) & ~7L;
+      if (nb < 8) nb = 8;
       m.p[k].blk0 = at;
       m.p[k].nblk = (int)nb;
       at += (int)nb;
     }
     gx = at;
   }
-  return dwc_any(m, ntw, p.dw_k, p.dw_stride, (int)gx, lds, dbuf, st, false, nullptr);
+  return dwc_any(m, ntw, p.dw_k, p.dw_stride, (int)gx, lds, st, false, nullptr);
 }

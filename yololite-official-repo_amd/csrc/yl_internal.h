@@ -136,6 +136,9 @@ bool yl_uib_supported(int c1, int cmid, int n, int dk);
 // block-cooperative depthwise -> 1x1 kernel (yl_convc.hip); hipErrorNotSupported = shape outside its limits
 hipError_t yl_launch_conv_dwc(YlConvMulti& m, hipStream_t st);
 hipError_t yl_launch_conv_dwc_bf16(YlConvMulti& m, hipStream_t st);
+// wave-autonomous 1x1 conv for small pixel counts (yl_convc.hip); hipErrorNotSupported = not a plain 1x1 layer
+hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv_pwt_bf16(const YlConvP& p, hipStream_t st);
 hipError_t yl_convc_init();
 hipError_t yl_convc_init_bf16();
 // bf16-MFMA builds of yl_conv.hip / yl_stemblock.hip (compiled a second time with -DYL_BF16=1, see yl_dev.h)
