@@ -165,7 +165,12 @@ yl_status yl_forward(yl_ctx* ctx, const float* x_dev, int32_t batch, float* cons
  * per-layer durations (ms) in layer_ms[num_layers].  Measurement aid for bench.py (roofline).      */
 yl_status yl_forward_timed(yl_ctx* ctx, const float* x_dev, int32_t batch, float* const* level_out_dev,
                            void* stream, float* layer_ms);
-/* Copies activation slot `slot` (NHWC fp32, [B,h,w,c]) of the last forward to dst_dev (testing aid). */
+/* Bytes of activation memory the context holds for the batch of its last forward / predict call (one arena per
+ * batch chunk, tensors placed by liveness; see option "reuse_slots").  0 before the first call. */
+int64_t yl_activation_bytes(const yl_ctx* ctx);
+/* Copies activation slot `slot` (NHWC fp32, [B,h,w,c]) of the last forward to dst_dev (testing aid).  With option
+ * "reuse_slots" on (default) only tensors that are outputs of the network (mask prototypes) are guaranteed to still
+ * hold their values after the call; set the option to 0 to inspect intermediate tensors. */
 yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev, void* stream);
 /* Options: "graph" (0/1: replay the whole call from a captured hipGraph), "streams" (1..4 internal
  * streams the batch is split over; default 2), "tile_m" (conv M-tile hint), "lanes" (0/1, default 0: neck/head
@@ -176,6 +181,8 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * head outputs of all pyramid levels in one launch each),
  * "fuse_decode" (0/1, default 1: yl_predict decodes inside the head-output convs; the raw level tensors are
  * then NOT materialised unless the model has mask coefficients),
+ * "reuse_slots" (0/1, default 1: activation tensors share memory by liveness inside one arena per batch chunk;
+ * 0 keeps every tensor of the forward pass),
  * "mfma_bf16" (0/1, default 0: SURVEY 8(f) f4 reduced-precision inference mode -- conv operands are rounded
  * to bf16 in registers and multiplied on v_mfma_f32_16x16x16_bf16 with fp32 accumulation; tensors stay
  * fp32 in memory.  The reference's counterpart is fp16 autocast in evaluate_model

@@ -379,6 +379,44 @@ def test_predict_fused_equals_forward_plus_postprocess_and_graph():
     ctx.set_option("graph", 0)
 
 
+@pytest.mark.parametrize("name,seg", [("edge_n", False), ("edge_m", True), ("yololite_m", False)])
+def test_liveness_slot_reuse_is_bitwise_and_smaller(name, seg):
+    """activation tensors placed by liveness in one arena per batch chunk (default) vs one buffer per tensor:
+    same bits (levels, detections, prototypes, masks), a fraction of the memory."""
+    from yololite_amd.program import MODEL_ZOO
+    S, B = 256, 16
+    meta = make_meta(num_classes=80, img_size=S, seg=seg, **MODEL_ZOO[name])
+    sd = synth_state_dict(meta, seed={"edge_n": 2, "edge_m": 9, "yololite_m": 10}[name], head_noise=2.0)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    x = _x(B, S, seed=2).to(DEV)
+    res, mem = {}, {}
+    for reuse in (1, 0):
+        ctx.set_option("reuse_slots", reuse)
+        for streams in (1, 2):
+            ctx.set_option("streams", streams)
+            out = m(x)
+            lv = [t.clone() for t in (out[0] if seg else out)]
+            pr = out[1].clone() if seg else None
+            d, c, idx = ctx.predict(x, _lib.POST_MAIN, 0.01, 0.5, per_class_cap=300, max_out=512, want_idx=True)
+            mk = ctx.masks(c, idx, 512).clone() if seg else None
+            res[(reuse, streams)] = (lv, pr, d.clone(), c.clone(), mk)
+            mem[(reuse, streams)] = ctx.activation_bytes()
+    ref = res[(0, 1)]
+    assert int(ref[3].sum()) > 0
+    for k, v in res.items():
+        for a, b in zip(v[0], ref[0]):
+            assert torch.equal(a, b), k
+        assert torch.equal(v[3], ref[3]), k
+        for b in range(B):
+            n = min(int(ref[3][b]), 512)
+            assert torch.equal(v[2][b, :n], ref[2][b, :n]), k
+        if seg:
+            assert torch.equal(v[1], ref[1]) and torch.equal(v[4], ref[4]), k
+    assert mem[(1, 2)] * 3 < mem[(0, 2)], mem
+    ctx.set_option("reuse_slots", 1); ctx.set_option("streams", 2)
+
+
 def test_cached_graph_survives_post_workspace_growth():
     """forward(B=16) sizes the activations only; predict(B=4) captures a graph with the post workspaces of a
     4-image batch baked in; predict(B=16) reallocates those workspaces WITHOUT growing the activations; the next

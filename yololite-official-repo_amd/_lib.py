@@ -60,6 +60,7 @@ SYMBOLS = [
     ("yl_abi_version", C.c_int32, []),
     ("yl_forward", C.c_int32, [_vp, _vp, C.c_int32, _vpp, _vp]),
     ("yl_forward_timed", C.c_int32, [_vp, _vp, C.c_int32, _vpp, _vp, _fp]),
+    ("yl_activation_bytes", C.c_int64, [_vp]),
     ("yl_read_slot", C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     ("yl_set_option", C.c_int32, [_vp, C.c_char_p, C.c_int32]),
     ("yl_preprocess", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),

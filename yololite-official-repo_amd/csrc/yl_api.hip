@@ -7,6 +7,7 @@
 #include <stddef.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -30,7 +31,10 @@ struct DevLayer {
 
 struct Slot {
   int h, w, c;
-  float* ptr = nullptr;
+  size_t sz = 0;         // bytes per image
+  size_t off = 0;        // byte offset of the slot inside a chunk arena, per image of the chunk (x chunk capacity)
+  bool pinned = false;   // whole-batch contiguous allocation of its own (tensors the ABI hands out: mask prototypes)
+  float* pin = nullptr;
 };
 
 }  // namespace
@@ -44,7 +48,18 @@ struct yl_ctx {
   std::vector<Slot> slots;
   std::vector<DevLayer> layers;
   float* zeros = nullptr;                  // 256 zero bytes (padding source for the conv kernels)
-  int cap_batch = 0;                       // activations / workspaces are sized for this batch
+  int cap_batch = 0;                       // activations are planned for exactly this batch ...
+  // Activation memory: ONE arena per batch chunk (chunks run concurrently on their own streams), slots placed by
+  // liveness -- a slot's bytes are reused by later tensors once its last consumer (launch group) has run.  edge_n,
+  // B = 64: 3.8 GB with one buffer per tensor -> a few hundred MB, so that a chunk's producer -> consumer pairs have
+  // a chance to meet in the 256 MB Infinity Cache instead of HBM.  "reuse_slots" 0 keeps every tensor (debugging).
+  char* arena[4] = {nullptr, nullptr, nullptr, nullptr};
+  int plan_n = 0;                          // ... split into this many chunks
+  int plan_b0[5] = {0, 0, 0, 0, 0};        // chunk i covers images [plan_b0[i], plan_b0[i + 1])
+  int plan_cap = 0;                        // images of the largest chunk
+  size_t arena_unit = 0;                   // arena bytes per image of a chunk (peak of the live set)
+  bool plan_reuse = false;
+  int opt_reuse = 1;
   float* level_buf[YL_MAX_LEVELS] = {nullptr};
   // post-processing workspace
   float4* ws_boxes = nullptr;
@@ -208,23 +223,136 @@ void drop_graph(yl_ctx* c) {
 
 void free_act(yl_ctx* c) {
   drop_graph(c);
-  for (auto& s : c->slots) { hipFree(s.ptr); s.ptr = nullptr; }
+  for (int i = 0; i < 4; ++i) { hipFree(c->arena[i]); c->arena[i] = nullptr; }
+  for (auto& s : c->slots) { hipFree(s.pin); s.pin = nullptr; }
   for (int l = 0; l < YL_MAX_LEVELS; ++l) { hipFree(c->level_buf[l]); c->level_buf[l] = nullptr; }
-  c->cap_batch = 0;
+  c->cap_batch = 0; c->plan_n = 0;
 }
 
 int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
 
-yl_status ensure_act(yl_ctx* c, int B) {
-  if (B <= c->cap_batch) return YL_OK;
+// layers [i, end) that run_layers sends out as ONE launch (level-batched heads / smooth blocks): same kernel
+// configuration, no residual / upsample operands, no dependency inside the run
+size_t layer_group_end(const yl_ctx* c, size_t i, size_t lend) {
+  auto same_shape = [&](size_t x, size_t y) {
+    const yl_layer& a = c->layers[x].d; const yl_layer& e = c->layers[y].d;
+    return a.op == YL_OP_CONV && e.op == YL_OP_CONV && a.cin == e.cin && a.cout == e.cout && a.k == e.k &&
+           a.stride == e.stride && a.pad_t == e.pad_t && a.pad_l == e.pad_l && a.act == e.act &&
+           a.in_shift == e.in_shift && a.dw_k == e.dw_k && a.dw_stride == e.dw_stride && a.dw_pad_t == e.dw_pad_t &&
+           a.dw_pad_l == e.dw_pad_l && a.dw_act == e.dw_act && a.c2 == 0 && e.c2 == 0 && a.res_slot < 0 &&
+           e.res_slot < 0 && a.up_slot < 0 && e.up_slot < 0 && (a.head_level >= 0) == (e.head_level >= 0) &&
+           (a.cout + 15) / 16 <= 8;
+  };
+  size_t gend = i + 1;
+  if (c->layers[i].d.op != YL_OP_CONV) return gend;
+  while (gend < lend && gend - i < 4 && same_shape(i, gend)) {
+    bool dep = false;
+    for (size_t q = i; q < gend; ++q)
+      if (c->layers[q].d.head_level < 0 && c->layers[q].d.out_slot == c->layers[gend].d.in_slot) dep = true;
+    if (dep) break;
+    ++gend;
+  }
+  return gend;
+}
+
+// Place the slots inside a chunk arena.  Liveness is tracked per LAUNCH GROUP (a level-batched run reads and writes
+// all of its layers' tensors at once): slot s is live from the group that produces it to the group of its last
+// consumer, inclusive; first-fit over the gaps of the live set.  reuse == false: every slot gets its own range.
+void plan_slots(yl_ctx* c, bool reuse) {
+  const size_t NL = c->layers.size(), NS = c->slots.size();
+  std::vector<int> grp(NL, 0);
+  int g = 0;
+  for (size_t i = 0; i < NL; ++g) {
+    const size_t e = layer_group_end(c, i, NL);
+    for (size_t q = i; q < e; ++q) grp[q] = g;
+    i = e;
+  }
+  const int INF = 1 << 30;
+  std::vector<int> def(NS, INF), last(NS, -1);
+  for (size_t i = 0; i < NL; ++i) {
+    const yl_layer& d = c->layers[i].d;
+    if (d.head_level < 0 && d.out_slot >= 0 && grp[i] < def[d.out_slot]) def[d.out_slot] = grp[i];
+    const int ins[3] = {(d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? -1 : d.in_slot, d.res_slot, d.up_slot};
+    for (int k = 0; k < 3; ++k)
+      if (ins[k] >= 0 && grp[i] > last[ins[k]]) last[ins[k]] = grp[i];
+  }
+  for (size_t s = 0; s < NS; ++s) {
+    Slot& t = c->slots[s];
+    t.sz = (size_t)t.h * t.w * t.c * sizeof(float);                   // images of a slot are contiguous (a multiple of 16 B)
+    t.pinned = (int)s == c->proto_slot;
+    if (last[s] < def[s]) last[s] = def[s] == INF ? -1 : def[s];     // produced, never consumed: live in its own group
+  }
+  struct Iv { size_t off, sz; int last; };
+  std::vector<Iv> live;
+  size_t peak = 0;
+  std::vector<size_t> order;
+  for (size_t s = 0; s < NS; ++s) if (!c->slots[s].pinned && def[s] != INF) order.push_back(s);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return def[a] < def[b]; });
+  size_t bump = 0;
+  for (size_t s : order) {
+    Slot& t = c->slots[s];
+    const size_t need = (t.sz + 255) & ~(size_t)255;                  // placement granule: slot bases stay 256-B aligned
+    if (!reuse) { t.off = bump; bump += need; peak = bump; continue; }
+    live.erase(std::remove_if(live.begin(), live.end(), [&](const Iv& v) { return v.last < def[s]; }), live.end());
+    std::sort(live.begin(), live.end(), [](const Iv& a, const Iv& b) { return a.off < b.off; });
+    size_t at = 0;
+    for (const Iv& v : live) {
+      if (at + need <= v.off) break;
+      if (v.off + v.sz > at) at = v.off + v.sz;
+    }
+    t.off = at;
+    live.push_back({at, need, last[s]});
+    if (at + need > peak) peak = at + need;
+  }
+  c->arena_unit = peak;
+}
+
+// number of batch chunks a job of B images is split into (submit / walk_plan)
+int chunks_for(const yl_ctx* c, int B) {
+  int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
+  if (B < 4 * n) n = 1;
+  return n;
+}
+
+// activations for a batch of B images processed as n chunks (the split walk_plan uses), one arena per chunk.
+// The hybrid plan mixes full-batch and chunked segments and the side-lane option runs layers of one chunk
+// concurrently: both get ONE arena with every tensor kept (any image range addressable, nothing reused).
+yl_status ensure_act(yl_ctx* c, int B, int n) {
+  const bool flat = c->opt_hybrid || c->opt_lanes;
+  if (flat) n = 1;
+  const bool reuse = c->opt_reuse && !flat;
+  if (B == c->cap_batch && n == c->plan_n && reuse == c->plan_reuse) return YL_OK;
   free_act(c);
+  c->plan_reuse = reuse;
+  plan_slots(c, reuse);
+  const int base = B / n, rem = B % n;
+  int b0 = 0;
+  c->plan_cap = 0;
+  for (int i = 0; i < n; ++i) {
+    const int bn = base + (i < rem ? 1 : 0);
+    c->plan_b0[i] = b0;
+    b0 += bn;
+    if (bn > c->plan_cap) c->plan_cap = bn;
+  }
+  c->plan_b0[n] = B;
+  for (int i = 0; i < n; ++i)
+    if (c->arena_unit) HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)c->plan_cap));
   for (auto& s : c->slots)
-    HIPCHK(c, hipMalloc((void**)&s.ptr, (size_t)B * s.h * s.w * s.c * sizeof(float)));
+    if (s.pinned) HIPCHK(c, hipMalloc((void**)&s.pin, s.sz * (size_t)B));
   for (int l = 0; l < c->L; ++l)
     HIPCHK(c, hipMalloc((void**)&c->level_buf[l],
                         (size_t)B * c->level_A[l] * c->level_S[l] * c->level_S[l] * c->E * sizeof(float)));
-  c->cap_batch = B;
+  c->cap_batch = B; c->plan_n = n;
   return YL_OK;
+}
+
+// image b of slot `sl` (b must lie in the planned chunk that contains it)
+float* slot_addr(const yl_ctx* c, int sl, int b) {
+  const Slot& t = c->slots[sl];
+  if (t.pinned) return (float*)((char*)t.pin + (size_t)b * t.sz);
+  int ch = 0;
+  while (ch + 1 < c->plan_n && b >= c->plan_b0[ch + 1]) ++ch;
+  return (float*)(c->arena[ch] + t.off * (size_t)c->plan_cap + (size_t)(b - c->plan_b0[ch]) * t.sz);
 }
 
 yl_status ensure_post(yl_ctx* c, int B) {
@@ -277,7 +405,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   p.TK = d.k * d.k * p.KB;
   p.NTtot = cdiv(d.cout, 16);
   p.M = B * L.out_h * L.out_w;
-  auto slot_ptr = [&](int sl) { const Slot& t = c->slots[sl]; return t.ptr + (size_t)b0 * t.h * t.w * t.c; };
+  auto slot_ptr = [&](int sl) { return slot_addr(c, sl, b0); };
   p.x = (d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? x + (size_t)b0 * 3 * L.in_h * L.in_w : slot_ptr(d.in_slot);
   if (d.op == YL_OP_CONV && d.c2 > 0) {      // fused expand -> depthwise -> project
     p.w2p = L.w2p; p.b2 = L.b2; p.C1 = d.c2; p.act2 = d.act2;
@@ -353,30 +481,12 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
       p.dec_hi = (float)(c->img_size - 1);
     }
   };
-  // layers i and j can share a launch: same kernel configuration, no residual / upsample operands
-  auto same_shape = [&](size_t i, size_t j) {
-    const yl_layer& a = c->layers[i].d; const yl_layer& e = c->layers[j].d;
-    return a.op == YL_OP_CONV && e.op == YL_OP_CONV && a.cin == e.cin && a.cout == e.cout && a.k == e.k &&
-           a.stride == e.stride && a.pad_t == e.pad_t && a.pad_l == e.pad_l && a.act == e.act &&
-           a.in_shift == e.in_shift && a.dw_k == e.dw_k && a.dw_stride == e.dw_stride && a.dw_pad_t == e.dw_pad_t &&
-           a.dw_pad_l == e.dw_pad_l && a.dw_act == e.dw_act && a.c2 == 0 && e.c2 == 0 && a.res_slot < 0 &&
-           e.res_slot < 0 && a.up_slot < 0 && e.up_slot < 0 && (a.head_level >= 0) == (e.head_level >= 0) &&
-           (a.cout + 15) / 16 <= 8;
-  };
   const size_t lend = hi < 0 ? c->layers.size() : (size_t)hi;
   for (size_t i = (size_t)lo; i < lend;) {
     const yl_layer& d = c->layers[i].d;
     // ---- level-batched run starting at i (not under per-layer timing, not with side lanes)
     size_t gend = i + 1;
-    if (!evs && !lanes && c->opt_batch_levels && d.op == YL_OP_CONV) {
-      while (gend < lend && gend - i < 4 && same_shape(i, gend)) {
-        bool dep = false;
-        for (size_t q = i; q < gend; ++q)
-          if (c->layers[q].d.head_level < 0 && c->layers[q].d.out_slot == c->layers[gend].d.in_slot) dep = true;
-        if (dep) break;
-        ++gend;
-      }
-    }
+    if (!evs && !lanes && c->opt_batch_levels && d.op == YL_OP_CONV) gend = layer_group_end(c, i, lend);
     if (gend - i > 1) {
       YlConvP ps[4];
       for (size_t q = i; q < gend; ++q) params(q, ps[q - i]);
@@ -613,8 +723,7 @@ yl_status walk_plan(yl_ctx* c, const Job& j, hipStream_t st, int n, const Seg* s
 // run a job eagerly, or by replaying cached hipGraphs of exactly this job (one graph per piece: capturing several
 // chunks plus side lanes into ONE graph -- 4 streams -- crashed hipGraphInstantiate on ROCm 7.2)
 yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = true) {
-  int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
-  if (j.B < 4 * n) n = 1;
+  const int n = chunks_for(c, j.B);
   Seg segs[3];
   const int nseg = plan_segments(c, j, n, segs);
   yl_status s = ensure_streams(c);
@@ -942,6 +1051,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "nms_groups")) { c->opt_nms_groups = value < 1 ? 1 : (value > YL_NMS_GROUPS ? YL_NMS_GROUPS : value); drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "reuse_slots")) { c->opt_reuse = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "hybrid")) { c->opt_hybrid = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "batch_levels")) { c->opt_batch_levels = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "fuse_decode")) { c->opt_fuse_decode = value ? 1 : 0; drop_graph(c); return YL_OK; }
@@ -957,7 +1067,7 @@ static yl_status forward_impl(yl_ctx* c, const float* x, int B, float* const* le
   if (c->layers.empty()) return fail(c, YL_ERR_STATE, "context was created without layers");
   if (!x || B < 1) return fail(c, YL_ERR_INVALID, "bad input");
   HIPCHK(c, hipSetDevice(c->device));
-  yl_status s = ensure_act(c, B);
+  yl_status s = ensure_act(c, B, layer_ms ? 1 : chunks_for(c, B));
   if (s != YL_OK) return s;
   if (cfg && (s = ensure_post(c, B)) != YL_OK) return s;
   Job j;
@@ -987,14 +1097,27 @@ yl_status yl_forward_timed(yl_ctx* c, const float* x, int32_t B, float* const* l
   return forward_impl(c, x, B, level_out, (hipStream_t)stream, layer_ms, nullptr, nullptr, nullptr);
 }
 
+int64_t yl_activation_bytes(const yl_ctx* c) {
+  if (!c || c->plan_n < 1) return 0;
+  int64_t t = (int64_t)c->arena_unit * c->plan_cap * c->plan_n;
+  for (const auto& s : c->slots)
+    if (s.pinned) t += (int64_t)s.sz * c->cap_batch;
+  return t;
+}
+
 yl_status yl_read_slot(yl_ctx* c, int32_t slot, int32_t B, float* dst, void* stream) {
   if (!c || !dst) return YL_ERR_INVALID;
   if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, YL_ERR_INVALID, "bad slot");
-  if (B > c->cap_batch || !c->slots[slot].ptr) return fail(c, YL_ERR_STATE, "no forward has produced this slot");
+  if (B > c->cap_batch || c->plan_n < 1) return fail(c, YL_ERR_STATE, "no forward has produced this slot");
   HIPCHK(c, hipSetDevice(c->device));
   const Slot& s = c->slots[slot];
-  HIPCHK(c, hipMemcpyAsync(dst, s.ptr, (size_t)B * s.h * s.w * s.c * sizeof(float), hipMemcpyDeviceToDevice,
-                           (hipStream_t)stream));
+  // (with "reuse_slots" on, a tensor that is not an output of the network may have been overwritten by later layers)
+  for (int i = 0; i < c->plan_n; ++i) {
+    const int b0 = c->plan_b0[i], b1 = c->plan_b0[i + 1] < B ? c->plan_b0[i + 1] : B;
+    if (b1 <= b0) break;
+    HIPCHK(c, hipMemcpyAsync((char*)dst + (size_t)b0 * s.sz, slot_addr(c, slot, b0), (size_t)(b1 - b0) * s.sz,
+                             hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  }
   return YL_OK;
 }
 
@@ -1043,7 +1166,7 @@ yl_status yl_masks(yl_ctx* c, const float* const* levels, int32_t B, const int32
                    int32_t max_out, float thr, uint8_t* masks, void* stream) {
   if (!c || !counts || !keep_idx || !masks || B < 1 || max_out < 1) return YL_ERR_INVALID;
   if (c->NM <= 0 || c->proto_slot < 0) return fail(c, YL_ERR_STATE, "context has no mask branch");
-  if (B > c->cap_batch || B > c->post_cap_batch || !c->slots[c->proto_slot].ptr)
+  if (B > c->cap_batch || B > c->post_cap_batch || !c->slots[c->proto_slot].pin)
     return fail(c, YL_ERR_STATE, "yl_masks needs a preceding yl_predict / yl_forward+yl_postprocess of this batch");
   HIPCHK(c, hipSetDevice(c->device));
   const float* lp[YL_MAX_LEVELS];
@@ -1051,7 +1174,7 @@ yl_status yl_masks(yl_ctx* c, const float* const* levels, int32_t B, const int32
   YlLevels lv;
   fill_levels(c, lp, lv);
   const Slot& ps = c->slots[c->proto_slot];
-  HIPCHK(c, yl_launch_masks(lv, B, ps.ptr, ps.h, ps.w, c->NM, c->img_size, c->ws_boxes, counts, keep_idx, max_out, thr,
+  HIPCHK(c, yl_launch_masks(lv, B, ps.pin, ps.h, ps.w, c->NM, c->img_size, c->ws_boxes, counts, keep_idx, max_out, thr,
                             masks, (hipStream_t)stream));
   return YL_OK;
 }

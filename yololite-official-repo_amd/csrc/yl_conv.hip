@@ -473,6 +473,9 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 && MODE <= 1) ? YL_PW_WAVES : 3)
 #ifndef YL_DWH_PREADD
 #define YL_DWH_PREADD 1
 #endif
+#ifndef YL_DWH_EXP
+#define YL_DWH_EXP 0      // timing experiments (variant builds; results WRONG): 1 no stores, 2 no MFMAs, 3 no taps, 4 no halo loads
+#endif
 template <int NT, int DK, int DS>
 __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
   YL_SELECT_PROBLEM(mp)
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
 #if YL_DWH_BUF
       r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
 #else
-      r[j] = yl_ld4(off < OOB ? p.x + (off >> 2) : p.zeros);
+      r[j] = yl_ld4((YL_DWH_EXP != 4 && off < OOB) ? p.x + (off >> 2) : p.zeros);
 #endif
     }
   };
@@ -627,7 +630,9 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
       const int c = kb * 16 + 4 * kq;
       const int cs = c < p.Cin ? c : p.Cin - 4;
       f32x4 s = yl_ld4(dwl + DK * DK * p.Cin + cs);
-      if (DK == 3) {
+      if (YL_DWH_EXP == 3) {
+        s += *reinterpret_cast<const f32x4*>(halo + rbase);
+      } else if (DK == 3) {
 #pragma unroll
         for (int dy = 0; dy < DK; ++dy)
 #pragma unroll
@@ -656,11 +661,19 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
       f32x4 wq[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
-      yl_mma_step<NT, 1>(wq, xq, acc);
+      if (YL_DWH_EXP == 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[0][nt] += wq[nt] * xq[0];
+      } else yl_mma_step<NT, 1>(wq, xq, acc);
       if (more) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // this step's tap reads are complete
         stage_store(stg);
       }
+    }
+    if (YL_DWH_EXP == 1) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(acc[0][nt].x), "v"(acc[0][nt].y), "v"(acc[0][nt].z), "v"(acc[0][nt].w));
+      continue;
     }
     if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, !bias0);

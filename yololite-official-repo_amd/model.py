@@ -141,6 +141,9 @@ class HipContext:
         _lib.check(self.lib.yl_forward(self.handle, x.data_ptr(), B, arr, sp), self.handle, "yl_forward")
         return outs
 
+    def activation_bytes(self) -> int:
+        return int(self.lib.yl_activation_bytes(self.handle))
+
     def read_slot(self, slot: int, B: int, shape) -> torch.Tensor:
         h, w, c = shape
         t = torch.empty((B, h, w, c), device=self.device, dtype=torch.float32)
