@@ -165,6 +165,12 @@ yl_status yl_forward(yl_ctx* ctx, const float* x_dev, int32_t batch, float* cons
  * per-layer durations (ms) in layer_ms[num_layers].  Measurement aid for bench.py (roofline).      */
 yl_status yl_forward_timed(yl_ctx* ctx, const float* x_dev, int32_t batch, float* const* level_out_dev,
                            void* stream, float* layer_ms);
+/* With option "time_split" 1, yl_predict runs as ONE chunk on the caller's stream (no hipGraph) with a HIP event
+ * before the conv layers, between the last conv layer and the NMS, and after the NMS; this call waits for the last
+ * event and returns the two intervals: infer_ms (backbone + neck + heads, decode fused into the head epilogues) and
+ * post_ms (per-class NMS + back-map) -- the pre / infer / post split of the reference's timing harness
+ * (export/infer_onnx.py:152-244, README.md:182-189).  Measurement aid: the split costs the chunk overlap. */
+yl_status yl_last_timing(yl_ctx* ctx, float* infer_ms, float* post_ms);
 /* Bytes of activation memory the context holds for the batch of its last forward / predict call (one arena per
  * batch chunk, tensors placed by liveness; see option "reuse_slots").  0 before the first call. */
 int64_t yl_activation_bytes(const yl_ctx* ctx);
@@ -181,6 +187,7 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * head outputs of all pyramid levels in one launch each),
  * "fuse_decode" (0/1, default 1: yl_predict decodes inside the head-output convs; the raw level tensors are
  * then NOT materialised unless the model has mask coefficients),
+ * "time_split" (0/1, default 0: see yl_last_timing), "pre_norm" (0/1: see yl_preprocess),
  * "reuse_slots" (0/1, default 1: activation tensors share memory by liveness inside one arena per batch chunk;
  * 0 keeps every tensor of the forward pass),
  * "mfma_bf16" (0/1, default 0: SURVEY 8(f) f4 reduced-precision inference mode -- conv operands are rounded
@@ -194,7 +201,11 @@ yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
  * Replaces letterbox() + cv2.cvtColor + /255 + (x-mean)/std + transpose of tools/infer.py:121-131,446-453
  * for a batch: `packed_u8_dev` holds the BGR uint8 HWC images back to back, `imgs_dev` one descriptor
  * per image (the caller computes the letterbox geometry exactly like the reference: scale=min(S/h,S/w),
- * nh,nw=int(round(.)), top=(S-nh)//2, left=(S-nw)//2).  x_dev receives [B,3,S,S] fp32.              */
+ * nh,nw=int(round(.)), top=(S-nh)//2, left=(S-nw)//2).  x_dev receives [B,3,S,S] fp32.
+ * Option "pre_norm" 1 switches the normalisation arithmetic to the evaluate path's (tools/evaluate.py:57-72 ->
+ * scripts/data/augment.py:153-171: LongestMaxSize + PadIfNeeded give the SAME geometry -- scale S/max(h,w),
+ * round-half-even sizes, floor-half padding, border 114 -- and A.Normalize computes (x - 255*mean) * (1/(255*std))
+ * in float32 instead of (x/255 - mean)/std).                                                          */
 typedef struct {
   int64_t offset;             /* byte offset of image b in packed_u8_dev                          */
   int32_t h0, w0;             /* source size                                                      */
@@ -225,6 +236,17 @@ yl_status yl_postprocess(yl_ctx* ctx, const float* const* levels_dev, int32_t ba
  * keep_idx_dev: optional [B][max_out] candidate indices (needed by yl_masks), NULL to skip.          */
 yl_status yl_predict(yl_ctx* ctx, const float* x_dev, int32_t batch, const yl_post_cfg* cfg,
                      float* dets_dev, int32_t* counts_dev, int32_t* keep_idx_dev, void* stream);
+
+/* ---- multi-GPU exchange ----------------------------------------------------------------------
+ * The reference is single-device; sharding the batch over GPUs needs exactly ONE exchange per step: an all-gather
+ * of the packed per-rank result.  Every rank runs yl_predict on its shard with dets_dev / counts_dev pointing INTO
+ * one flat buffer  local_dev = [ dets: b*max_out*6 floats | counts: b int32 ]  (row_floats = b*max_out*6 + b; equal
+ * shards), then this call issues ncclAllGather(local_dev -> all_dev[world][row_floats]) on `stream` -- asynchronous,
+ * no pack / unpack kernels.  `nccl_comm` is the caller's ncclComm_t (RCCL).  RCCL is resolved at run time from the
+ * libraries already loaded in the process (YL_ERR_UNSUPPORTED if none is).  Python hosts use torch.distributed
+ * instead (yololite_amd.dist.DetGatherer: same buffer layout). */
+yl_status yl_allgather_dets(yl_ctx* ctx, void* nccl_comm, const float* local_dev, int64_t row_floats, float* all_dev,
+                            void* stream);
 
 /* ---- instance masks (BUILD-DEFINED: the reference repository contains no mask code; parity unpinned) --
  * For detection i of image b (candidate keep_idx[b][i] of the levels of the last yl_forward/yl_predict on

@@ -74,3 +74,25 @@ def preprocess(img_bgr: np.ndarray, new_size: int):
     im = lb[..., ::-1].astype(np.float32) / 255.0
     im = (im - MEAN) / STD
     return np.ascontiguousarray(im.transpose(2, 0, 1)), (padx, pady, scale, img_bgr.shape[1], img_bgr.shape[0])
+
+
+def preprocess_albumentations(img_bgr: np.ndarray, new_size: int, resize: bool = False):
+    """The evaluate path (tools/evaluate.py:57-72 -> scripts/data/augment.py:153-171, images read by
+    scripts/data/dataset.py:88-92 as RGB): A.Resize(p=resize) | A.LongestMaxSize(S) + A.PadIfNeeded(S, S, constant
+    114, centred: top = int((S - nh) / 2.0)) -> the geometry of letterbox() above -- then A.Normalize restated FROM
+    RECOLLECTION of albumentations' functional.normalize (albumentations is third-party, un-pinned in
+    requirements.txt and absent here: PARITY UNPINNED):
+        mean = float32(mean) * 255; std = float32(std) * 255; denominator = np.reciprocal(std, dtype=float32)
+        img = img.astype(float32); img -= mean; img *= denominator
+    -> (x [3,S,S] fp32, (padx, pady, scale, w0, h0))."""
+    h, w = img_bgr.shape[:2]
+    if resize:
+        lb, scale, padx, pady = resize_linear_u8(img_bgr, new_size, new_size), min(new_size / h, new_size / w), 0, 0
+    else:
+        lb, scale, (padx, pady) = letterbox(img_bgr, new_size)
+    mean = MEAN * np.float32(255.0)
+    den = np.reciprocal(STD * np.float32(255.0), dtype=np.float32)
+    im = lb[..., ::-1].astype(np.float32)
+    im -= mean
+    im *= den
+    return np.ascontiguousarray(im.transpose(2, 0, 1)), (padx, pady, scale, w, h)

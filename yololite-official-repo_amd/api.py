@@ -4,7 +4,8 @@
 
 Everything from the uint8 image bytes to the final detections runs in the HIP library: letterbox +
 normalise (yl_preprocess, tools/infer.py:121-131,442-453), forward, decode, NMS, back-map (yl_predict).
-`preprocess_bgr` below is the host (numpy/PIL) variant kept for tests and tools."""
+There is ONE pre-processing implementation in the product (preprocess.preprocess_batch -> yl_preprocess); the CLIs
+use it too."""
 from __future__ import annotations
 
 import time
@@ -17,39 +18,6 @@ from . import _lib
 from .model import load_model_names_imgsize_from_ckpt
 from .preprocess import preprocess_batch
 
-MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
-STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
-
-
-def _resize_bilinear_u8(im: np.ndarray, nw: int, nh: int) -> np.ndarray:
-    if im.shape[0] == nh and im.shape[1] == nw:
-        return im
-    from PIL import Image
-    return np.asarray(Image.fromarray(im).resize((nw, nh), Image.BILINEAR))
-
-
-def letterbox(im: np.ndarray, new_size: int = 640, color=(114, 114, 114)):
-    """tools/infer.py:121-131 (cv2.resize INTER_LINEAR replaced by PIL bilinear: cv2 is absent here)."""
-    h, w = im.shape[:2]
-    scale = min(new_size / h, new_size / w)
-    nh, nw = int(round(h * scale)), int(round(w * scale))
-    r = _resize_bilinear_u8(im, nw, nh)
-    top, left = (new_size - nh) // 2, (new_size - nw) // 2
-    out = np.empty((new_size, new_size, 3), np.uint8)
-    out[...] = np.asarray(color, np.uint8)
-    out[top:top + nh, left:left + nw] = r
-    return out, scale, (left, top)
-
-
-def preprocess_bgr(img_bgr: np.ndarray, img_size: int):
-    """BGR uint8 HWC -> (normalised CHW fp32, (padx, pady, scale, w0, h0))  (tools/infer.py:446-453)."""
-    lb, scale, (padx, pady) = letterbox(img_bgr, img_size)
-    im = lb[..., ::-1].astype(np.float32) / 255.0
-    im = (im - MEAN) / STD
-    h0, w0 = img_bgr.shape[:2]
-    return np.ascontiguousarray(im.transpose(2, 0, 1)), (padx, pady, scale, w0, h0)
-
-
 class YoloLite:
     def __init__(self, weights: str, device: Union[str, int] = "cuda:0"):
         dev = torch.device(device if isinstance(device, str) else f"cuda:{device}")
@@ -58,9 +26,13 @@ class YoloLite:
 
     @torch.no_grad()
     def predict(self, source: Union[np.ndarray, Sequence[np.ndarray]], device=None, draw: bool = False,
-                conf: float = 0.4, iou: float = 0.5) -> List[dict]:
+                conf: float = 0.4, iou: float = 0.5, profile: bool = True) -> List[dict]:
         """source: one BGR uint8 image (HWC) or a sequence of them.  Main-path semantics of
-        tools/infer.py:460-516 (conf 0.4 / iou 0.5 defaults :403-404, 300 per class)."""
+        tools/infer.py:460-516 (conf 0.4 / iou 0.5 defaults :403-404, 300 per class).
+        `speed` (ms per image, like the reference's pre / infer / post / total split, README.md:182-189):
+        pre_ms = host packing + H2D copy + letterbox/normalise kernel (wall clock around a stream sync), infer_ms /
+        post_ms = HIP-event intervals on the launch stream (yl_last_timing), total_ms = their sum.  profile=False
+        skips the event split (the batch then runs as overlapped chunks) and reports infer_post_ms from the wall clock."""
         imgs = [source] if isinstance(source, np.ndarray) else list(source)
         t0 = time.perf_counter()
         ctx = self.model._ctx_for(self.img_size)
@@ -69,8 +41,9 @@ class YoloLite:
         bm[:, 2] = np.maximum(bm[:, 2], 1e-6)
         bm = bm.astype(np.float32)
         t1 = time.perf_counter()
+        ctx.set_option("time_split", 1 if profile else 0)
         masks = None
-        if ctx.NM:                                              # build-defined seg model: masks at prototype resolution
+        if ctx.NM:                                              # build-defined seg model
             dets, counts, idx = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300,
                                             backmap=torch.from_numpy(bm), want_idx=True)
             masks = ctx.masks(counts, idx, dets.shape[1]).cpu().numpy()
@@ -79,11 +52,17 @@ class YoloLite:
         cn = counts.cpu().numpy()
         d = dets.cpu().numpy()
         t2 = time.perf_counter()
+        n = len(imgs)
+        speed = {"pre_ms": (t1 - t0) * 1e3 / n}
+        if profile:
+            infer_ms, post_ms = ctx.last_timing()
+            speed.update(infer_ms=infer_ms / n, post_ms=post_ms / n)
+            speed["total_ms"] = speed["pre_ms"] + speed["infer_ms"] + speed["post_ms"]
+        else:
+            speed.update(infer_post_ms=(t2 - t1) * 1e3 / n, total_ms=(t2 - t0) * 1e3 / n)
         out = []
-        for b in range(len(imgs)):
+        for b in range(n):
             r = d[b, :min(int(cn[b]), d.shape[1])]
             out.append({"boxes": r[:, :4].copy(), "scores": r[:, 4].copy(), "classes": r[:, 5].astype(np.int64),
-                        "masks": (masks[b, :len(r)].copy() if masks is not None else None),
-                        "speed": {"pre_ms": (t1 - t0) * 1e3 / len(imgs), "infer_post_ms": (t2 - t1) * 1e3 / len(imgs),
-                                  "total_ms": (t2 - t0) * 1e3 / len(imgs)}})
+                        "masks": (masks[b, :len(r)].copy() if masks is not None else None), "speed": dict(speed)})
         return out

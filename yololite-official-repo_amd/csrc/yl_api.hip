@@ -1,6 +1,7 @@
 // C ABI (include/yololite_hip.h): context, weight packing, forward executor, post-processing driver.
 #include "yl_internal.h"
 
+#include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
@@ -60,6 +61,10 @@ struct yl_ctx {
   size_t arena_unit = 0;                   // arena bytes per image of a chunk (peak of the live set)
   bool plan_reuse = false;
   int opt_reuse = 1;
+  int opt_time_split = 0;    // yl_predict records HIP events around the conv layers and the NMS (one chunk, eager)
+  hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};
+  bool timing_valid = false;
+  int opt_pre_norm = 0;      // yl_preprocess: 0 = tools/infer.py arithmetic, 1 = the evaluate path's A.Normalize
   float* level_buf[YL_MAX_LEVELS] = {nullptr};
   // post-processing workspace
   float4* ws_boxes = nullptr;
@@ -309,6 +314,7 @@ void plan_slots(yl_ctx* c, bool reuse) {
 
 // number of batch chunks a job of B images is split into (submit / walk_plan)
 int chunks_for(const yl_ctx* c, int B) {
+  if (c->opt_time_split) return 1;          // the infer / post split is defined on ONE stream
   int n = c->opt_streams < 1 ? 1 : (c->opt_streams > 4 ? 4 : c->opt_streams);
   if (B < 4 * n) n = 1;
   return n;
@@ -674,8 +680,12 @@ int plan_segments(const yl_ctx* c, const Job& j, int n, Seg* segs) {
 yl_status run_piece(yl_ctx* c, const Job& j, const Seg& sg, int b0, int bn, hipStream_t st, int chunk) {
   yl_status s = YL_OK;
   const bool fused = j.x && j.cfg && can_fuse_decode(c);
+  const bool timed = c->opt_time_split && j.x && j.cfg && chunk == 0 && bn == j.B && c->ev_t[0];
+  if (timed) hipEventRecord(c->ev_t[0], st);
   if (j.x && sg.hi > sg.lo) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr, chunk, fused ? j.cfg : nullptr, sg.lo, sg.hi);
+  if (timed) hipEventRecord(c->ev_t[1], st);
   if (s == YL_OK && sg.post && j.cfg) s = do_post(c, j.outs, b0, bn, j.cfg, j.dets, j.counts, j.keep_idx, st, fused);
+  if (timed) { hipEventRecord(c->ev_t[2], st); c->timing_valid = true; }
   return s;
 }
 
@@ -728,7 +738,7 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = tru
   const int nseg = plan_segments(c, j, n, segs);
   yl_status s = ensure_streams(c);
   if (s != YL_OK) return s;
-  if (!c->opt_graph || !allow_graph)
+  if (!c->opt_graph || !allow_graph || c->opt_time_split)
     return walk_plan(c, j, st, n, segs, nseg, [&](int g, int i, int b0, int bn, hipStream_t ws) -> yl_status {
       return run_piece(c, j, segs[g], b0, bn, ws, i);
     });
@@ -836,6 +846,7 @@ void yl_destroy(yl_ctx* c) {
     if (c->ev_lb[i]) hipEventDestroy(c->ev_lb[i]);
   }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < 3; ++i) if (c->ev_t[i]) hipEventDestroy(c->ev_t[i]);
   hipFree(c->ws_nms_gkeys);
   for (auto& L : c->layers) {
     hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b);
@@ -1051,6 +1062,15 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "nms_groups")) { c->opt_nms_groups = value < 1 ? 1 : (value > YL_NMS_GROUPS ? YL_NMS_GROUPS : value); drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "time_split")) {
+    c->opt_time_split = value ? 1 : 0;
+    for (int i = 0; i < 3 && value; ++i)
+      if (!c->ev_t[i]) HIPCHK(c, hipEventCreate(&c->ev_t[i]));
+    c->timing_valid = false;
+    drop_graph(c);
+    return YL_OK;
+  }
+  if (!strcmp(name, "pre_norm")) { c->opt_pre_norm = value ? 1 : 0; return YL_OK; }
   if (!strcmp(name, "reuse_slots")) { c->opt_reuse = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "hybrid")) { c->opt_hybrid = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "batch_levels")) { c->opt_batch_levels = value ? 1 : 0; drop_graph(c); return YL_OK; }
@@ -1097,6 +1117,15 @@ yl_status yl_forward_timed(yl_ctx* c, const float* x, int32_t B, float* const* l
   return forward_impl(c, x, B, level_out, (hipStream_t)stream, layer_ms, nullptr, nullptr, nullptr);
 }
 
+yl_status yl_last_timing(yl_ctx* c, float* infer_ms, float* post_ms) {
+  if (!c || !infer_ms || !post_ms) return YL_ERR_INVALID;
+  if (!c->opt_time_split || !c->timing_valid) return fail(c, YL_ERR_STATE, "set option time_split and call yl_predict first");
+  HIPCHK(c, hipEventSynchronize(c->ev_t[2]));
+  HIPCHK(c, hipEventElapsedTime(infer_ms, c->ev_t[0], c->ev_t[1]));
+  HIPCHK(c, hipEventElapsedTime(post_ms, c->ev_t[1], c->ev_t[2]));
+  return YL_OK;
+}
+
 int64_t yl_activation_bytes(const yl_ctx* c) {
   if (!c || c->plan_n < 1) return 0;
   int64_t t = (int64_t)c->arena_unit * c->plan_cap * c->plan_n;
@@ -1125,7 +1154,7 @@ yl_status yl_preprocess(yl_ctx* c, const uint8_t* packed, const yl_pre_image* im
   if (!c || !packed || !imgs || !x || B < 1) return YL_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   static_assert(sizeof(yl_pre_image) == 32, "yl_pre_image layout");
-  HIPCHK(c, yl_launch_preprocess(packed, imgs, B, c->img_size, x, (hipStream_t)stream));
+  HIPCHK(c, yl_launch_preprocess(packed, imgs, B, c->img_size, x, c->opt_pre_norm, (hipStream_t)stream));
   return YL_OK;
 }
 
@@ -1176,6 +1205,25 @@ yl_status yl_masks(yl_ctx* c, const float* const* levels, int32_t B, const int32
   const Slot& ps = c->slots[c->proto_slot];
   HIPCHK(c, yl_launch_masks(lv, B, ps.pin, ps.h, ps.w, c->NM, c->img_size, c->ws_boxes, counts, keep_idx, max_out, thr,
                             masks, (hipStream_t)stream));
+  return YL_OK;
+}
+
+// the one exchange of the multi-GPU path, for hosts that do not go through torch.distributed.  RCCL is
+// NOT a link-time dependency of this library: ncclAllGather is looked up among the libraries already loaded in the
+// process, i.e. the RCCL that created the caller's communicator (PyTorch ships its own copy).
+yl_status yl_allgather_dets(yl_ctx* c, void* comm, const float* local_dev, int64_t row_floats, float* all_dev, void* stream) {
+  if (!c || !comm || !local_dev || !all_dev || row_floats <= 0) return c ? fail(c, YL_ERR_INVALID, "bad argument") : YL_ERR_INVALID;
+  typedef int (*allgather_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/, hipStream_t);
+  static allgather_fn fn = nullptr;
+  if (!fn) fn = (allgather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather");
+  if (!fn) return fail(c, YL_ERR_UNSUPPORTED, "ncclAllGather not found: load RCCL (librccl.so) in this process first");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rc = fn(local_dev, all_dev, (size_t)row_floats, 7 /*ncclFloat32*/, comm, (hipStream_t)stream);
+  if (rc != 0) {
+    char b[96];
+    snprintf(b, sizeof(b), "ncclAllGather failed with ncclResult_t %d", rc);
+    return fail(c, YL_ERR_HIP, b);
+  }
   return YL_OK;
 }
 

@@ -118,7 +118,8 @@ hipError_t yl_launch_decode_score(const YlLevels& lv, int B, const YlDecodeP& p,
 hipError_t yl_launch_decode_only(const YlLevels& lv, int B, int center_mode, int wh_mode, float* box,
                                  float* obj, float* cls, hipStream_t st);
 hipError_t yl_launch_nms(const YlNmsP& p, int B, hipStream_t st);
-hipError_t yl_launch_preprocess(const unsigned char* src, const void* imgs, int B, int S, float* out, hipStream_t st);
+hipError_t yl_launch_preprocess(const unsigned char* src, const void* imgs, int B, int S, float* out, int norm_mode,
+                                hipStream_t st);
 hipError_t yl_launch_masks(const YlLevels& lv, int B, const float* proto, int PH, int PW, int NM, int img_size,
                            const float4* boxes, const int* counts, const int* keep_idx, int max_out, float thr,
                            unsigned char* masks, hipStream_t st);

@@ -3,7 +3,9 @@
 // buffer.  Replaces cv2.resize / copyMakeBorder / cvtColor / the numpy normalisation of the reference
 // (tools/infer.py:121-131, 446-453).  Integer arithmetic follows OpenCV's 8-bit INTER_LINEAR path
 // (11-bit coefficients; restated in oracle/preproc.py) and is bit-exact with that statement; the fp32
-// normalisation is evaluated op by op (compiled with -ffp-contract=off).
+// normalisation is evaluated op by op (compiled with -ffp-contract=off).  Option "pre_norm" 1 selects the
+// evaluate path's arithmetic instead (Albumentations LongestMaxSize + PadIfNeeded + Normalize,
+// scripts/data/augment.py:153-171: the same letterbox geometry, normalisation as (x - 255*mean) * (1 / (255*std))).
 // HBM-bound: reads each source pixel ~once (L2 absorbs the 4-tap reuse), writes 12 B per output pixel.
 #include "yl_internal.h"
 #include <math.h>
@@ -26,7 +28,7 @@ __device__ __forceinline__ void yl_coef(int d, int src, int dst, int& s, int& a0
 
 __global__ __launch_bounds__(256) void yl_preprocess_kernel(const unsigned char* __restrict__ src,
                                                             const YlPreImg* __restrict__ imgs, int B, int S,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int norm_mode) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.z;
@@ -60,13 +62,20 @@ __global__ __launch_bounds__(256) void yl_preprocess_kernel(const unsigned char*
   float* o = out + (size_t)b * 3 * plane + (size_t)y * S + x;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {                    // output channel c = R,G,B  <-  source channel 2-c
-    const float v = (float)px[2 - c] / 255.0f;
-    o[c * plane] = (v - mean[c]) / stdv[c];
+    if (norm_mode == 0) {                          // tools/infer.py:449-450: x/255, then (x - mean) / std
+      const float v = (float)px[2 - c] / 255.0f;
+      o[c * plane] = (v - mean[c]) / stdv[c];
+    } else {                                       // A.Normalize of the evaluate path (scripts/data/augment.py:160-161):
+      const float m255 = mean[c] * 255.0f;         // float32 mean*255, std*255, reciprocal; x -= mean; x *= 1/std
+      const float d = 1.0f / (stdv[c] * 255.0f);
+      o[c * plane] = ((float)px[2 - c] - m255) * d;
+    }
   }
 }
 
-hipError_t yl_launch_preprocess(const unsigned char* src, const void* imgs, int B, int S, float* out, hipStream_t st) {
+hipError_t yl_launch_preprocess(const unsigned char* src, const void* imgs, int B, int S, float* out, int norm_mode,
+                                hipStream_t st) {
   dim3 grid((S + 63) / 64, (S + 3) / 4, B);
-  hipLaunchKernelGGL(yl_preprocess_kernel, grid, dim3(256), 0, st, src, (const YlPreImg*)imgs, B, S, out);
+  hipLaunchKernelGGL(yl_preprocess_kernel, grid, dim3(256), 0, st, src, (const YlPreImg*)imgs, B, S, out, norm_mode);
   return hipGetLastError();
 }

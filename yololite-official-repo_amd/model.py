@@ -141,6 +141,12 @@ class HipContext:
         _lib.check(self.lib.yl_forward(self.handle, x.data_ptr(), B, arr, sp), self.handle, "yl_forward")
         return outs
 
+    def last_timing(self):
+        """(infer_ms, post_ms) of the last predict() under option "time_split" (HIP events on the launch stream)."""
+        a, b = C.c_float(), C.c_float()
+        _lib.check(self.lib.yl_last_timing(self.handle, C.byref(a), C.byref(b)), self.handle, "yl_last_timing")
+        return float(a.value), float(b.value)
+
     def activation_bytes(self) -> int:
         return int(self.lib.yl_activation_bytes(self.handle))
 

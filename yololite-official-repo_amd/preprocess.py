@@ -25,10 +25,15 @@ def letterbox_geometry(h: int, w: int, new_size: int):
     return scale, nh, nw, (new_size - nh) // 2, (new_size - nw) // 2
 
 
-def preprocess_batch(ctx, images: Sequence[np.ndarray], letterbox: bool = True) -> Tuple[torch.Tensor, np.ndarray]:
+def preprocess_batch(ctx, images: Sequence[np.ndarray], letterbox: bool = True,
+                     norm: str = "infer") -> Tuple[torch.Tensor, np.ndarray]:
     """images: BGR uint8 HWC arrays (any sizes).  Returns (x [B,3,S,S] fp32 on ctx.device,
-    backmap [B,5] float64 = padx, pady, scale, w0, h0 as tools/infer.py:442-447 defines them)."""
+    backmap [B,5] float64 = padx, pady, scale, w0, h0 as tools/infer.py:442-447 defines them).
+    norm: "infer" = tools/infer.py:449-450 arithmetic; "albumentations" = the evaluate path's pipeline
+    (tools/evaluate.py:57-72 -> scripts/data/augment.py:153-171: A.LongestMaxSize + A.PadIfNeeded produce the same
+    geometry as letterbox(), A.Normalize a differently rounded normalisation; letterbox=False = its A.Resize(p=1))."""
     S = ctx.img_size
+    ctx.set_option("pre_norm", 1 if norm == "albumentations" else 0)
     desc = np.zeros(len(images), _DESC)
     backmap = np.zeros((len(images), 5), np.float64)
     off = 0
