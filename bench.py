@@ -352,7 +352,7 @@ def main():
         if args.seg:
             _, _, idx = ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
                                     out=(dets, counts), want_idx=True)
-            ctx.masks(counts, idx, max_out)
+            ctx.masks_image(dets, counts, idx, packed=True)        # image-resolution (640 x 640) masks, bit-packed rows
             return dets, counts
         if gat is not None:      # results go straight into the gather slot; its all-gather overlaps the next step
             ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,

@@ -256,6 +256,23 @@ yl_status yl_allgather_dets(yl_ctx* ctx, void* nccl_comm, const float* local_dev
  * masks_dev: uint8 [B][max_out][PH][PW] (rows >= counts[b] are left untouched).                       */
 yl_status yl_masks(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, const int32_t* counts_dev,
                    const int32_t* keep_idx_dev, int32_t max_out, float thr, uint8_t* masks_dev, void* stream);
+/* Masks at IMAGE resolution -- the form the pip API returns (README.md:38-42: results['masks']).  BUILD-DEFINED like
+ * yl_masks.  For detection i of image b (row dets_dev[b][i] = x1,y1,x2,y2,.. as written by yl_predict / yl_postprocess,
+ * i.e. ALREADY back-mapped when `backmap_dev` was given there; candidate keep_idx[b][i]) and every pixel (y,x) of the
+ * output grid of image b (h_b x w_b = out_hw_dev[b]: the original image, or S x S without back-map):
+ *     xs = (x + 0.5) * scale + padx,  ys = (y + 0.5) * scale + pady        letterbox coordinate of the pixel centre
+ *                                                                          (scale 1, pad 0 without backmap_dev)
+ *     u  = max(xs, 0) * (PW / S) - 0.5 clamped at 0,  v likewise           source index of a bilinear PW/S resize,
+ *                                                                          align_corners = false, edges replicated
+ *     m  = bilinear interpolation of sigmoid(mc . proto[b]) at (v, u)      4 prototype pixels
+ *     mask(y,x) = m > thr  and  x1 <= x < x2  and  y1 <= y < y2
+ * Output of image b starts at masks_dev + mask_off_dev[b] bytes: [min(counts[b], max_out)][h_b][row] with row = w_b
+ * uint8 (packed = 0) or ceil(w_b / 32) uint32 words, bit k of word j = pixel 32 j + k (packed = 1).
+ * max_h / max_w: the largest h_b / w_b of the batch (grid size).  The caller sizes masks_dev from the counts. */
+yl_status yl_masks_image(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, const float* dets_dev,
+                         const int32_t* counts_dev, const int32_t* keep_idx_dev, int32_t max_out, float thr,
+                         const float* backmap_dev, const int32_t* out_hw_dev, const int64_t* mask_off_dev, int32_t max_h,
+                         int32_t max_w, int32_t packed, uint8_t* masks_dev, void* stream);
 /* Replaces nms(boxes, scores, iou_th, max_det) (tools/infer.py:134-152): keep_dev[max_det] receives
  * the kept indices in score-descending order, count_dev[0] their number (<= max_det).              */
 yl_status yl_nms(yl_ctx* ctx, const float* boxes_dev, const float* scores_dev, int32_t n, float iou_thr,

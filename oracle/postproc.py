@@ -323,3 +323,46 @@ def masks_for(levels, protos: torch.Tensor, num_classes: int, img_size: int, kee
         inside = (xs >= x1[:, None, None]) & (xs < x2[:, None, None]) & (ys >= y1[:, None, None]) & (ys < y2[:, None, None])
         out.append(((m > thr) & inside).numpy().astype(np.uint8))
     return out
+
+
+@torch.no_grad()
+def masks_image_for(levels, protos: torch.Tensor, num_classes: int, img_size: int, keep_idx, det_boxes, out_hw,
+                    backmap=None, thr: float = 0.5):
+    """BUILD-DEFINED image-resolution masks (include/yololite_hip.h: yl_masks_image; no reference code exists, parity
+    unpinned).  For image b: kept candidates keep_idx[b], their OUTPUT boxes det_boxes[b] (back-mapped when `backmap`
+    = [(padx, pady, scale, w0, h0)] is given), output grid out_hw[b] = (h, w).  float32 throughout:
+        xs = (x + 0.5) * scale + padx;  u = max(max(xs, 0) * (PW / S) - 0.5, 0);  u0 = min(floor(u), PW-1),
+        u1 = min(u0 + 1, PW-1), lu = u - u0  (rows likewise);  m = lerp(lerp(p00, p01, lu), lerp(p10, p11, lu), lv)
+        with p = sigmoid(coef . proto);  mask = m > thr inside x1 <= x < x2, y1 <= y < y2.
+    Returns list of uint8 [Ni, h, w]."""
+    _, coef_lv = split_mask_levels(levels, num_classes)
+    B, NM, PH, PW = protos.shape
+    coefs = torch.cat([c.reshape(B, -1, NM) for c in coef_lv], 1)
+    f32 = np.float32
+    out = []
+    for b in range(B):
+        h, w = int(out_hw[b][0]), int(out_hw[b][1])
+        idx = torch.as_tensor(np.asarray(keep_idx[b], dtype=np.int64))
+        if idx.numel() == 0:
+            out.append(np.zeros((0, h, w), np.uint8))
+            continue
+        padx, pady, sc = (f32(0), f32(0), f32(1)) if backmap is None else (f32(backmap[b][0]), f32(backmap[b][1]), f32(backmap[b][2]))
+        prob = torch.sigmoid(torch.einsum("nk,kyx->nyx", coefs[b][idx], protos[b])).numpy()      # [N, PH, PW]
+
+        def taps(n, pad, P):
+            c = (np.arange(n, dtype=f32) + f32(0.5)) * sc + pad
+            u = np.maximum(np.maximum(c, f32(0)) * (f32(P) / f32(img_size)) - f32(0.5), f32(0))
+            i0 = np.minimum(np.floor(u).astype(np.int64), P - 1)
+            return i0, np.minimum(i0 + 1, P - 1), (u - i0.astype(f32)).astype(f32)
+        u0, u1, lu = taps(w, padx, PW)
+        v0, v1, lv_ = taps(h, pady, PH)
+        p00, p01 = prob[:, v0][:, :, u0], prob[:, v0][:, :, u1]
+        p10, p11 = prob[:, v1][:, :, u0], prob[:, v1][:, :, u1]
+        top = p00 + (p01 - p00) * lu[None, None, :]
+        bot = p10 + (p11 - p10) * lu[None, None, :]
+        m = top + (bot - top) * lv_[None, :, None]
+        bx = np.asarray(det_boxes[b], dtype=f32).reshape(-1, 4)
+        xs, ys = np.arange(w, dtype=f32)[None, None, :], np.arange(h, dtype=f32)[None, :, None]
+        inside = (xs >= bx[:, 0, None, None]) & (xs < bx[:, 2, None, None]) & (ys >= bx[:, 1, None, None]) & (ys < bx[:, 3, None, None])
+        out.append(((m > f32(thr)) & inside).astype(np.uint8))
+    return out

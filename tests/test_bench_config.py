@@ -154,6 +154,28 @@ def test_full_size_configs_3_and_4(name, seg):
         _assert_north_star(_rows(d1, c1, cand[i]), exp, i)
     got_s = _score_tensor([t[cand].cpu() for t in la])
     assert float((got_s - _score_tensor(det_lv)).abs().max()) <= 1e-4
+    if seg:
+        # config 4: image-resolution masks (640 x 640 input grid, no back-map) of the sampled images vs the oracle's
+        # restatement on the ORACLE's own levels / prototypes, mask IoU >= 0.999 (north_star); packed == unpacked
+        ctx.set_option("graph", 0); ctx.set_option("streams", 1)
+        d2, c2, i2 = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo, want_idx=True)
+        mk = ctx.masks_image(d2, c2, i2)
+        mp = ctx.masks_image(d2, c2, i2, packed=True)
+        tot_i = tot_u = 0
+        for i in sel:
+            b = cand[i]
+            n = min(int(c2[b]), 48)                                # the oracle materialises [n, 640, 640] floats
+            keep = [i2[b, :n].cpu().numpy()]
+            boxes = [d2[b, :n, :4].cpu().numpy()]
+            exp = opost.masks_image_for([t[i:i + 1] for t in ref_lv], ref_pr[i:i + 1], 80, 640, keep, boxes, [(640, 640)])[0]
+            got = mk[b][:n].cpu().numpy().astype(bool)
+            inter, union = (got & exp.astype(bool)).sum(), (got | exp.astype(bool)).sum()
+            tot_i += int(inter); tot_u += int(union)
+            assert union == 0 or inter / union >= 0.999, (b, inter, union)
+            words = mp[b][:n].cpu().numpy().view(np.uint32)
+            bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, 640, -1)[..., :640].astype(bool)
+            assert np.array_equal(bits, got)
+        assert tot_u > 1000, tot_u
 
 
 def test_config1_edge_n_640_batch1_through_cli(tmp_path):

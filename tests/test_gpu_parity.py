@@ -635,6 +635,27 @@ def test_seg_model_forward_and_masks(name, B, S):
             assert union == 0 or inter / union >= 0.999, (thr, b, inter, union)
             total += int(union)
     assert total > 100
+    # image-resolution masks through a letterbox: original images of different sizes / aspect ratios
+    hw = [(S // 2 + 7, S), (S + 40, S * 2 // 3)][:B]
+    bm = []
+    for (h0, w0) in hw:
+        sc = min(S / h0, S / w0)
+        nh, nw = int(round(h0 * sc)), int(round(w0 * sc))
+        bm.append(((S - nw) // 2, (S - nh) // 2, sc, w0, h0))
+    bmt = torch.tensor(bm, dtype=torch.float32)
+    d3, c3, i3 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.02, 0.5, per_class_cap=300, want_idx=True, backmap=bmt)
+    got = ctx.masks_image(d3, c3, i3, backmap=bmt, thr=0.3)
+    keep3 = [i3[b, :int(c3[b])].cpu().numpy() for b in range(B)]
+    box3 = [d3[b, :int(c3[b]), :4].cpu().numpy() for b in range(B)]
+    exp3 = opost.masks_image_for(lv_cpu, pr.cpu(), 80, S, keep3, box3, hw, backmap=bm, thr=0.3)
+    tot = 0
+    for b in range(B):
+        g, e = got[b].cpu().numpy().astype(bool), exp3[b].astype(bool)
+        assert g.shape == e.shape == (int(c3[b]), hw[b][0], hw[b][1])
+        inter, union = (g & e).sum(), (g | e).sum()
+        assert union == 0 or inter / union >= 0.999, (b, inter, union)
+        tot += int(union)
+    assert tot > 100
     # detections themselves: same as the detector-only pipeline run on the detection part of the rows
     exp_det = opost.pipeline_main([t[..., :85] for t in lv_cpu], S, 0.02, 0.5, 300)
     for b in range(B):

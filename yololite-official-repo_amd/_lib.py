@@ -70,6 +70,8 @@ SYMBOLS = [
     ("yl_predict", C.c_int32, [_vp, _vp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp, _vp]),
     ("yl_allgather_dets", C.c_int32, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
     ("yl_masks", C.c_int32, [_vp, _vpp, C.c_int32, _vp, _vp, C.c_int32, C.c_float, _vp, _vp]),
+    ("yl_masks_image", C.c_int32, [_vp, _vpp, C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_float, _vp, _vp, _vp, C.c_int32,
+                                   C.c_int32, C.c_int32, _vp, _vp]),
     ("yl_nms", C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     ("yl_eval_match", C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_double, _vp, _vp, _vp, _vp]),
     ("yl_eval_sweep", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp]),

@@ -43,10 +43,10 @@ class YoloLite:
         t1 = time.perf_counter()
         ctx.set_option("time_split", 1 if profile else 0)
         masks = None
-        if ctx.NM:                                              # build-defined seg model
+        if ctx.NM:                                              # build-defined seg model: masks at ORIGINAL image resolution
             dets, counts, idx = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300,
                                             backmap=torch.from_numpy(bm), want_idx=True)
-            masks = ctx.masks(counts, idx, dets.shape[1]).cpu().numpy()
+            masks = [m.cpu().numpy() for m in ctx.masks_image(dets, counts, idx, backmap=torch.from_numpy(bm))]
         else:
             dets, counts = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300, backmap=torch.from_numpy(bm))
         cn = counts.cpu().numpy()
@@ -64,5 +64,5 @@ class YoloLite:
         for b in range(n):
             r = d[b, :min(int(cn[b]), d.shape[1])]
             out.append({"boxes": r[:, :4].copy(), "scores": r[:, 4].copy(), "classes": r[:, 5].astype(np.int64),
-                        "masks": (masks[b, :len(r)].copy() if masks is not None else None), "speed": dict(speed)})
+                        "masks": (masks[b] if masks is not None else None), "speed": dict(speed)})
         return out

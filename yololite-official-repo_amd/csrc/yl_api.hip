@@ -1208,6 +1208,28 @@ yl_status yl_masks(yl_ctx* c, const float* const* levels, int32_t B, const int32
   return YL_OK;
 }
 
+yl_status yl_masks_image(yl_ctx* c, const float* const* levels, int32_t B, const float* dets, const int32_t* counts,
+                         const int32_t* keep_idx, int32_t max_out, float thr, const float* backmap,
+                         const int32_t* out_hw, const int64_t* mask_off, int32_t max_h, int32_t max_w, int32_t packed,
+                         uint8_t* masks, void* stream) {
+  if (!c || !dets || !counts || !keep_idx || !out_hw || !mask_off || !masks || B < 1 || max_out < 1 || max_h < 1 || max_w < 1)
+    return YL_ERR_INVALID;
+  if (c->NM <= 0 || c->proto_slot < 0) return fail(c, YL_ERR_STATE, "context has no mask branch");
+  if (B > c->cap_batch || !c->slots[c->proto_slot].pin)
+    return fail(c, YL_ERR_STATE, "yl_masks_image needs a preceding yl_predict / yl_forward of this batch");
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* lp[YL_MAX_LEVELS];
+  for (int l = 0; l < c->L; ++l) lp[l] = (levels && levels[l]) ? levels[l] : c->level_buf[l];
+  YlLevels lv;
+  fill_levels(c, lp, lv);
+  const Slot& ps = c->slots[c->proto_slot];
+  static_assert(sizeof(long long) == sizeof(int64_t), "offset type");
+  HIPCHK(c, yl_launch_masks_image(lv, B, ps.pin, ps.h, ps.w, c->NM, c->img_size, dets, counts, keep_idx, max_out, thr,
+                                  backmap, out_hw, (const long long*)mask_off, max_h, max_w, packed ? 1 : 0, masks,
+                                  (hipStream_t)stream));
+  return YL_OK;
+}
+
 // the one exchange of the multi-GPU path, for hosts that do not go through torch.distributed.  RCCL is
 // NOT a link-time dependency of this library: ncclAllGather is looked up among the libraries already loaded in the
 // process, i.e. the RCCL that created the caller's communicator (PyTorch ships its own copy).

@@ -123,6 +123,10 @@ hipError_t yl_launch_preprocess(const unsigned char* src, const void* imgs, int 
 hipError_t yl_launch_masks(const YlLevels& lv, int B, const float* proto, int PH, int PW, int NM, int img_size,
                            const float4* boxes, const int* counts, const int* keep_idx, int max_out, float thr,
                            unsigned char* masks, hipStream_t st);
+hipError_t yl_launch_masks_image(const YlLevels& lv, int B, const float* proto, int PH, int PW, int NM, int S,
+                                 const float* dets, const int* counts, const int* keep_idx, int max_out, float thr,
+                                 const float* backmap, const int* out_hw, const long long* mask_off, int max_h, int max_w,
+                                 int packed, unsigned char* masks, hipStream_t st);
 hipError_t yl_post_init();   // one-time function attributes (large dynamic LDS)
 
 hipError_t yl_launch_stem(const YlConvP& p, hipStream_t st);

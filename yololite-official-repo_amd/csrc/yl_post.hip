@@ -918,6 +918,137 @@ hipError_t yl_launch_masks(const YlLevels& lv, int B, const float* proto, int PH
 }
 
 // ------------------------------------------------------------------------------------------------
+// Instance masks at IMAGE resolution (BUILD-DEFINED, see include/yololite_hip.h: yl_masks_image): for every kept
+// detection, sigmoid(mc . proto) on the prototype grid, bilinear (align_corners = false, edge-replicating like
+// F.interpolate) sampling at the centre of every pixel of the ORIGINAL image mapped through the letterbox, crop to the
+// detection's box, threshold -- one pass, no intermediate full-resolution probability map.
+// Work split: a workgroup owns a 64 x 4 pixel tile of one image's output grid for ALL detections of that image.
+// The prototype vectors the tile can touch (its bilinear footprint, a few dozen prototype pixels) are staged in LDS
+// once; per detection that intersects the tile the workgroup evaluates the probabilities on that footprint (one
+// prototype pixel per thread: NM MACs + one sigmoid), then every thread interpolates its pixel from 4 LDS values.
+// Detections that miss the tile cost a zero store.  Output: uint8 per pixel, or bit-packed rows (32 pixels per
+// uint32, LSB = leftmost) -- 1/8 of the bytes, the form the benchmark uses.
+#define YL_MI_MAXPATCH 160
+struct YlMaskImgP {
+  const float* proto; int PH, PW, NM;          // [B][PH][PW][NM]
+  int S;                                        // network input size
+  const float* dets; const int* counts; const int* keep_idx; int max_out;
+  const float* backmap;                         // [B][5] padx,pady,scale,w0,h0 or nullptr (masks on the S x S input grid)
+  const int* out_hw;                            // [B][2] output height, width
+  const long long* mask_off;                    // [B] byte offset of image b's masks
+  unsigned char* masks; float thr; int packed;
+};
+
+__global__ __launch_bounds__(256) void yl_masks_image_kernel(YlLevels lv, YlMaskImgP p) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) float mi_lds[];
+  const int b = blockIdx.z;
+  const int H = p.out_hw[2 * b], W = p.out_hw[2 * b + 1];
+  const int x0t = blockIdx.x * 64, y0t = blockIdx.y * 4;
+  if (x0t >= W || y0t >= H) return;
+  const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+  const int x = x0t + lane, y = y0t + row;
+  const int NM = p.NM;
+  float sx = 1.0f, padx = 0.0f, pady = 0.0f;
+  if (p.backmap) { padx = p.backmap[5 * b]; pady = p.backmap[5 * b + 1]; sx = p.backmap[5 * b + 2]; }
+  const float kx = (float)p.PW / (float)p.S, ky = (float)p.PH / (float)p.S;
+  // prototype-grid coordinate of a pixel centre: letterbox coordinate (c + 0.5) * scale + pad, then the
+  // align_corners = false source index of a PW/S resize, clamped at 0 (F.interpolate)
+  auto src_u = [&](int c, float pad, float k) { return fmaxf(((float)c + 0.5f) * sx + pad, 0.0f) * k - 0.5f; };
+  const int xl = min(x0t + 63, W - 1), yl_ = min(y0t + 3, H - 1);
+  const int pu0 = max(min((int)floorf(fmaxf(src_u(x0t, padx, kx), 0.0f)), p.PW - 1), 0);
+  const int pv0 = max(min((int)floorf(fmaxf(src_u(y0t, pady, ky), 0.0f)), p.PH - 1), 0);
+  const int pu1 = min(min((int)floorf(fmaxf(src_u(xl, padx, kx), 0.0f)), p.PW - 1) + 1, p.PW - 1);
+  const int pv1 = min(min((int)floorf(fmaxf(src_u(yl_, pady, ky), 0.0f)), p.PH - 1) + 1, p.PH - 1);
+  const int pw = pu1 - pu0 + 1, ph = pv1 - pv0 + 1, np = pw * ph;
+  const bool staged = np <= YL_MI_MAXPATCH;               // else (extreme up-scaling): prototypes straight from memory
+  float* coef = mi_lds;                                   // [64]
+  float* pbuf = mi_lds + 64;                              // [YL_MI_MAXPATCH] probabilities of the footprint
+  float* patch = pbuf + YL_MI_MAXPATCH;                   // [np][NM]
+  const float* pimg = p.proto + (size_t)b * p.PH * p.PW * NM;
+  if (staged) {
+    for (int i = tid; i < np * NM; i += 256) {
+      const int q = i / NM, k = i - q * NM;
+      const int v = pv0 + q / pw, u = pu0 + q % pw;
+      patch[i] = pimg[((size_t)v * p.PW + u) * NM + k];
+    }
+  }
+  // this pixel's bilinear taps
+  const bool live = x < W && y < H;
+  const float fu_ = fmaxf(src_u(x, padx, kx), 0.0f), fv_ = fmaxf(src_u(y, pady, ky), 0.0f);
+  const int u0 = min((int)floorf(fu_), p.PW - 1), v0 = min((int)floorf(fv_), p.PH - 1);
+  const int u1 = min(u0 + 1, p.PW - 1), v1 = min(v0 + 1, p.PH - 1);
+  const float lu = fu_ - (float)u0, lv_ = fv_ - (float)v0;
+  const int n = min(p.counts[b], p.max_out);
+  unsigned char* mb = p.masks + p.mask_off[b];
+  const size_t wrow = p.packed ? (size_t)((W + 31) >> 5) * 4 : (size_t)W;      // bytes per mask row
+  for (int d = 0; d < n; ++d) {
+    const float* dr = p.dets + ((size_t)b * p.max_out + d) * 6;
+    const float x1 = dr[0], y1 = dr[1], x2 = dr[2], y2 = dr[3];
+    // tile / box intersection (same predicate as the per-pixel test below)
+    const bool hit = (float)min(x0t + 63, W - 1) >= x1 && (float)x0t < x2 && (float)min(y0t + 3, H - 1) >= y1 && (float)y0t < y2;
+    bool on = false;
+    if (hit) {                                            // workgroup-uniform
+      __syncthreads();                                    // previous detection's pbuf / coef reads are done
+      if (tid < NM) {
+        const int cand = p.keep_idx[(size_t)b * p.max_out + d];
+        const int l = yl_level_of(lv, cand);
+        const int nl = lv.A[l] * lv.S[l] * lv.S[l];
+        coef[tid] = lv.ptr[l][((size_t)b * nl + (cand - lv.off[l])) * lv.E + 5 + lv.C + tid];
+      }
+      __syncthreads();
+      if (staged) {
+        if (tid < np) {
+          float acc = 0.0f;
+          for (int k = 0; k < NM; ++k) acc = fmaf(coef[k], patch[tid * NM + k], acc);
+          pbuf[tid] = yl_sigmoid(acc);
+        }
+        __syncthreads();
+      }
+      if (live && (float)x >= x1 && (float)x < x2 && (float)y >= y1 && (float)y < y2) {
+        float p00, p01, p10, p11;
+        if (staged) {
+          p00 = pbuf[(v0 - pv0) * pw + (u0 - pu0)]; p01 = pbuf[(v0 - pv0) * pw + (u1 - pu0)];
+          p10 = pbuf[(v1 - pv0) * pw + (u0 - pu0)]; p11 = pbuf[(v1 - pv0) * pw + (u1 - pu0)];
+        } else {
+          auto prob = [&](int v, int u) {
+            const float* q = pimg + ((size_t)v * p.PW + u) * NM;
+            float acc = 0.0f;
+            for (int k = 0; k < NM; ++k) acc = fmaf(coef[k], q[k], acc);
+            return yl_sigmoid(acc);
+          };
+          p00 = prob(v0, u0); p01 = prob(v0, u1); p10 = prob(v1, u0); p11 = prob(v1, u1);
+        }
+        const float top = p00 + (p01 - p00) * lu, bot = p10 + (p11 - p10) * lu;
+        on = (top + (bot - top) * lv_) > p.thr;
+      }
+    }
+    unsigned char* mrow = mb + ((size_t)d * H + y) * wrow;
+    if (p.packed) {
+      const unsigned long long bits = __ballot(on);
+      if (y < H && (lane & 31) == 0 && x < W) *reinterpret_cast<unsigned*>(mrow + (size_t)(x >> 5) * 4) = (unsigned)(bits >> (lane & 32));
+    } else if (live) {
+      mrow[x] = on ? 1 : 0;
+    }
+  }
+}
+
+hipError_t yl_launch_masks_image(const YlLevels& lv, int B, const float* proto, int PH, int PW, int NM, int S,
+                                 const float* dets, const int* counts, const int* keep_idx, int max_out, float thr,
+                                 const float* backmap, const int* out_hw, const long long* mask_off, int max_h, int max_w,
+                                 int packed, unsigned char* masks, hipStream_t st) {
+  if (NM > 64 || max_h < 1 || max_w < 1) return hipErrorInvalidValue;
+  YlMaskImgP p;
+  p.proto = proto; p.PH = PH; p.PW = PW; p.NM = NM; p.S = S; p.dets = dets; p.counts = counts; p.keep_idx = keep_idx;
+  p.max_out = max_out; p.backmap = backmap; p.out_hw = out_hw; p.mask_off = mask_off; p.masks = masks; p.thr = thr;
+  p.packed = packed;
+  const size_t lds = (size_t)(64 + YL_MI_MAXPATCH + YL_MI_MAXPATCH * NM) * sizeof(float);
+  dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, B);
+  hipLaunchKernelGGL(yl_masks_image_kernel, grid, dim3(256), lds, st, lv, p);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 static int g_nms_lds_max = 0;
 
 hipError_t yl_post_init() {

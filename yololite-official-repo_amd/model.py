@@ -225,6 +225,46 @@ class HipContext:
                                      float(thr), out.data_ptr(), _stream_ptr(self.device)), self.handle, "yl_masks")
         return out
 
+    def masks_image(self, dets: torch.Tensor, counts: torch.Tensor, keep_idx: torch.Tensor, backmap=None, out_hw=None,
+                    thr: float = 0.5, packed: bool = False, levels: Optional[Sequence[torch.Tensor]] = None):
+        """Image-resolution instance masks of the detections of the last predict() (yl_masks_image, build-defined).
+        backmap: the [B,5] rows given to predict() (then `dets` are already in original-image coordinates and
+        out_hw[b] = (h0, w0)); None: masks on the S x S network-input grid.  Returns a list of B device tensors:
+        uint8 [Ni, h_b, w_b], or with packed=True uint32 [Ni, h_b, ceil(w_b/32)] (bit k of word j = pixel 32j+k)."""
+        B, max_out = int(dets.shape[0]), int(dets.shape[1])
+        cn = np.minimum(counts.cpu().numpy().astype(np.int64), max_out)
+        if out_hw is None:
+            if backmap is not None:
+                bmh = np.asarray(backmap.cpu() if torch.is_tensor(backmap) else backmap, dtype=np.float64).reshape(B, 5)
+                out_hw = np.stack([bmh[:, 4], bmh[:, 3]], 1)
+            else:
+                out_hw = np.full((B, 2), self.img_size)
+        hw = np.ascontiguousarray(np.asarray(out_hw).reshape(B, 2), np.int32)
+        rowb = (((hw[:, 1].astype(np.int64) + 31) // 32) * 4) if packed else hw[:, 1].astype(np.int64)
+        sizes = cn * hw[:, 0].astype(np.int64) * rowb
+        sizes = (sizes + 15) & ~15
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        total = int(sizes.sum())
+        buf = torch.empty((max(total, 16),), device=self.device, dtype=torch.uint8)
+        hw_d = torch.from_numpy(hw).to(self.device)
+        off_d = torch.from_numpy(offs).to(self.device)
+        bm_d = None
+        if backmap is not None:
+            bm_d = (backmap if torch.is_tensor(backmap) else torch.as_tensor(np.asarray(backmap, np.float32)))
+            bm_d = bm_d.to(device=self.device, dtype=torch.float32).contiguous()
+        arr = self._ptr_array(self._check_levels(levels)) if levels is not None else None
+        _lib.check(self.lib.yl_masks_image(self.handle, arr, B, dets.data_ptr(), counts.data_ptr(), keep_idx.data_ptr(),
+                                           max_out, float(thr), bm_d.data_ptr() if bm_d is not None else None,
+                                           hw_d.data_ptr(), off_d.data_ptr(), int(hw[:, 0].max()), int(hw[:, 1].max()),
+                                           1 if packed else 0, buf.data_ptr(), _stream_ptr(self.device)),
+                   self.handle, "yl_masks_image")
+        out = []
+        for b in range(B):
+            n, h, w = int(cn[b]), int(hw[b, 0]), int(hw[b, 1])
+            seg = buf[int(offs[b]):int(offs[b]) + n * h * int(rowb[b])]
+            out.append(seg.view(torch.int32).view(n, h, (w + 31) // 32) if packed else seg.view(n, h, w))
+        return out
+
     def predict(self, x: torch.Tensor, mode, conf, iou, per_class_cap=300, topk=0, max_out=None, backmap=None,
                 out: Optional[tuple] = None, want_idx: bool = False, center_mode="v8", wh_mode="softplus",
                 fallback_nms: int = _lib.NMS_TORCHVISION):
