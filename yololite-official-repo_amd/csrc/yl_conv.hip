@@ -37,6 +37,7 @@
 #define yl_uib_lds_bytes yl_uib_lds_bytes_bf16
 #define yl_launch_conv_dwc yl_launch_conv_dwc_bf16
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
+#define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #endif
 #include <stdio.h>
 #include <stdlib.h>
@@ -1203,6 +1204,11 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   if (n == 1 && p.dw_k == 0 && p.k == 1 && p.stride == 1 && tile_hint != 6) {
     const hipError_t ep = yl_launch_conv_pwt(p, st);
     if (ep != hipErrorNotSupported) return ep;
+  }
+  // dense k x k with a weight image beyond LDS: double-buffered weight stream (yl_convc.hip); tile_hint 6 = off
+  if (n == 1 && p.dw_k == 0 && p.k > 1 && tile_hint != 6) {
+    const hipError_t ek = yl_launch_conv_kxk(p, st);
+    if (ek != hipErrorNotSupported) return ek;
   }
   // depthwise prologue with LDS-staged halo tiles (4x4 output pixels per wave)
   bool halo = p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.N & 3) == 0 &&

@@ -30,6 +30,8 @@
 #define yl_convc_init yl_convc_init_bf16
 #define yl_conv_pwt_kernel yl_conv_pwt_kernel_bf16
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
+#define yl_conv_kxk_kernel yl_conv_kxk_kernel_bf16
+#define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #endif
 #include <stdlib.h>
 #include <map>
@@ -490,6 +492,187 @@ hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense k x k convolution whose weights do not fit LDS (yololite_m's FPN: 3x3, 328 -> 328 channels = 3.9 MB packed,
+// 16.3 of the model's ~24 GMAC per image; model_v2.py:15-22,125-127) as an implicit GEMM with the weight stream
+// DOUBLE-BUFFERED through LDS.  yl_conv_mfma_kernel streams the same weights in 48 KiB chunks between two
+// workgroup barriers each (fill, then use): while a chunk is fetched the workgroup's four waves issue no MFMA,
+// and with 21 n-tiles split 8 + 8 + 5 an eighth of the issued MFMAs multiplies zero padding -- 75 TFLOP/s = 0.48 of
+// the fp32 MFMA peak.  Here: NT = 7 n-tiles per workgroup (21 = 3 x 7, no padding), chunks of CH k-steps in two LDS
+// buffers, the asynchronous global->LDS copies of chunk c+1 issued before the MFMAs of chunk c (ONE barrier per
+// chunk, which is also where the copies are waited for), the chunk pipeline running on across tile boundaries.
+// Same transposed GEMM, k order and epilogues as yl_conv_mfma_kernel: bit-identical results.
+template <int NT, int MT>
+__global__ __launch_bounds__(256, 3) void yl_conv_kxk_kernel(YlConvP p, int CH) {
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int nt0 = blockIdx.y * NT;
+  const int ntc = (p.NTtot - nt0) < NT ? (p.NTtot - nt0) : NT;
+  const int TK = p.TK, KB = p.KB, K = p.k, NTtot = p.NTtot;
+  const int Cin = p.Cin, H = p.H, W = p.W, stride = p.stride, pad_t = p.pad_t, pad_l = p.pad_l, sh = p.in_shift;
+  const int ohw = p.OH * p.OW, OW = p.OW, M = p.M;
+  const float* const xin = p.x;
+  const long zdelta = p.zeros - p.x;
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][CH][NT][64] float4
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
+  const int NC = (TK + CH - 1) / CH;                         // chunks per tile
+  const int bx = blockIdx.x, gx = gridDim.x;
+  const int nmine = bx < p.ntiles ? (p.ntiles - 1 - bx) / gx + 1 : 0;
+  const long total_chunks = (long)nmine * NC;
+
+  // asynchronous copy of chunk c (k-steps [c*CH, min(TK, c*CH+CH))) into buffer `buf`: (k-step, n-tile) pieces of
+  // 1 KiB dealt round-robin to the four waves; padding n-tiles of a partial last n-chunk are zero-filled
+  auto load_chunk = [&](int c, int buf) {
+    const int c0 = c * CH, c1 = (c0 + CH) < TK ? (c0 + CH) : TK;
+    const int items = (c1 - c0) * NT;
+    for (int i = wave; i < items; i += 4) {
+      const int t = c0 + i / NT, nt = i % NT;
+      f32x4* dst = wl + ((size_t)buf * CH * NT + (size_t)(t - c0) * NT + nt) * 64;
+      if (nt < ntc) yl_glds16(wg + ((size_t)t * NTtot + nt0 + nt) * 64 + lane, dst);
+      else dst[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (total_chunks > 0) load_chunk(0, 0);
+  long gchunk = 0;                                            // chunks consumed so far (buffer = gchunk & 1)
+  __syncthreads();
+  const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE;
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+
+  for (int ti = 0; ti < nmine; ++ti) {
+    const int tile = bx + ti * gx;
+    YlPix px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      size_t lin = ((size_t)tile * 4 + wave) * (MT * 16) + mt * 16 + pl;
+      px[mt].valid = lin < (size_t)M;
+      if (!px[mt].valid) lin = (size_t)M - 1;
+      px[mt].lin = lin;
+      const int b = (int)(lin / ohw);
+      const int rem = (int)(lin - (size_t)b * ohw);
+      px[mt].b = b;
+      px[mt].oy = rem / OW;
+      px[mt].ox = rem - px[mt].oy * OW;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pre_add) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const size_t obase = px[mt].lin * p.N;
+        size_t up_off = 0;
+        if (p.up) {
+          const int uy = (px[mt].oy * p.UH) / p.OH, ux = (px[mt].ox * p.UW) / p.OW;
+          up_off = (((size_t)px[mt].b * p.UH + uy) * p.UW + ux) * p.N;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = (nt0 + nt) * 16 + 4 * kq;
+          if (n < p.N) {
+            if (p.res) acc[mt][nt] = yl_ld4(p.res + obase + n);
+            if (p.up) acc[mt][nt] += yl_ld4(p.up + up_off + n);
+          }
+        }
+      }
+    }
+    // Activation stream of the lane's pixels: per TAP one base pointer (or the zero buffer when the tap falls outside
+    // the image), advanced by 16 channels per k-step -- the per-step address arithmetic is one pointer add and one
+    // select for the channel tail instead of a full (b, y, x, c) recomputation (fp32 MFMA and VALU share the FMA
+    // lanes: every VALU op in this loop is MFMA time).
+    const float* ptr[MT];          // activations of the NEXT k-step to fetch
+    int inc[MT];
+    int ntap = 0, nkb = 0;         // (tap, channel block) of the next fetch
+    auto tap_setup = [&](int tap) {
+      const int ky = tap / K, kx = tap - ky * K;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int iy = px[mt].oy * stride - pad_t + ky, ix = px[mt].ox * stride - pad_l + kx;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const long off = in ? ((((long)px[mt].b * (H >> sh) + (iy >> sh)) * (W >> sh) + (ix >> sh)) * Cin + 4 * kq) : zdelta;
+        ptr[mt] = xin + off;
+        inc[mt] = in ? 16 : 0;
+      }
+    };
+    auto fetch_next = [&](f32x4 (&dst)[MT]) {
+      const bool tail = nkb * 16 + 4 * kq >= Cin;                 // channel tail of the last block: zeros
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        dst[mt] = yl_ld4(tail ? xin + zdelta : ptr[mt]);
+        ptr[mt] += inc[mt];
+      }
+      if (++nkb == KB) {
+        nkb = 0;
+        if (++ntap < K * K) tap_setup(ntap);                      // (after the last tap the pointers are not used again)
+      }
+    };
+    tap_setup(0);
+    f32x4 xq[MT];
+    fetch_next(xq);
+    for (int c = 0; c < NC; ++c, ++gchunk) {
+      const int buf = (int)(gchunk & 1);
+      // next chunk of the stream (this tile's, or the first one of the workgroup's next tile) into the other buffer
+      if (gchunk + 1 < total_chunks) load_chunk(c + 1 < NC ? c + 1 : 0, buf ^ 1);
+      const int c0 = c * CH, c1 = (c0 + CH) < TK ? (c0 + CH) : TK;
+      const f32x4* wb = wl + (size_t)buf * CH * NT * 64 + lane;
+      for (int t = c0; t < c1; ++t) {
+        f32x4 xn[MT];
+        if (t + 1 < TK) fetch_next(xn);
+        else {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) xn[mt] = xq[mt];
+        }
+        f32x4 wq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wq[nt] = wb[((size_t)(t - c0) * NT + nt) * 64];
+        yl_mma_step<NT, MT>(wq, xq, acc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xq[mt] = xn[mt];
+      }
+      __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
+    }
+    if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, true);
+  }
+}
+
+template <int NT, int MT>
+static hipError_t kxk_go(const YlConvP& p0, int gy, int CH, hipStream_t st, bool attr_only) {
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_kxk_kernel<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  YlConvP p = p0;
+  p.ntiles = (int)(((long)p.M + 64 * MT - 1) / (64 * MT));
+  const size_t lds = (size_t)2 * CH * NT * 1024;
+  static int res_cache[16] = {0};
+  int& res = res_cache[(CH & 7) * 2 + (MT - 1)];
+  if (!res) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)yl_conv_kxk_kernel<NT, MT>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (nb > 4) nb = 4;
+    res = nb * YL_NUM_CU;
+  }
+  int gx = (res / gy) & ~7;
+  if (gx < 8) gx = 8;
+  if (gx > p.ntiles) gx = p.ntiles;
+  hipLaunchKernelGGL((yl_conv_kxk_kernel<NT, MT>), dim3(gx, gy), dim3(256), lds, st, p, CH);
+  return hipGetLastError();
+}
+
+// dense k x k (k > 1) layers with N % 4 == 0 whose weight image exceeds the LDS budget and whose n-tile count is a
+// multiple of 7.  hipErrorNotSupported otherwise (yl_conv_mfma_kernel then runs the layer).
+hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
+  if (p.k < 2 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.NTtot % 7 != 0) return hipErrorNotSupported;
+  if ((size_t)p.TK * 7 * 1024 <= 96 * 1024) return hipErrorNotSupported;      // small enough to stay resident: other kernel
+  static const int CH = getenv("YL_KXK_CH") ? atoi(getenv("YL_KXK_CH")) : 3;
+  static const int MTsel = getenv("YL_KXK_MT") ? atoi(getenv("YL_KXK_MT")) : 1;
+  const int gy = p.NTtot / 7;
+  return MTsel == 1 ? kxk_go<7, 1>(p, gy, CH, st, false) : kxk_go<7, 2>(p, gy, CH, st, false);
+}
+
+// ------------------------------------------------------------------------------------------------
 namespace {
 
 template <typename K>
@@ -545,6 +728,10 @@ int kbmax_of(int ntw) { return ntw == 1 ? 18 : ntw == 2 ? 9 : ntw == 3 ? 6 : 4; 
 
 hipError_t yl_convc_init() {
   YlConvMulti m = {};
+  YlConvP q = {};
+  hipError_t e = kxk_go<7, 1>(q, 1, 3, nullptr, true);
+  if (e == hipSuccess) e = kxk_go<7, 2>(q, 1, 3, nullptr, true);
+  if (e != hipSuccess) return e;
   return dwc_any(m, 0, 0, 0, 0, 0, nullptr, true, nullptr);
 }
 
