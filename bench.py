@@ -429,18 +429,29 @@ def main():
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
         roof["traffic"] = None
         # HBM-side bytes per launch from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, separate runs, tools/profile_round.sh): bench.py cannot run the profiler on itself
+        # WRITE_SIZE, separate runs, tools/profile_round.sh): bench.py cannot run the profiler on itself.  The
+        # counters are corrected with factors measured on INDEPENDENT kernels of known byte counts in the same lane
+        # access patterns (tools/fetch_calib.hip -> profiles/r02_fetch_calibration.json): FETCH_SIZE reads 0.50-0.53
+        # of the bytes for 4-, 12- and 16-byte lane reads alike, WRITE_SIZE 1.00.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc_file = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)["kernels"]
+            ffac = 0.5
+            try:
+                with open(os.path.join(ROOT, "profiles", "r02_fetch_calibration.json")) as f:
+                    cal = json.load(f)["kernels"]
+                ffac = cal["calib_x3s8" if L.op == 3 else "calib_x4"]["counter_over_actual"]
+            except (OSError, KeyError, ValueError):
+                pass
             kname = {3: "yl_stemblock_kernel"}.get(L.op)
             hit = [v for k, v in pmc.items() if kname and kname in k]
             if hit and B == 64 and args.model == "edge_n" and S == 640:
-                # FETCH_SIZE calibration: this kernel reads 4/12-byte lanes and its counter equals the input tensor
-                # bytes (315 MB) -- factor 1; the guide's x2 applies to 16-byte/lane streaming reads
-                roof["traffic"] = round((hit[0]["FETCH_SIZE_KB_mean"] + hit[0]["WRITE_SIZE_KB_mean"]) * 1024.0)
-                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE x1 + WRITE_SIZE, eager full-batch launches)"
-        except (OSError, KeyError, ValueError):
+                roof["traffic"] = round((hit[0]["FETCH_SIZE_KB_mean"] / ffac + hit[0]["WRITE_SIZE_KB_mean"]) * 1024.0)
+                roof["traffic_source"] = (f"profiles/{pmc_file}: FETCH_SIZE / {ffac} + WRITE_SIZE, eager full-batch launches; "
+                                          "factors from profiles/r02_fetch_calibration.json (independent known-byte-count kernels)")
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         roof["kernel"] = f"layer {k} {L.name} (yl_conv_mfma_kernel, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})" \
             if L.op == 1 else f"layer {k} {L.name}"
@@ -468,6 +479,7 @@ def main():
                        "max_out": max_out, "dets_dropped": dropped},
             "roofline": roof,
             "network": {"conv_gflop_per_image": round(2.0 * prog.macs / 1e9, 4), "launches": len(prog.layers),
+                        "activation_mb": round(ctx.activation_bytes() / 1e6, 1),
                         "forward_ms_sum_of_layers": round(fwd_ms, 4),
                         "forward_tflops": round(net_flops / (fwd_ms * 1e-3) / 1e12, 2),
                         "forward_frac_of_fp32_mfma_peak": round(net_flops / (fwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Round profile set (run on the MI355X box through gpurun; outputs under gpurun_out/prof_$TAG, summaries are then
-# copied into profiles/ by hand):   tools/profile_round.sh r01
-#   1. rocprofv3 --kernel-trace --stats of the bench command (per-kernel durations)
+# copied into profiles/ with tools/collect_profiles.sh):   tools/profile_round.sh r02
+#   1. rocprofv3 --kernel-trace --stats of the bench command (per-kernel durations), 2 streams and 1 stream
 #   2. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE, SQ set
-#   3. un-profiled bench line + per-layer table
-TAG=${1:-r01}
+#   3. un-profiled bench line + per-layer table; NMS-stress line; configs 3 and 4 (kernel stats + bench + layer table)
+#   4. FETCH_SIZE / WRITE_SIZE calibration on independent kernels (tools/fetch_calib.sh)
+TAG=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -18,10 +19,22 @@ PM="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --graph 0 --str
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $PM > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $PM > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o p --output-format csv -- $PM > $OUT/pmc_sq.log 2>&1
+for cfg in "yololite_m 0" "edge_m 1"; do
+  set -- $cfg
+  N=$1; [ "$2" == "1" ] && N=${1}_seg
+  rocprofv3 --kernel-trace --stats -d $OUT/stats_$N -o s --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --streams 1 > $OUT/stats_$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcf_$N -o p --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 > $OUT/pmcf_$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcw_$N -o p --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 > $OUT/pmcw_$N.log 2>&1
+done
 cd $ROOT
 python bench.py --steps 30 --warmup 5 --layers > $OUT/bench.json 2> $OUT/layers.txt
+python bench.py --steps 30 --warmup 5 --stress 1 --no-cpu-baseline > $OUT/bench_stress.json 2> /dev/null
+python bench.py --model yololite_m --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --layers > $OUT/bench_yololite_m.json 2> $OUT/layers_yololite_m.txt
+python bench.py --model edge_m --seg 1 --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --layers > $OUT/bench_edge_m_seg.json 2> $OUT/layers_edge_m_seg.txt
+python bench.py --workload eval > $OUT/bench_eval.json 2> /dev/null
+python bench.py --workload track > $OUT/bench_track.json 2> /dev/null
 {
-  echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE (KB per dispatch, mean; gfx950: wide coalesced reads report 1/2 of the bytes)"
+  echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE (KB per dispatch, mean; gfx950: reads are counted at ~1/2 of their bytes, see rNN_fetch_calibration.json)"
   python tools/pmc_summary.py $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1)
   echo; echo "# rocprofv3 --kernel-trace --pmc WRITE_SIZE (KB per dispatch, mean)"
   python tools/pmc_summary.py $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
@@ -31,4 +44,11 @@ python bench.py --steps 30 --warmup 5 --layers > $OUT/bench.json 2> $OUT/layers.
 python tools/pmc_summary.py --json $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) > $OUT/pmc_traffic.json
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/stats1 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_streams1.csv
+for N in yololite_m edge_m_seg; do
+  cp $(find $OUT/stats_$N -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_$N.csv
+  python tools/pmc_summary.py --json $(find $OUT/pmcf_$N -name '*counter_collection.csv' | head -1) $(find $OUT/pmcw_$N -name '*counter_collection.csv' | head -1) > $OUT/pmc_traffic_$N.json
+done
+tools/fetch_calib.sh gpurun_out/prof_$TAG/calib > $OUT/calib.log 2>&1
+# keep the merge-back small: raw traces are not needed
+rm -rf $OUT/stats $OUT/stats1 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/stats_* $OUT/pmcf_* $OUT/pmcw_* $OUT/calib/f $OUT/calib/w
 ls -la $OUT; tail -1 $OUT/bench.json | cut -c1-300
