@@ -292,7 +292,7 @@ def main():
                     "(program.calibrate_head), so every seed detects")
     ap.add_argument("--stress", type=int, default=0, help="1: round-1 NMS stress workload instead (uncalibrated head noise, "
                     "~2000 survivors in 10 classes; rows beyond max_out are dropped) -- labelled in the JSON")
-    ap.add_argument("--nms-groups", type=int, default=4, help="NMS workgroups per image (classes split mod G)")
+    ap.add_argument("--nms-groups", type=int, default=0, help="NMS workgroups per image (0 = auto: 1 at detector thresholds, 4 at conf < 0.05)")
     ap.add_argument("--hybrid", type=int, default=0, help="full-batch launches for the high-resolution layers, chunks only for the low-resolution run")
     ap.add_argument("--batch-levels", type=int, default=1, help="smooth / head layers of all pyramid levels as one launch")
     ap.add_argument("--fuse-decode", type=int, default=1, help="decode inside the head-output conv epilogue")

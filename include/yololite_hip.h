@@ -181,7 +181,8 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
 /* Options: "graph" (0/1: replay the whole call from a captured hipGraph), "streams" (1..4 internal
  * streams the batch is split over; default 2), "tile_m" (conv M-tile hint), "lanes" (0/1, default 0: neck/head
  * layers of the coarser levels run on a side stream next to the finest level's chain),
- * "nms_groups" (1..4, default 4: NMS workgroups per image, classes split mod G; main / eval modes),
+ * "nms_groups" (0..4, default 0 = auto: NMS workgroups per image, classes dealt to the groups by load; auto takes 4 at
+ * evaluation thresholds (conf < 0.05: thousands of survivors per image) and 1 otherwise; main / eval modes),
  * "hybrid" (0/1, default 0: high-resolution layers run as full-batch launches, only the run of <= 1/16-resolution
  * layers is split into batch chunks over the internal streams), "batch_levels" (0/1, default 1: head trunks /
  * head outputs of all pyramid levels in one launch each),

@@ -89,6 +89,13 @@ def test_bench_configuration_edge_n_b64_parity():
     assert cn.min() >= 50 and cn.max() <= mo, (cn.min(), cn.max())          # every image detects, nothing dropped
     ncls = [len(np.unique(_rows(d0, c0, b)[2])) for b in range(64)]
     assert np.mean(ncls) >= 40, np.mean(ncls)
+    for g in (4, 2, 1):                                                      # NMS class-group split: same detections
+        ctx.set_option("nms_groups", g)
+        dg, cg = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
+        assert torch.equal(cg, c0), g
+        for b in range(64):
+            assert torch.equal(dg[b, :cn[b]], d0[b, :cn[b]]), (g, b)
+    ctx.set_option("nms_groups", 0)
     # ---- the bench schedule (bench.py defaults): hipGraph replay, 2 streams, level-batched heads, fused decode
     for k, v in (("graph", 1), ("streams", 2), ("batch_levels", 1), ("fuse_decode", 1)):
         ctx.set_option(k, v)

@@ -84,7 +84,7 @@ struct yl_ctx {
   int nms_gP = 0;
   // options
   int opt_graph = 0, opt_tile_m = 0, opt_streams = 2;
-  int opt_nms_groups = YL_NMS_GROUPS;   // workgroups per image in the NMS kernel (1 = single)
+  int opt_nms_groups = 0;    // workgroups per image in the NMS kernel: 1..4, 0 = auto (by confidence threshold, see do_post)
   int opt_hybrid = 0;        // (off: measured -0.5 % at B=64) full-batch launches for the high-resolution layers, batch chunks on the internal streams only
                              // for the run of low-resolution (<= 1/16) layers, see plan_segments()
   int small_lo = 0, small_hi = 0;   // that run: layers [small_lo, small_hi)
@@ -634,7 +634,11 @@ yl_status do_post(yl_ctx* c, const float* const* levels_all, int b0, int B, cons
   np.tmp_dets = c->ws_tmp_dets + o * 6; np.tmp_idx = c->ws_tmp_idx + o;
   // several workgroups per image (classes split mod G) unless the fallback's global top-k needs the whole kept
   // set in one workgroup, or survivors could exceed the LDS key capacity
-  np.G = (c->opt_nms_groups > 1 && np.topk == 0 && c->C > 1 && c->C <= 256 && c->N <= YL_LDS_KEYS_MAX) ? c->opt_nms_groups : 1;
+  // auto: the class-group split (histogram + assignment prologue, merge kernel) pays when an image has thousands of
+  // survivors -- evaluation thresholds (conf 0.001: +2.7 % on a 2000-survivor workload) -- and costs 0.8 % at the
+  // few hundred survivors of a detector operating point (conf 0.4, calibrated benchmark workload)
+  const int groups = c->opt_nms_groups > 0 ? c->opt_nms_groups : (cfg->conf_thr < 0.05f ? YL_NMS_GROUPS : 1);
+  np.G = (groups > 1 && np.topk == 0 && c->C > 1 && c->C <= 256 && c->N <= YL_LDS_KEYS_MAX) ? groups : 1;
   np.kept_list = c->ws_kept_list + o * YL_NMS_GROUPS;
   np.done = c->ws_done + (size_t)b0 * 64;                              // 256 bytes per image
   HIPCHK(c, yl_launch_nms(np, B, st));
@@ -1061,7 +1065,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
-  if (!strcmp(name, "nms_groups")) { c->opt_nms_groups = value < 1 ? 1 : (value > YL_NMS_GROUPS ? YL_NMS_GROUPS : value); drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "nms_groups")) { c->opt_nms_groups = value < 0 ? 0 : (value > YL_NMS_GROUPS ? YL_NMS_GROUPS : value); drop_graph(c); return YL_OK; }
   if (!strcmp(name, "time_split")) {
     c->opt_time_split = value ? 1 : 0;
     for (int i = 0; i < 3 && value; ++i)
