@@ -37,6 +37,7 @@
 #define yl_uib_lds_bytes yl_uib_lds_bytes_bf16
 #define yl_launch_conv_dwc yl_launch_conv_dwc_bf16
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
+#define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #endif
 #include <stdio.h>
@@ -148,76 +149,6 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
     const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
     s = yl_actc(s, p.dw_act, dlo, dhi);
     return yl_sel4(cin_ok, s);
-  }
-}
-
-// Head-output layers under yl_predict: decode fused into the epilogue (replaces yl_decode_score_kernel and the
-// 2.9 MB/image write + read of the raw level tensor).  Candidate = pixel of the tile; its row of 5+C logits
-// is spread over the wave: channel c = (nt0+nt)*16 + 4*kq + r sits in element r of acc[mt][nt] of lane
-// (kq, pl).  tx,ty,tw,th = lane kq 0 / n-tile 0, obj = element 0 of lane kq 1; the class arg-max is a
-// per-lane scan + a butterfly over the four kq lanes of the pixel (xor 16, 32).  Class choice follows the
-// reference exactly: (conf, idx) = sigmoid(cls).max(-1), FIRST maximum -- i.e. the smallest class whose
-// sigmoid equals sigmoid(max logit) (see yl_decode_score_kernel for the band argument).  Same arithmetic
-// (yl_decode.h, contraction off) on the same fp32 logits as the unfused path -> bit-identical NMS inputs.
-template <int NT, int MT>
-__device__ __forceinline__ void yl_epi_decode(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT], int nt0,
-                                              int kq, int lane) {
-#pragma clang fp contract(off)
-  const int C = p.dec_C;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    f32x4 v[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt] + yl_ld4(p.bias + (nt0 + nt) * 16 + 4 * kq);
-    // ---- objectness: channel 4 = element 0 of the kq-1 lane
-    const float tobj = __shfl(v[0].x, (lane & 15) + 16, 64);
-    // ---- class logits: local first-maximum, then across the 4 lanes of the pixel
-    float lmax = -INFINITY;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ch = (nt0 + nt) * 16 + 4 * kq + r;
-        if (ch >= 5 && ch < 5 + C) lmax = fmaxf(lmax, v[nt][r]);
-      }
-    lmax = fmaxf(lmax, __shfl_xor(lmax, 16, 64));
-    lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
-    float score;
-    int ci = 0;
-    const float obj = yl_sigmoid(tobj);
-    if (C > 1) {
-      const float best = yl_sigmoid(lmax);
-      const float band = lmax - 1e-3f * (1.0f + fabsf(lmax));
-      const bool wide = best < 1.2e-38f;
-      int first = 0x7fffffff;                               // smallest class whose sigmoid equals `best`
-#pragma unroll
-      for (int nt = NT - 1; nt >= 0; --nt)
-#pragma unroll
-        for (int r = 3; r >= 0; --r) {
-          const int ch = (nt0 + nt) * 16 + 4 * kq + r;
-          const float l = v[nt][r];
-          if (ch >= 5 && ch < 5 + C && (wide || l >= band || l > 10.0f) && yl_sigmoid(l) == best) first = ch - 5;
-        }
-      first = min(first, __shfl_xor(first, 16, 64));
-      first = min(first, __shfl_xor(first, 32, 64));
-      ci = first;
-      score = obj * best;
-    } else if (C == 1 && p.dec_mode == YL_POST_FALLBACK) {
-      const float l0 = __shfl(v[0].y, (lane & 15) + 16, 64);  // channel 5 = element 1 of the kq-1 lane
-      score = obj * yl_sigmoid(l0);
-    } else {
-      score = obj;
-    }
-    if (kq == 0 && px[mt].valid) {
-      float cx, cy, pw, ph;
-      yl_decode_cell((float)px[mt].ox, (float)px[mt].oy, p.dec_stride, v[0].x, v[0].y, v[0].z, v[0].w, p.dec_center,
-                     p.dec_wh, cx, cy, pw, ph);
-      if (p.dec_mode == YL_POST_FALLBACK && !(pw >= 2.0f && ph >= 2.0f)) score = -INFINITY;
-      const size_t o = (size_t)px[mt].b * p.dec_N + p.dec_off + px[mt].oy * p.OW + px[mt].ox;
-      p.dec_boxes[o] = yl_box_corners(cx, cy, pw, ph, p.dec_hi);
-      p.dec_scores[o] = score;
-      p.dec_cls[o] = ci;
-    }
   }
 }
 
@@ -1201,8 +1132,9 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   // weight prologue, no barrier.  Measured against the persistent LDS kernel (edge_n, B = 64, eager, us): 48->96
   // @40x40 31 -> 26, 64->256 @20x20 28 -> 23, 64->480 @20x20 45 -> 35, 48->32 @80x80 40 -> 34, lateral3 32->96
   // @80x80 99 -> 81.  Same k order and epilogues: bit-identical results.  tile_hint 6 switches it off.
-  if (n == 1 && p.dw_k == 0 && p.k == 1 && p.stride == 1 && tile_hint != 6) {
-    const hipError_t ep = yl_launch_conv_pwt(p, st);
+  if (p.dw_k == 0 && p.k == 1 && p.stride == 1 && tile_hint != 6) {
+    // (also the head-output layers of all levels in one launch when their decode runs in the epilogue)
+    const hipError_t ep = yl_launch_conv_pwt_multi(ps, n, st);
     if (ep != hipErrorNotSupported) return ep;
   }
   // dense k x k with a weight image beyond LDS: double-buffered weight stream (yl_convc.hip); tile_hint 6 = off

@@ -30,6 +30,7 @@
 #define yl_convc_init yl_convc_init_bf16
 #define yl_conv_pwt_kernel yl_conv_pwt_kernel_bf16
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
+#define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
 #define yl_conv_kxk_kernel yl_conv_kxk_kernel_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #endif
@@ -360,12 +361,14 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwc_kernel(YlConvMulti mp) {
 // weights), ~70 VGPRs, so 6-8 waves per SIMD cover each other's load latency and MFMA dependency chains, and the
 // launch has thousands of waves instead of a few hundred.  Same k order, same epilogues as yl_conv_mfma_kernel:
 // bit-identical results.
-template <int NTW, int MT>
-__global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvP p, int nchunk) {
+template <int NTW, int MT, bool DEC>
+__global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nchunk) {
+  YL_SELECT_PROBLEM_C(mp)                                   // level-batched launches: block ranges per problem
+  (void)gx;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
-  const int item = blockIdx.x * 4 + wave;
+  const int item = bx * 4 + wave;
   const int mg = item / nchunk, nc = item - mg * nchunk;
   const int nt0 = nc * NTW;
   const int Cin = p.Cin, N = p.N, NTtot = p.NTtot, KB = p.KB, M = p.M;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvP p, int nchunk)
     if (!px[mt].valid) lin = (size_t)M - 1;
     px[mt].lin = lin;
     px[mt].b = 0; px[mt].oy = 0; px[mt].ox = 0;
-    if (p.up) {                                             // only the nearest-upsample-add epilogue needs coordinates
+    if (DEC || p.up) {                                      // only the upsample-add / decode epilogues need coordinates
       const int ohw = p.OH * p.OW;
       const int b = (int)(lin / ohw);
       const int rem = (int)(lin - (size_t)b * ohw);
@@ -463,33 +466,70 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvP p, int nchunk)
     for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(acc[mt][nt].x), "v"(acc[mt][nt].y), "v"(acc[mt][nt].z), "v"(acc[mt][nt].w));
   return;
 #endif
+  if (DEC) { yl_epi_decode<NTW, MT>(p, acc, px, nt0, kq, lane); return; }   // head output under yl_predict (one wave = whole rows)
   if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NTW, MT>(p, acc, px, nt0, kq);
   else yl_epi_fast<NTW, MT>(p, acc, px, nt0, kq, lo, hi, true);
 }
 
-template <int NTW, int MT>
-static hipError_t pwt_go(const YlConvP& p, int nchunk, hipStream_t st) {
-  const long groups = ((long)p.M + MT * 16 - 1) / (MT * 16);
-  const long items = groups * nchunk;
-  hipLaunchKernelGGL((yl_conv_pwt_kernel<NTW, MT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p, nchunk);
+template <int NTW, int MT, bool DEC = false>
+static hipError_t pwt_go(YlConvMulti& m, int nchunk, hipStream_t st) {
+  int at = 0;
+  for (int k = 0; k < m.n; ++k) {
+    const long groups = ((long)m.p[k].M + MT * 16 - 1) / (MT * 16);
+    const long items = groups * nchunk;
+    m.p[k].blk0 = at;
+    m.p[k].nblk = (int)((items + 3) / 4);
+    at += m.p[k].nblk;
+  }
+  if (m.n == 1) m.p[0].nblk = 0;                                 // single problem: the whole grid (YL_SELECT_PROBLEM_C)
+  hipLaunchKernelGGL((yl_conv_pwt_kernel<NTW, MT, DEC>), dim3((unsigned)at), dim3(256), 0, st, m, nchunk);
   return hipGetLastError();
 }
 
-// plain 1x1 stride-1 conv, N % 4 == 0, no depthwise prologue, not a head layer.  hipErrorNotSupported otherwise.
-hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st) {
-  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.in_shift) return hipErrorNotSupported;
+// n <= 4 plain 1x1 stride-1 convs of identical configuration (one launch).  Either N % 4 == 0 (float4 epilogues),
+// or head-output layers whose decode runs in the epilogue and whose raw rows are not wanted (yl_predict, no mask
+// coefficients): then one wave holds whole rows (N <= 96).  hipErrorNotSupported otherwise.
+hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st) {
+  if (n < 1 || n > 4) return hipErrorNotSupported;
+  YlConvMulti m = {};
+  m.n = n;
+  long Mtot = 0;
+  for (int k = 0; k < n; ++k) {
+    const YlConvP& p = ps[k];
+    if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift) return hipErrorNotSupported;
+    const bool dec = p.dec_boxes && !p.dec_raw;
+    if ((p.N & 3) && !dec) return hipErrorNotSupported;
+    if (p.dec_boxes && !dec) return hipErrorNotSupported;
+    if (dec && p.NTtot > 6) return hipErrorNotSupported;
+    if (p.NTtot != ps[0].NTtot || p.KB != ps[0].KB || (p.dec_boxes != nullptr) != (ps[0].dec_boxes != nullptr)) return hipErrorNotSupported;
+    m.p[k] = p;
+    Mtot += p.M;
+  }
+  const YlConvP& p = ps[0];
   const int NT = p.NTtot;
-  // n-tiles per wave: as many as 4 (the activations are fetched once per wave), chunks of equal size
-  int ntw = NT <= 4 ? NT : (NT % 4 == 0 ? 4 : (NT % 3 == 0 ? 3 : 4));
-  const int nchunk = (NT + ntw - 1) / ntw;
-  const bool two = p.M >= 65536;                                // two m-tiles per wave halve the weight traffic
+  const bool dec = p.dec_boxes != nullptr;
+  // n-tiles per wave: as many as 4 (the activations are fetched once per wave), chunks of equal size; decode: the row
+  int ntw = dec ? (NT <= 4 ? NT : 6) : (NT <= 4 ? NT : (NT % 4 == 0 ? 4 : (NT % 3 == 0 ? 3 : 4)));
+  const int nchunk = dec ? 1 : (NT + ntw - 1) / ntw;
+  const bool two = Mtot >= 65536;                               // two m-tiles per wave halve the weight traffic
+  if (dec) {
+    switch (ntw) {
+      case 1: return pwt_go<1, 1, true>(m, nchunk, st);
+      case 2: return pwt_go<2, 1, true>(m, nchunk, st);
+      case 3: return pwt_go<3, 1, true>(m, nchunk, st);
+      case 4: return pwt_go<4, 1, true>(m, nchunk, st);
+      default: return two ? pwt_go<6, 2, true>(m, nchunk, st) : pwt_go<6, 1, true>(m, nchunk, st);
+    }
+  }
   switch (ntw) {
-    case 1: return two ? pwt_go<1, 2>(p, nchunk, st) : pwt_go<1, 1>(p, nchunk, st);
-    case 2: return two ? pwt_go<2, 2>(p, nchunk, st) : pwt_go<2, 1>(p, nchunk, st);
-    case 3: return two ? pwt_go<3, 2>(p, nchunk, st) : pwt_go<3, 1>(p, nchunk, st);
-    default: return two ? pwt_go<4, 2>(p, nchunk, st) : pwt_go<4, 1>(p, nchunk, st);
+    case 1: return two ? pwt_go<1, 2>(m, nchunk, st) : pwt_go<1, 1>(m, nchunk, st);
+    case 2: return two ? pwt_go<2, 2>(m, nchunk, st) : pwt_go<2, 1>(m, nchunk, st);
+    case 3: return two ? pwt_go<3, 2>(m, nchunk, st) : pwt_go<3, 1>(m, nchunk, st);
+    default: return two ? pwt_go<4, 2>(m, nchunk, st) : pwt_go<4, 1>(m, nchunk, st);
   }
 }
+
+hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st) { return yl_launch_conv_pwt_multi(&p, 1, st); }
 
 // ------------------------------------------------------------------------------------------------
 // Dense k x k convolution whose weights do not fit LDS (yololite_m's FPN: 3x3, 328 -> 328 channels = 3.9 MB packed,

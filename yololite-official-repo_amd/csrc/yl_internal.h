@@ -144,6 +144,8 @@ hipError_t yl_launch_conv_dwc_bf16(YlConvMulti& m, hipStream_t st);
 // wave-autonomous 1x1 conv for small pixel counts (yl_convc.hip); hipErrorNotSupported = not a plain 1x1 layer
 hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_pwt_bf16(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st);
+hipError_t yl_launch_conv_pwt_multi_bf16(const YlConvP* ps, int n, hipStream_t st);
 // dense k x k conv with a double-buffered weight stream (yl_convc.hip); hipErrorNotSupported = other kernel runs it
 hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_kxk_bf16(const YlConvP& p, hipStream_t st);
