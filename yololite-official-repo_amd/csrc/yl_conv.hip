@@ -39,6 +39,7 @@
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
 #define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
+#define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
 #endif
 #include <stdio.h>
 #include <stdlib.h>
@@ -1148,6 +1149,11 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   for (int k = 0; k < n; ++k)
     halo = halo && (m.p[k].OH & 3) == 0 && (m.p[k].OW & 3) == 0 &&
            (size_t)m.p[k].B * m.p[k].H * m.p[k].W * m.p[k].Cin * 4 < ((size_t)1 << 31);
+  if (halo && tile_hint != 6 && tile_hint != 7) {
+    // wave-autonomous kernel (yl_convc.hip): one tile per wave, A fragments from L1/L2, ~15 KB of LDS per workgroup
+    const hipError_t et = yl_launch_conv_dwt(m, st);
+    if (et != hipErrorNotSupported) return et;
+  }
   if (halo && tile_hint == 7) {
     // producer / consumer kernel (yl_convc.hip: 4 depthwise waves + 4 GEMM waves per workgroup, 1x1 weights resident
     // in registers).  OPT-IN (tile_hint 7): faster in isolation on the K >= 192 layers (28 vs 38 us, 44 vs 50 us at

@@ -31,6 +31,8 @@
 #define yl_conv_pwt_kernel yl_conv_pwt_kernel_bf16
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
 #define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
+#define yl_conv_dwt_kernel yl_conv_dwt_kernel_bf16
+#define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
 #define yl_conv_kxk_kernel yl_conv_kxk_kernel_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #endif
@@ -530,6 +532,222 @@ hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st) {
 }
 
 hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st) { return yl_launch_conv_pwt_multi(&p, 1, st); }
+
+// ------------------------------------------------------------------------------------------------
+// Wave-autonomous depthwise -> 1x1 convolution: the depthwise counterpart of yl_conv_pwt_kernel.  Same layer and the
+// same per-wave algorithm as yl_conv_dwh_kernel (4x4-pixel m-tiles, per 16-channel block the halo patch goes through
+// the wave's private LDS region, B = act(bias + sum_taps w*x), NT x 4 MFMAs), but
+//   * NOT persistent and no weight image in LDS: one tile per wave, the 1x1 A fragments come straight from L1/L2
+//     (requested before the taps of the block they belong to), so a workgroup holds ~15 KB of LDS instead of 50-115 KB
+//     and 5 waves per SIMD are resident instead of 3 (or 1 at K = 256) -- the phases of one wave (halo fetch, taps,
+//     MFMAs, stores) were measured to be additive, more waves are what overlaps them;
+//   * MT = 2: a wave may own a 4x8-pixel tile (two m-tiles sharing one 6x10 / 8x12 halo patch and every A fragment).
+// One workgroup barrier in the whole kernel (depthwise taps -> LDS).  Same k order and epilogues: bit-identical.
+#ifndef YL_DWT_WAVES
+#define YL_DWT_WAVES 1
+#endif
+template <int NT, int DK, int DS, int MT>
+__global__ __launch_bounds__(256, YL_DWT_WAVES) void yl_conv_dwt_kernel(YlConvMulti mp) {
+  YL_SELECT_PROBLEM_C(mp)
+  (void)gx;
+  constexpr int HPY = 3 * DS + DK, HPX = (4 * MT - 1) * DS + DK;     // halo patch rows / columns
+  constexpr int PITCHF = ((HPX * 16 + 7) / 64) * 64 + 56;            // row pitch in floats (see yl_conv_dwh_kernel)
+  constexpr int HF4 = HPY * HPX * 4;
+  constexpr int NSLOT = (HF4 + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N, NTtot = p.NTtot, KB = p.KB;
+  const float* const xin = p.x;
+  const long zdelta = p.zeros - p.x;
+  float* dwl = yl_clds;                                              // [DK*DK][Cin] taps, [Cin] bias
+  float* halo = dwl + (((size_t)(DK * DK + 1) * Cin + 3) & ~(size_t)3) + wave * (HPY * PITCHF);
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
+  {
+    const int nw = DK * DK * Cin;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cin, tid, 256);
+    else for (int i = tid; i < Cin; i += 256) dwl[nw + i] = 0.0f;
+  }
+  const int twn = OW / (4 * MT), thn = OH >> 2;
+  const int tiles_img = twn * thn;
+  const long ntiles = (long)p.B * tiles_img;
+  const long tile = (long)bx * 4 + wave;
+  const bool active = tile < ntiles;
+  const int b = active ? (int)(tile / tiles_img) : 0;
+  const int trem = active ? (int)(tile - (long)b * tiles_img) : 0;
+  const int tyi = trem / twn, txi = trem - tyi * twn;
+  // staging slots of this lane: halo pixel / channel quad -> LDS offset and (block 0) global offset
+  int s_lo[NSLOT];
+  long goff[NSLOT];
+  bool s_ok[NSLOT];
+  {
+    const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * MT * txi * DS - p.dw_pad_l;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int e = j * 64 + lane;
+      s_ok[j] = e < HF4;
+      const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
+      const int hr = hp / HPX, hc = hp - hr * HPX;
+      s_lo[j] = hr * PITCHF + hc * 16 + quad * 4;
+      const int iy = iy0 + hr, ix = ix0 + hc;
+      const bool in = s_ok[j] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      goff[j] = in ? (((long)b * H + iy) * W + ix) * Cin + quad * 4 : -1;
+    }
+  }
+  auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
+    const bool cok = kb * 16 + (lane & 3) * 4 < Cin;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) r[j] = yl_ld4(xin + ((cok && goff[j] >= 0) ? goff[j] + kb * 16 : zdelta));
+  };
+  auto stage_store = [&](const f32x4 (&r)[NSLOT]) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+      if (s_ok[j]) *reinterpret_cast<f32x4*>(halo + s_lo[j]) = r[j];
+  };
+  f32x4 stg[NSLOT];
+  if (active) stage_load(0, stg);
+  __syncthreads();                                                   // taps are in LDS (the only workgroup barrier)
+  if (!active) return;
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const int dw_act = p.dw_act;
+  YlPix px[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    px[mt].b = b;
+    px[mt].oy = 4 * tyi + (pl >> 2);
+    px[mt].ox = 4 * MT * txi + 4 * mt + (pl & 3);
+    px[mt].valid = true;
+    px[mt].lin = ((size_t)b * OH + px[mt].oy) * OW + px[mt].ox;
+  }
+  const bool pre_add = p.res != nullptr && p.up == nullptr && p.act == YL_ACT_NONE;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + 4 * kq;
+      acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (pre_add && n < N) acc[mt][nt] = yl_ld4(p.res + px[mt].lin * N + n);
+    }
+  const int rbase = ((pl >> 2) * DS) * PITCHF + ((pl & 3) * DS) * 16 + 4 * kq;
+  stage_store(stg);
+  for (int kb = 0; kb < KB; ++kb) {
+    const bool more = kb + 1 < KB;
+    if (more) stage_load(kb + 1, stg);
+    f32x4 wq[NT];                                                    // this block's A fragments: in flight under the taps
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wq[nt] = wg[((size_t)kb * NTtot + (nt < NTtot ? nt : NTtot - 1)) * 64 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // halo writes (all lanes) -> tap reads
+    const int c = kb * 16 + 4 * kq;
+    const int cs = c < Cin ? c : Cin - 4;
+    const float* tapw = dwl + cs;
+    f32x4 xq[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_ld4(tapw + DK * DK * Cin);
+    if (DK == 3) {
+#pragma unroll
+      for (int dy = 0; dy < DK; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < DK; ++dx) {
+          const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * Cin);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + (dx + 4 * mt * DS) * 16);
+            xq[mt].x = fmaf(v.x, w.x, xq[mt].x); xq[mt].y = fmaf(v.y, w.y, xq[mt].y);
+            xq[mt].z = fmaf(v.z, w.z, xq[mt].z); xq[mt].w = fmaf(v.w, w.w, xq[mt].w);
+          }
+        }
+    } else {
+#pragma unroll 1
+      for (int dy = 0; dy < DK; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < DK; ++dx) {
+          const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * Cin);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + (dx + 4 * mt * DS) * 16);
+            xq[mt].x = fmaf(v.x, w.x, xq[mt].x); xq[mt].y = fmaf(v.y, w.y, xq[mt].y);
+            xq[mt].z = fmaf(v.z, w.z, xq[mt].z); xq[mt].w = fmaf(v.w, w.w, xq[mt].w);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_actc(xq[mt], dw_act, dlo, dhi);
+    // channel tail (c >= Cin): the packed 1x1 weights of those k slots are zero, no select needed
+    yl_mma_step<NT, MT>(wq, xq, acc);
+    if (more) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // this block's tap reads are complete
+      stage_store(stg);
+    }
+  }
+  if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
+  else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
+}
+
+template <int NT, int DK, int DS, int MT>
+static hipError_t dwt_go(YlConvMulti& m, hipStream_t st, bool attr_only) {
+  if (attr_only) return hipSuccess;
+  constexpr int HPY = 3 * DS + DK, HPX = (4 * MT - 1) * DS + DK;
+  constexpr int PITCHF = ((HPX * 16 + 7) / 64) * 64 + 56;
+  const YlConvP& p = m.p[0];
+  const size_t lds = ((((size_t)(DK * DK + 1) * p.Cin + 3) & ~(size_t)3) + (size_t)4 * HPY * PITCHF) * 4;
+  if (lds > 64 * 1024) return hipErrorNotSupported;
+  int at = 0;
+  for (int k = 0; k < m.n; ++k) {
+    const long tiles = (long)m.p[k].B * (m.p[k].OH >> 2) * (m.p[k].OW / (4 * MT));
+    m.p[k].blk0 = at;
+    m.p[k].nblk = (int)((tiles + 3) / 4);
+    at += m.p[k].nblk;
+  }
+  if (m.n == 1) m.p[0].nblk = 0;
+  hipLaunchKernelGGL((yl_conv_dwt_kernel<NT, DK, DS, MT>), dim3((unsigned)at), dim3(256), lds, st, m);
+  return hipGetLastError();
+}
+
+template <int NT, int MT>
+static hipError_t dwt_dk(YlConvMulti& m, hipStream_t st) {
+  const YlConvP& p = m.p[0];
+  if (p.dw_k == 3 && p.dw_stride == 1) return dwt_go<NT, 3, 1, MT>(m, st, false);
+  if (p.dw_k == 3 && p.dw_stride == 2) return dwt_go<NT, 3, 2, MT>(m, st, false);
+  if (p.dw_k == 5 && p.dw_stride == 1) return dwt_go<NT, 5, 1, MT>(m, st, false);
+  if (p.dw_k == 5 && p.dw_stride == 2) return dwt_go<NT, 5, 2, MT>(m, st, false);
+  return hipErrorNotSupported;
+}
+
+// depthwise (3x3 / 5x5, stride 1 / 2) -> 1x1 with N % 4 == 0, N <= 96 (all n-tiles in one wave), OH % 4 == 0,
+// OW % 4 == 0.  hipErrorNotSupported otherwise (yl_conv_dwh_kernel then runs the layer).
+hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st) {
+  const YlConvP& p = m.p[0];
+  if (p.dw_k == 0 || (p.N & 3) || p.NTtot > 6 || p.dec_boxes || p.C1 > 0) return hipErrorNotSupported;
+  // measured per layer against yl_conv_dwh_kernel (edge_n, B = 64): the wave-autonomous form wins where the LDS
+  // weight image would leave one workgroup per CU (K >= 192: 50 -> 36 us) and for narrow outputs (N <= 48: 33.5 ->
+  // 32 us, 64 -> 58 us at dw5 stride 2); at K = N = 96 both hold 3 waves per SIMD and the LDS-resident weights win
+  // by 5 %.  YL_DWT_MT: 0 = never, 1 / 2 = every supported layer with that m-tile count (ablation).
+  static const int mtsel = getenv("YL_DWT_MT") ? atoi(getenv("YL_DWT_MT")) : -1;
+  if (mtsel == 0) return hipErrorNotSupported;
+  if (mtsel < 0 && !(p.KB >= 12 || p.NTtot <= 3)) return hipErrorNotSupported;
+  bool two = mtsel == 2 && p.dw_stride == 1;
+  for (int k = 0; k < m.n; ++k) {
+    if ((m.p[k].OH & 3) || (m.p[k].OW & 3)) return hipErrorNotSupported;
+    if (m.p[k].OW & 7) two = false;
+  }
+  const int nts[5] = {1, 2, 3, 4, 6};
+  int NT = 6;
+  for (int i = 0; i < 5; ++i) if (nts[i] >= p.NTtot) { NT = nts[i]; break; }
+  switch (NT) {
+    case 1: return two ? dwt_dk<1, 2>(m, st) : dwt_dk<1, 1>(m, st);
+    case 2: return two ? dwt_dk<2, 2>(m, st) : dwt_dk<2, 1>(m, st);
+    case 3: return two ? dwt_dk<3, 2>(m, st) : dwt_dk<3, 1>(m, st);
+    case 4: return two ? dwt_dk<4, 2>(m, st) : dwt_dk<4, 1>(m, st);
+    default: return two ? dwt_dk<6, 2>(m, st) : dwt_dk<6, 1>(m, st);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Dense k x k convolution whose weights do not fit LDS (yololite_m's FPN: 3x3, 328 -> 328 channels = 3.9 MB packed,

@@ -149,6 +149,9 @@ hipError_t yl_launch_conv_pwt_multi_bf16(const YlConvP* ps, int n, hipStream_t s
 // dense k x k conv with a double-buffered weight stream (yl_convc.hip); hipErrorNotSupported = other kernel runs it
 hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_kxk_bf16(const YlConvP& p, hipStream_t st);
+// wave-autonomous depthwise -> 1x1 kernel (yl_convc.hip); hipErrorNotSupported = shape outside its limits
+hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st);
+hipError_t yl_launch_conv_dwt_bf16(YlConvMulti& m, hipStream_t st);
 hipError_t yl_convc_init();
 hipError_t yl_convc_init_bf16();
 // bf16-MFMA builds of yl_conv.hip / yl_stemblock.hip (compiled a second time with -DYL_BF16=1, see yl_dev.h)
