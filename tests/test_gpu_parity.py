@@ -189,8 +189,10 @@ def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
 @pytest.mark.parametrize("name,B,S", [("edge_n", 3, 320), ("edge_n", 2, 640), ("edge_m", 2, 320), ("yololite_m", 1, 256)])
 def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
     """Alternative kernels of yl_convc.hip sum every output's k blocks in the same order as the kernels they replace
-    -> identical bits.  "tile_m" 6: wave-autonomous 1x1 kernel (default for plain 1x1 layers) OFF; 7: producer /
-    consumer depthwise -> 1x1 kernel (opt-in) ON, with YL_DWC_ALL=1 on every layer shape it supports."""
+    -> identical bits.  "tile_m" 6: wave-autonomous 1x1 / depthwise kernels and the streamed dense 3x3 kernel OFF; 7:
+    producer / consumer depthwise -> 1x1 kernel (opt-in) ON, with YL_DWC_ALL=1 on every layer shape it supports.
+    Exception: yl_conv_kxk_kernel (yololite_m's dense 3x3) walks K channel-block-major instead of tap-major (cache
+    locality), a different fp32 summation order of the same 2952 products: compared at rounding-noise tolerance."""
     os.environ["YL_DWC_ALL"] = "1"
     meta = zoo_meta(name, 80, S)
     sd = synth_state_dict(meta, seed=4)
@@ -203,7 +205,10 @@ def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
         b = m(x)
         ctx.set_option("tile_m", 0)
         for u, v in zip(a, b):
-            assert torch.equal(u, v), hint
+            if name == "yololite_m" and hint == 6:
+                assert torch.allclose(u, v, atol=2e-5, rtol=1e-5), (hint, float((u - v).abs().max()))
+            else:
+                assert torch.equal(u, v), hint
 
 
 def test_forward_batch_invariance_and_determinism_full_size():

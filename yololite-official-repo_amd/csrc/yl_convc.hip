@@ -759,51 +759,62 @@ hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st) {
 // buffers, the asynchronous global->LDS copies of chunk c+1 issued before the MFMAs of chunk c (ONE barrier per
 // chunk, which is also where the copies are waited for), the chunk pipeline running on across tile boundaries.
 // Same transposed GEMM, k order and epilogues as yl_conv_mfma_kernel: bit-identical results.
-template <int NT, int MT>
-__global__ __launch_bounds__(256, 3) void yl_conv_kxk_kernel(YlConvP p, int CH) {
+template <int NT, int MT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_kxk_kernel(YlConvP p) {
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
-  const int nt0 = blockIdx.y * NT;
-  const int ntc = (p.NTtot - nt0) < NT ? (p.NTtot - nt0) : NT;
   const int TK = p.TK, KB = p.KB, K = p.k, NTtot = p.NTtot;
   const int Cin = p.Cin, H = p.H, W = p.W, stride = p.stride, pad_t = p.pad_t, pad_l = p.pad_l, sh = p.in_shift;
   const int ohw = p.OH * p.OW, OW = p.OW, M = p.M;
   const float* const xin = p.x;
   const long zdelta = p.zeros - p.x;
-  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][CH][NT][64] float4
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][3][NT][64] float4
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
-  const int NC = (TK + CH - 1) / CH;                         // chunks per tile
-  const int bx = blockIdx.x, gx = gridDim.x;
-  const int nmine = bx < p.ntiles ? (p.ntiles - 1 - bx) / gx + 1 : 0;
+  const int NC = 3 * KB;                                     // chunks (3 taps each) per (m-tile, n-group) item
+  const int G = NTtot / NT;                                  // n-groups of NT n-tiles (the launcher guarantees NTtot % NT == 0)
+  // Work order.  A workgroup runs ALL its m-tiles for n-group 0, then for group 1, ...: at any time the workgroups
+  // of an XCD stream the same 1/G of the weights (1.3 MB of yololite_m's 3.9 MB), which stays in that XCD's 4 MB L2;
+  // with the groups spread over gridDim.y every XCD cycled through the whole image and FETCH_SIZE showed each pass
+  // coming from HBM/MALL again (20x the algorithmic bytes).  The m-tiles of an XCD (workgroup b -> XCD b % 8) are
+  // one contiguous band of the output, so the 3x3 halo rows of neighbouring tiles hit the same L2 as well.
+  const int bx = blockIdx.x, gx = gridDim.x;                 // gx % 8 == 0
+  const int per = gx >> 3, slot = bx >> 3;
+  const int tpx = (p.ntiles + 7) >> 3;
+  const int band0 = (bx & 7) * tpx;
+  const int band1 = (band0 + tpx) < p.ntiles ? (band0 + tpx) : p.ntiles;
+  const int bt = band1 > band0 ? band1 - band0 : 0;          // (n-group, m-tile) items of the band, group-major;
+  const int nitems = bt * G;                                 // workgroup `slot` of the XCD takes items slot, slot+per, ...
+  const int nmine = slot < nitems ? (nitems - 1 - slot) / per + 1 : 0;
   const long total_chunks = (long)nmine * NC;
 
-  // asynchronous copy of chunk c (k-steps [c*CH, min(TK, c*CH+CH))) into buffer `buf`: (k-step, n-tile) pieces of
-  // 1 KiB dealt round-robin to the four waves; padding n-tiles of a partial last n-chunk are zero-filled
-  auto load_chunk = [&](int c, int buf) {
-    const int c0 = c * CH, c1 = (c0 + CH) < TK ? (c0 + CH) : TK;
-    const int items = (c1 - c0) * NT;
-    for (int i = wave; i < items; i += 4) {
-      const int t = c0 + i / NT, nt = i % NT;
-      f32x4* dst = wl + ((size_t)buf * CH * NT + (size_t)(t - c0) * NT + nt) * 64;
-      if (nt < ntc) yl_glds16(wg + ((size_t)t * NTtot + nt0 + nt) * 64 + lane, dst);
-      else dst[lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // asynchronous copy of one chunk = the three taps (ky = cc, kx = 0..2) of channel block kb, n-group g, into buffer
+  // `buf`: (tap, n-tile) pieces of 1 KiB dealt round-robin to the waves.  The packed image is tap-major (k-step
+  // tap * KB + kb, shared with yl_conv_mfma_kernel); this kernel walks it channel-block-major, see below.
+  auto load_chunk = [&](int g, int kb, int cc, int buf) {
+    for (int i = wave; i < 3 * NT; i += NW) {
+      const int j = i / NT, nt = i - j * NT;
+      f32x4* dst = wl + ((size_t)buf * 3 * NT + i) * 64;
+      yl_glds16(wg + ((size_t)((cc * 3 + j) * KB + kb) * NTtot + g * NT + nt) * 64 + lane, dst);
     }
   };
-  if (total_chunks > 0) load_chunk(0, 0);
+  if (total_chunks > 0) load_chunk(slot / bt, 0, 0, 0);
   long gchunk = 0;                                            // chunks consumed so far (buffer = gchunk & 1)
   __syncthreads();
   const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE;
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
 
-  for (int ti = 0; ti < nmine; ++ti) {
-    const int tile = bx + ti * gx;
+  for (int wi = 0; wi < nmine; ++wi) {
+    const int item = slot + wi * per;
+    const int g = item / bt;
+    const int nt0 = g * NT;
+    const int tile = band0 + item - g * bt;
     YlPix px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      size_t lin = ((size_t)tile * 4 + wave) * (MT * 16) + mt * 16 + pl;
+      size_t lin = ((size_t)tile * NW + wave) * (MT * 16) + mt * 16 + pl;
       px[mt].valid = lin < (size_t)M;
       if (!px[mt].valid) lin = (size_t)M - 1;
       px[mt].lin = lin;
@@ -837,97 +848,104 @@ __global__ __launch_bounds__(256, 3) void yl_conv_kxk_kernel(YlConvP p, int CH) 
         }
       }
     }
-    // Activation stream of the lane's pixels: per TAP one base pointer (or the zero buffer when the tap falls outside
-    // the image), advanced by 16 channels per k-step -- the per-step address arithmetic is one pointer add and one
-    // select for the channel tail instead of a full (b, y, x, c) recomputation (fp32 MFMA and VALU share the FMA
-    // lanes: every VALU op in this loop is MFMA time).
-    const float* ptr[MT];          // activations of the NEXT k-step to fetch
-    int inc[MT];
-    int ntap = 0, nkb = 0;         // (tap, channel block) of the next fetch
-    auto tap_setup = [&](int tap) {
-      const int ky = tap / K, kx = tap - ky * K;
+    // K order: channel block outer, the nine taps inner.  The taps of one 16-channel block read a 3 x 18 pixel x 64 B
+    // window per wave, which the 9 consecutive k-steps find in L1 / L2; tap-major (the order of yl_conv_mfma_kernel)
+    // puts KB = 21 k-steps of other channels between two touches of a line, more than L1 and the XCD's L2 hold, and
+    // FETCH_SIZE showed every tap of every pixel coming from HBM / MALL again: 7.5 GB per launch for a 269 MB input.
+    // Per lane: nine tap pointers (the zero buffer where a tap falls outside the image, marked in `inb`).
+    const float* tp[MT][9];
+    unsigned inb[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int iy = px[mt].oy * stride - pad_t + ky, ix = px[mt].ox * stride - pad_l + kx;
+    for (int mt = 0; mt < MT; ++mt) {
+      inb[mt] = 0;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int iy = px[mt].oy * stride - pad_t + tap / 3, ix = px[mt].ox * stride - pad_l + tap % 3;
         const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
         const long off = in ? ((((long)px[mt].b * (H >> sh) + (iy >> sh)) * (W >> sh) + (ix >> sh)) * Cin + 4 * kq) : zdelta;
-        ptr[mt] = xin + off;
-        inc[mt] = in ? 16 : 0;
+        tp[mt][tap] = xin + off;
+        inb[mt] |= in ? (1u << tap) : 0u;
       }
-    };
-    auto fetch_next = [&](f32x4 (&dst)[MT]) {
-      const bool tail = nkb * 16 + 4 * kq >= Cin;                 // channel tail of the last block: zeros
+    }
+    auto fetch = [&](f32x4 (&dst)[MT], int kb, int tap) {
+      const bool tail = kb * 16 + 4 * kq >= Cin;                  // channel tail of the last block: zeros
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        dst[mt] = yl_ld4(tail ? xin + zdelta : ptr[mt]);
-        ptr[mt] += inc[mt];
-      }
-      if (++nkb == KB) {
-        nkb = 0;
-        if (++ntap < K * K) tap_setup(ntap);                      // (after the last tap the pointers are not used again)
+        const float* q = tp[mt][tap] + (((inb[mt] >> tap) & 1u) ? kb * 16 : 0);
+        dst[mt] = yl_ld4(tail ? xin + zdelta : q);
       }
     };
-    tap_setup(0);
     f32x4 xq[MT];
-    fetch_next(xq);
-    for (int c = 0; c < NC; ++c, ++gchunk) {
-      const int buf = (int)(gchunk & 1);
-      // next chunk of the stream (this tile's, or the first one of the workgroup's next tile) into the other buffer
-      if (gchunk + 1 < total_chunks) load_chunk(c + 1 < NC ? c + 1 : 0, buf ^ 1);
-      const int c0 = c * CH, c1 = (c0 + CH) < TK ? (c0 + CH) : TK;
-      const f32x4* wb = wl + (size_t)buf * CH * NT * 64 + lane;
-      for (int t = c0; t < c1; ++t) {
-        f32x4 xn[MT];
-        if (t + 1 < TK) fetch_next(xn);
-        else {
+    fetch(xq, 0, 0);
+    for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) xn[mt] = xq[mt];
+      for (int cc = 0; cc < 3; ++cc, ++gchunk) {
+        const int buf = (int)(gchunk & 1);
+        // next chunk of the stream (this item's, or the first one of the workgroup's next item) into the other buffer
+        if (gchunk + 1 < total_chunks) {
+          if (cc < 2) load_chunk(g, kb, cc + 1, buf ^ 1);
+          else if (kb + 1 < KB) load_chunk(g, kb + 1, 0, buf ^ 1);
+          else load_chunk((item + per) / bt, 0, 0, buf ^ 1);
         }
-        f32x4 wq[NT];
+        const f32x4* wb = wl + (size_t)buf * 3 * NT * 64 + lane;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wq[nt] = wb[((size_t)(t - c0) * NT + nt) * 64];
-        yl_mma_step<NT, MT>(wq, xq, acc);
+        for (int j = 0; j < 3; ++j) {
+          const int tap = cc * 3 + j;
+          f32x4 xn[MT];
+          if (tap < 8) fetch(xn, kb, tap + 1);
+          else if (kb + 1 < KB) fetch(xn, kb + 1, 0);
+          else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xq[mt] = xn[mt];
+            for (int mt = 0; mt < MT; ++mt) xn[mt] = xq[mt];
+          }
+          f32x4 wq[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) wq[nt] = wb[(j * NT + nt) * 64];
+          yl_mma_step<NT, MT>(wq, xq, acc);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) xq[mt] = xn[mt];
+        }
+        __syncthreads();           // every wave is done with `buf`; the copies into the other buffer have landed
       }
-      __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
     }
     if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, true);
   }
 }
 
-template <int NT, int MT>
-static hipError_t kxk_go(const YlConvP& p0, int gy, int CH, hipStream_t st, bool attr_only) {
+template <int NT, int MT, int NW>
+static hipError_t kxk_go(const YlConvP& p0, int gy, hipStream_t st, bool attr_only) {
   if (attr_only)
-    return hipFuncSetAttribute((const void*)yl_conv_kxk_kernel<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    return hipFuncSetAttribute((const void*)yl_conv_kxk_kernel<NT, MT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   YlConvP p = p0;
-  p.ntiles = (int)(((long)p.M + 64 * MT - 1) / (64 * MT));
-  const size_t lds = (size_t)2 * CH * NT * 1024;
-  static int res_cache[16] = {0};
-  int& res = res_cache[(CH & 7) * 2 + (MT - 1)];
+  p.ntiles = (int)(((long)p.M + 16 * NW * MT - 1) / (16 * NW * MT));
+  const size_t lds = (size_t)2 * 3 * NT * 1024;
+  static int res = 0;
   if (!res) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)yl_conv_kxk_kernel<NT, MT>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)yl_conv_kxk_kernel<NT, MT, NW>, NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
     if (nb > 4) nb = 4;
     res = nb * YL_NUM_CU;
   }
-  int gx = (res / gy) & ~7;
-  if (gx < 8) gx = 8;
-  if (gx > p.ntiles) gx = p.ntiles;
-  hipLaunchKernelGGL((yl_conv_kxk_kernel<NT, MT>), dim3(gx, gy), dim3(256), lds, st, p, CH);
+  int gx = res & ~7;
+  while (gx > 8 && gx - 8 >= p.ntiles * gy) gx -= 8;       // gy = n-groups: (m-tile, n-group) items
+  hipLaunchKernelGGL((yl_conv_kxk_kernel<NT, MT, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
   return hipGetLastError();
 }
 
 // dense k x k (k > 1) layers with N % 4 == 0 whose weight image exceeds the LDS budget and whose n-tile count is a
 // multiple of 7.  hipErrorNotSupported otherwise (yl_conv_mfma_kernel then runs the layer).
 hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
-  if (p.k < 2 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.NTtot % 7 != 0) return hipErrorNotSupported;
+  if (p.k != 3 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.NTtot % 7 != 0) return hipErrorNotSupported;
   if ((size_t)p.TK * 7 * 1024 <= 96 * 1024) return hipErrorNotSupported;      // small enough to stay resident: other kernel
-  static const int CH = getenv("YL_KXK_CH") ? atoi(getenv("YL_KXK_CH")) : 3;
+  // 8 waves per workgroup share each weight chunk (half the LDS-DMA issue work per MFMA: 107 -> 114 TFLOP/s on
+  // yololite_m's 80x80 level) when there are enough 128-pixel items to keep the tail short; 4 otherwise
+  static const int NWsel = getenv("YL_KXK_NW") ? atoi(getenv("YL_KXK_NW")) : 0;
   static const int MTsel = getenv("YL_KXK_MT") ? atoi(getenv("YL_KXK_MT")) : 1;
   const int gy = p.NTtot / 7;
-  return MTsel == 1 ? kxk_go<7, 1>(p, gy, CH, st, false) : kxk_go<7, 2>(p, gy, CH, st, false);
+  const bool eight = NWsel ? NWsel == 8 : ((long)p.M / 128) * gy >= 2 * 2 * YL_NUM_CU;
+  if (eight) return kxk_go<7, 1, 8>(p, gy, st, false);
+  return MTsel == 1 ? kxk_go<7, 1, 4>(p, gy, st, false) : kxk_go<7, 2, 4>(p, gy, st, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -987,8 +1005,9 @@ int kbmax_of(int ntw) { return ntw == 1 ? 18 : ntw == 2 ? 9 : ntw == 3 ? 6 : 4; 
 hipError_t yl_convc_init() {
   YlConvMulti m = {};
   YlConvP q = {};
-  hipError_t e = kxk_go<7, 1>(q, 1, 3, nullptr, true);
-  if (e == hipSuccess) e = kxk_go<7, 2>(q, 1, 3, nullptr, true);
+  hipError_t e = kxk_go<7, 1, 4>(q, 1, nullptr, true);
+  if (e == hipSuccess) e = kxk_go<7, 2, 4>(q, 1, nullptr, true);
+  if (e == hipSuccess) e = kxk_go<7, 1, 8>(q, 1, nullptr, true);
   if (e != hipSuccess) return e;
   return dwc_any(m, 0, 0, 0, 0, 0, nullptr, true, nullptr);
 }
