@@ -44,6 +44,22 @@
 #include "yl_dev.h"
 #include "yl_epi.h"
 
+// co-resident workgroups of `kernel` on the whole device (occupancy query cached per kernel and LDS size)
+template <typename K>
+static int yl_resident_blocks_n(K kernel, int threads, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, int> cache;
+  const std::pair<const void*, size_t> key((const void*)kernel, lds);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, threads, lds) != hipSuccess || nb < 1) nb = 1;
+  if (nb > 8) nb = 8;
+  cache[key] = nb * YL_NUM_CU;
+  return nb * YL_NUM_CU;
+}
+
 #define YL_DWC_LDS_MAX (150 * 1024)
 
 // profiling aid (variant builds only: tools/build_variant.sh stamp yl_convc.hip -DYL_DWC_STAMP=<Cin>): shader-clock
@@ -534,22 +550,19 @@ hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st) {
 hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st) { return yl_launch_conv_pwt_multi(&p, 1, st); }
 
 // ------------------------------------------------------------------------------------------------
-// Wave-autonomous depthwise -> 1x1 convolution: the depthwise counterpart of yl_conv_pwt_kernel.  Same layer and the
-// same per-wave algorithm as yl_conv_dwh_kernel (4x4-pixel m-tiles, per 16-channel block the halo patch goes through
-// the wave's private LDS region, B = act(bias + sum_taps w*x), NT x 4 MFMAs), but
-//   * NOT persistent and no weight image in LDS: one tile per wave, the 1x1 A fragments come straight from L1/L2
-//     (requested before the taps of the block they belong to), so a workgroup holds ~15 KB of LDS instead of 50-115 KB
-//     and 5 waves per SIMD are resident instead of 3 (or 1 at K = 256) -- the phases of one wave (halo fetch, taps,
-//     MFMAs, stores) were measured to be additive, more waves are what overlaps them;
-//   * MT = 2: a wave may own a 4x8-pixel tile (two m-tiles sharing one 6x10 / 8x12 halo patch and every A fragment).
-// One workgroup barrier in the whole kernel (depthwise taps -> LDS).  Same k order and epilogues: bit-identical.
-#ifndef YL_DWT_WAVES
-#define YL_DWT_WAVES 1
-#endif
-template <int NT, int DK, int DS, int MT>
-__global__ __launch_bounds__(256, YL_DWT_WAVES) void yl_conv_dwt_kernel(YlConvMulti mp) {
+// Wave-autonomous depthwise -> 1x1 convolution: the depthwise counterpart of yl_conv_pwt_kernel and the successor of
+// yl_conv_dwh_kernel (same per-wave algorithm: 4x4-pixel m-tiles, per 16-channel block the halo patch goes through
+// the wave's private LDS region, B = act(bias + sum_taps w*x), NT x 4 MFMAs per m-tile; same k order and epilogues:
+// bit-identical).  Persistent workgroups of four waves, one barrier (prologue), tiles dealt in XCD bands.  Two knobs:
+//   WL   where the 1x1 A fragments come from.  false: straight from L1/L2 (requested before the taps of the block
+//        they belong to) -- ~15 KB of LDS per workgroup, so K >= 192 layers keep 3-4 waves per SIMD where the LDS
+//        weight image allowed one workgroup per CU (50 -> 36 us);  true: an LDS image filled once per workgroup,
+//        the better choice when it is small (K = N = 96: 36 KB).
+//   MT   m-tiles per wave: 2 = a 4x8-pixel tile, both m-tiles share the 6x10 / 8x12 halo patch, every A fragment
+//        and every tap-weight read (LDS reads per pixel -35 %).
+template <int NT, int DK, int DS, int MT, bool WL>
+__global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlConvMulti mp) {
   YL_SELECT_PROBLEM_C(mp)
-  (void)gx;
   constexpr int HPY = 3 * DS + DK, HPX = (4 * MT - 1) * DS + DK;     // halo patch rows / columns
   constexpr int PITCHF = ((HPX * 16 + 7) / 64) * 64 + 56;            // row pitch in floats (see yl_conv_dwh_kernel)
   constexpr int HF4 = HPY * HPX * 4;
@@ -561,41 +574,52 @@ __global__ __launch_bounds__(256, YL_DWT_WAVES) void yl_conv_dwt_kernel(YlConvMu
   const int Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N, NTtot = p.NTtot, KB = p.KB;
   const float* const xin = p.x;
   const long zdelta = p.zeros - p.x;
-  float* dwl = yl_clds;                                              // [DK*DK][Cin] taps, [Cin] bias
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);                     // WL: [KB][NTtot][64] float4
+  float* dwl = yl_clds + (WL ? (size_t)KB * NTtot * 256 : 0);        // [DK*DK][Cin] taps, [Cin] bias
   float* halo = dwl + (((size_t)(DK * DK + 1) * Cin + 3) & ~(size_t)3) + wave * (HPY * PITCHF);
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
-  {
-    const int nw = DK * DK * Cin;
-    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
-    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cin, tid, 256);
-    else for (int i = tid; i < Cin; i += 256) dwl[nw + i] = 0.0f;
-  }
   const int twn = OW / (4 * MT), thn = OH >> 2;
   const int tiles_img = twn * thn;
-  const long ntiles = (long)p.B * tiles_img;
-  const long tile = (long)bx * 4 + wave;
-  const bool active = tile < ntiles;
-  const int b = active ? (int)(tile / tiles_img) : 0;
-  const int trem = active ? (int)(tile - (long)b * tiles_img) : 0;
-  const int tyi = trem / twn, txi = trem - tyi * twn;
-  // staging slots of this lane: halo pixel / channel quad -> LDS offset and (block 0) global offset
+  const int ntiles = p.B * tiles_img;
+  // tile order: workgroup b runs on XCD b % 8; each XCD takes one contiguous band of tiles (halo rows of neighbouring
+  // tiles then meet in the same L2), its workgroups' waves interleave inside the band
+  int tile, tend, wstride;
+  if ((gx & 7) == 0) {
+    const int tpx = (ntiles + 7) >> 3;
+    const int band0 = (bx & 7) * tpx;
+    tend = (band0 + tpx) < ntiles ? (band0 + tpx) : ntiles;
+    tile = band0 + (bx >> 3) * 4 + wave;
+    wstride = (gx >> 3) * 4;
+  } else {
+    tile = bx * 4 + wave; tend = ntiles; wstride = gx * 4;
+  }
+  // staging slots of this lane: halo pixel / channel quad -> LDS offset; global offsets per tile
   int s_lo[NSLOT];
-  long goff[NSLOT];
   bool s_ok[NSLOT];
-  {
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int e = j * 64 + lane;
+    s_ok[j] = e < HF4;
+    const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
+    const int hr = hp / HPX, hc = hp - hr * HPX;
+    s_lo[j] = hr * PITCHF + hc * 16 + quad * 4;
+  }
+  long goff[NSLOT];
+  auto tile_geom = [&](int t) {
+    const int b = t / tiles_img;
+    const int trem = t - b * tiles_img;
+    const int tyi = trem / twn, txi = trem - tyi * twn;
     const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * MT * txi * DS - p.dw_pad_l;
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       const int e = j * 64 + lane;
-      s_ok[j] = e < HF4;
-      const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
+      const int hp = (e < HF4 ? e : 0) >> 2;
       const int hr = hp / HPX, hc = hp - hr * HPX;
-      s_lo[j] = hr * PITCHF + hc * 16 + quad * 4;
       const int iy = iy0 + hr, ix = ix0 + hc;
-      const bool in = s_ok[j] && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      goff[j] = in ? (((long)b * H + iy) * W + ix) * Cin + quad * 4 : -1;
+      const bool in = e < HF4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      goff[j] = in ? (((long)b * H + iy) * W + ix) * Cin + (lane & 3) * 4 : -1;
     }
-  }
+  };
   auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
     const bool cok = kb * 16 + (lane & 3) * 4 < Cin;
 #pragma unroll
@@ -607,117 +631,197 @@ __global__ __launch_bounds__(256, YL_DWT_WAVES) void yl_conv_dwt_kernel(YlConvMu
       if (s_ok[j]) *reinterpret_cast<f32x4*>(halo + s_lo[j]) = r[j];
   };
   f32x4 stg[NSLOT];
-  if (active) stage_load(0, stg);
-  __syncthreads();                                                   // taps are in LDS (the only workgroup barrier)
-  if (!active) return;
+  bool primed = false;
+  if (tile < tend) {                       // first tile's first halo block: in flight together with the LDS fills
+    tile_geom(tile);
+    stage_load(0, stg);
+    primed = true;
+  }
+  if (WL) {
+    for (int i = wave; i < KB * NTtot; i += 4) yl_glds16(wg + (size_t)i * 64 + lane, wl + (size_t)i * 64);
+  }
+  {
+    const int nw = DK * DK * Cin;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cin, tid, 256);
+    else for (int i = tid; i < Cin; i += 256) dwl[nw + i] = 0.0f;
+  }
+  __syncthreads();                                                   // the only workgroup barrier
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
   const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
   const int dw_act = p.dw_act;
-  YlPix px[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    px[mt].b = b;
-    px[mt].oy = 4 * tyi + (pl >> 2);
-    px[mt].ox = 4 * MT * txi + 4 * mt + (pl & 3);
-    px[mt].valid = true;
-    px[mt].lin = ((size_t)b * OH + px[mt].oy) * OW + px[mt].ox;
-  }
   const bool pre_add = p.res != nullptr && p.up == nullptr && p.act == YL_ACT_NONE;
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + 4 * kq;
-      acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (pre_add && n < N) acc[mt][nt] = yl_ld4(p.res + px[mt].lin * N + n);
-    }
   const int rbase = ((pl >> 2) * DS) * PITCHF + ((pl & 3) * DS) * 16 + 4 * kq;
-  stage_store(stg);
-  for (int kb = 0; kb < KB; ++kb) {
-    const bool more = kb + 1 < KB;
-    if (more) stage_load(kb + 1, stg);
-    f32x4 wq[NT];                                                    // this block's A fragments: in flight under the taps
+  for (; tile < tend; tile += wstride) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / twn, txi = trem - tyi * twn;
+    YlPix px[MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wq[nt] = wg[((size_t)kb * NTtot + (nt < NTtot ? nt : NTtot - 1)) * 64 + lane];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // halo writes (all lanes) -> tap reads
-    const int c = kb * 16 + 4 * kq;
-    const int cs = c < Cin ? c : Cin - 4;
-    const float* tapw = dwl + cs;
-    f32x4 xq[MT];
+    for (int mt = 0; mt < MT; ++mt) {
+      px[mt].b = b;
+      px[mt].oy = 4 * tyi + (pl >> 2);
+      px[mt].ox = 4 * MT * txi + 4 * mt + (pl & 3);
+      px[mt].valid = true;
+      px[mt].lin = ((size_t)b * OH + px[mt].oy) * OW + px[mt].ox;
+    }
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_ld4(tapw + DK * DK * Cin);
-    if (DK == 3) {
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int dy = 0; dy < DK; ++dy)
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + 4 * kq;
+        acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (pre_add && n < N) acc[mt][nt] = yl_ld4(p.res + px[mt].lin * N + n);
+      }
+    if (!primed) {
+      tile_geom(tile);
+      stage_load(0, stg);
+    }
+    primed = false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // previous tile's tap reads are complete
+    stage_store(stg);
+    for (int kb = 0; kb < KB; ++kb) {
+      const bool more = kb + 1 < KB;
+      if (more) stage_load(kb + 1, stg);
+      f32x4 wq[NT];
+      if (!WL) {                                                     // A fragments from L1/L2: in flight under the taps
 #pragma unroll
-        for (int dx = 0; dx < DK; ++dx) {
-          const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * Cin);
+        for (int nt = 0; nt < NT; ++nt) wq[nt] = wg[((size_t)kb * NTtot + (nt < NTtot ? nt : NTtot - 1)) * 64 + lane];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // halo writes (all lanes) -> tap reads
+      const int c = kb * 16 + 4 * kq;
+      const int cs = c < Cin ? c : Cin - 4;
+      const float* tapw = dwl + cs;
+      f32x4 xq[MT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + (dx + 4 * mt * DS) * 16);
-            xq[mt].x = fmaf(v.x, w.x, xq[mt].x); xq[mt].y = fmaf(v.y, w.y, xq[mt].y);
-            xq[mt].z = fmaf(v.z, w.z, xq[mt].z); xq[mt].w = fmaf(v.w, w.w, xq[mt].w);
+      for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_ld4(tapw + DK * DK * Cin);
+      if (DK == 3) {
+#pragma unroll
+        for (int dy = 0; dy < DK; ++dy) {
+#pragma unroll
+          for (int dx = 0; dx < DK; ++dx) {
+            const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * Cin);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + (dx + 4 * mt * DS) * 16);
+              xq[mt].x = fmaf(v.x, w.x, xq[mt].x); xq[mt].y = fmaf(v.y, w.y, xq[mt].y);
+              xq[mt].z = fmaf(v.z, w.z, xq[mt].z); xq[mt].w = fmaf(v.w, w.w, xq[mt].w);
+            }
           }
+          if (MT > 1) __builtin_amdgcn_sched_barrier(0);             // one tap row in flight: bounds the live LDS reads
         }
-    } else {
+      } else {
 #pragma unroll 1
-      for (int dy = 0; dy < DK; ++dy) {
+        for (int dy = 0; dy < DK; ++dy) {                            // one tap row at a time bounds the register footprint
 #pragma unroll
-        for (int dx = 0; dx < DK; ++dx) {
-          const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * Cin);
+          for (int dx = 0; dx < DK; ++dx) {
+            const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * Cin);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + (dx + 4 * mt * DS) * 16);
-            xq[mt].x = fmaf(v.x, w.x, xq[mt].x); xq[mt].y = fmaf(v.y, w.y, xq[mt].y);
-            xq[mt].z = fmaf(v.z, w.z, xq[mt].z); xq[mt].w = fmaf(v.w, w.w, xq[mt].w);
+            for (int mt = 0; mt < MT; ++mt) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + (dx + 4 * mt * DS) * 16);
+              xq[mt].x = fmaf(v.x, w.x, xq[mt].x); xq[mt].y = fmaf(v.y, w.y, xq[mt].y);
+              xq[mt].z = fmaf(v.z, w.z, xq[mt].z); xq[mt].w = fmaf(v.w, w.w, xq[mt].w);
+            }
           }
         }
       }
-    }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_actc(xq[mt], dw_act, dlo, dhi);
-    // channel tail (c >= Cin): the packed 1x1 weights of those k slots are zero, no select needed
-    yl_mma_step<NT, MT>(wq, xq, acc);
-    if (more) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // this block's tap reads are complete
-      stage_store(stg);
+      for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_actc(xq[mt], dw_act, dlo, dhi);
+      // channel tail (c >= Cin): the packed 1x1 weights of those k slots are zero, no select needed
+      if (WL) {
+        const f32x4* wrow = wl + (size_t)kb * NTtot * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[(nt < NTtot ? nt : NTtot - 1) * 64];
+      }
+      yl_mma_step<NT, MT>(wq, xq, acc);
+      if (more) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // this block's tap reads are complete
+        stage_store(stg);
+      }
     }
+    if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
+    else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
   }
-  if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
-  else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
 }
 
-template <int NT, int DK, int DS, int MT>
+template <int NT, int DK, int DS, int MT, bool WL>
 static hipError_t dwt_go(YlConvMulti& m, hipStream_t st, bool attr_only) {
-  if (attr_only) return hipSuccess;
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_dwt_kernel<NT, DK, DS, MT, WL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   constexpr int HPY = 3 * DS + DK, HPX = (4 * MT - 1) * DS + DK;
   constexpr int PITCHF = ((HPX * 16 + 7) / 64) * 64 + 56;
   const YlConvP& p = m.p[0];
-  const size_t lds = ((((size_t)(DK * DK + 1) * p.Cin + 3) & ~(size_t)3) + (size_t)4 * HPY * PITCHF) * 4;
-  if (lds > 64 * 1024) return hipErrorNotSupported;
+  const size_t lds = ((WL ? (size_t)p.KB * p.NTtot * 256 : 0) + (((size_t)(DK * DK + 1) * p.Cin + 3) & ~(size_t)3) +
+                      (size_t)4 * HPY * PITCHF) * 4;
+  if (lds > 96 * 1024) return hipErrorNotSupported;
+  const int res = yl_resident_blocks_n(yl_conv_dwt_kernel<NT, DK, DS, MT, WL>, 256, lds);
+  long tiles[4], total = 0;
+  for (int k = 0; k < m.n; ++k) {
+    tiles[k] = (long)m.p[k].B * (m.p[k].OH >> 2) * (m.p[k].OW / (4 * MT));
+    total += tiles[k];
+  }
+  // persistent workgroups: the co-resident count shared between the problems in proportion to their tiles, each
+  // share a multiple of 8 (XCD bands) and at most one wave per tile
   int at = 0;
   for (int k = 0; k < m.n; ++k) {
-    const long tiles = (long)m.p[k].B * (m.p[k].OH >> 2) * (m.p[k].OW / (4 * MT));
+    long g = ((long)res * tiles[k] / total + 7) & ~7L;
+    const long cap = ((tiles[k] + 3) / 4 + 7) & ~7L;
+    if (g > cap) g = cap;
+    if (g < 8) g = 8;
     m.p[k].blk0 = at;
-    m.p[k].nblk = (int)((tiles + 3) / 4);
-    at += m.p[k].nblk;
+    m.p[k].nblk = (int)g;
+    at += (int)g;
   }
   if (m.n == 1) m.p[0].nblk = 0;
-  hipLaunchKernelGGL((yl_conv_dwt_kernel<NT, DK, DS, MT>), dim3((unsigned)at), dim3(256), lds, st, m);
+  hipLaunchKernelGGL((yl_conv_dwt_kernel<NT, DK, DS, MT, WL>), dim3((unsigned)at), dim3(256), lds, st, m);
   return hipGetLastError();
 }
 
-template <int NT, int MT>
-static hipError_t dwt_dk(YlConvMulti& m, hipStream_t st) {
+template <int NT, int MT, bool WL>
+static hipError_t dwt_dk(YlConvMulti& m, hipStream_t st, bool attr_only) {
   const YlConvP& p = m.p[0];
-  if (p.dw_k == 3 && p.dw_stride == 1) return dwt_go<NT, 3, 1, MT>(m, st, false);
-  if (p.dw_k == 3 && p.dw_stride == 2) return dwt_go<NT, 3, 2, MT>(m, st, false);
-  if (p.dw_k == 5 && p.dw_stride == 1) return dwt_go<NT, 5, 1, MT>(m, st, false);
-  if (p.dw_k == 5 && p.dw_stride == 2) return dwt_go<NT, 5, 2, MT>(m, st, false);
+  if (attr_only) {
+    hipError_t e = dwt_go<NT, 3, 1, MT, WL>(m, st, true);
+    if (e == hipSuccess) e = dwt_go<NT, 3, 2, MT, WL>(m, st, true);
+    if (e == hipSuccess) e = dwt_go<NT, 5, 1, MT, WL>(m, st, true);
+    if (e == hipSuccess) e = dwt_go<NT, 5, 2, MT, WL>(m, st, true);
+    return e;
+  }
+  if (p.dw_k == 3 && p.dw_stride == 1) return dwt_go<NT, 3, 1, MT, WL>(m, st, false);
+  if (p.dw_k == 3 && p.dw_stride == 2) return dwt_go<NT, 3, 2, MT, WL>(m, st, false);
+  if (p.dw_k == 5 && p.dw_stride == 1) return dwt_go<NT, 5, 1, MT, WL>(m, st, false);
+  if (p.dw_k == 5 && p.dw_stride == 2) return dwt_go<NT, 5, 2, MT, WL>(m, st, false);
   return hipErrorNotSupported;
+}
+
+template <int NT>
+static hipError_t dwt_nt(YlConvMulti& m, hipStream_t st, bool two, bool wl, bool attr_only) {
+#ifdef YL_DWT_MT2          // 4x8-pixel wave tiles: measured slower (below), not compiled by default
+  if (attr_only) {
+    hipError_t e = dwt_dk<NT, 2, false>(m, st, true);
+    return e == hipSuccess ? dwt_dk<NT, 2, true>(m, st, true) : e;
+  }
+  if (two) return wl ? dwt_dk<NT, 2, true>(m, st, false) : dwt_dk<NT, 2, false>(m, st, false);
+#endif
+  (void)two;
+  if (attr_only) {
+    hipError_t e = dwt_dk<NT, 1, false>(m, st, true);
+    return e == hipSuccess ? dwt_dk<NT, 1, true>(m, st, true) : e;
+  }
+  return wl ? dwt_dk<NT, 1, true>(m, st, false) : dwt_dk<NT, 1, false>(m, st, false);
+}
+
+static hipError_t dwt_any(YlConvMulti& m, int NT, hipStream_t st, bool two, bool wl, bool attr_only) {
+  hipError_t e = hipSuccess;
+  if (attr_only || NT == 1) e = dwt_nt<1>(m, st, two, wl, attr_only);
+  if (attr_only ? e == hipSuccess : NT == 2) e = dwt_nt<2>(m, st, two, wl, attr_only);
+  if (attr_only ? e == hipSuccess : NT == 3) e = dwt_nt<3>(m, st, two, wl, attr_only);
+  if (attr_only ? e == hipSuccess : NT == 4) e = dwt_nt<4>(m, st, two, wl, attr_only);
+  if (attr_only ? e == hipSuccess : NT == 6) e = dwt_nt<6>(m, st, two, wl, attr_only);
+  return e;
 }
 
 // depthwise (3x3 / 5x5, stride 1 / 2) -> 1x1 with N % 4 == 0, N <= 96 (all n-tiles in one wave), OH % 4 == 0,
@@ -725,14 +829,16 @@ static hipError_t dwt_dk(YlConvMulti& m, hipStream_t st) {
 hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st) {
   const YlConvP& p = m.p[0];
   if (p.dw_k == 0 || (p.N & 3) || p.NTtot > 6 || p.dec_boxes || p.C1 > 0) return hipErrorNotSupported;
-  // measured per layer against yl_conv_dwh_kernel (edge_n, B = 64): the wave-autonomous form wins where the LDS
-  // weight image would leave one workgroup per CU (K >= 192: 50 -> 36 us) and for narrow outputs (N <= 48: 33.5 ->
-  // 32 us, 64 -> 58 us at dw5 stride 2); at K = N = 96 both hold 3 waves per SIMD and the LDS-resident weights win
-  // by 5 %.  YL_DWT_MT: 0 = never, 1 / 2 = every supported layer with that m-tile count (ablation).
-  static const int mtsel = getenv("YL_DWT_MT") ? atoi(getenv("YL_DWT_MT")) : -1;
-  if (mtsel == 0) return hipErrorNotSupported;
-  if (mtsel < 0 && !(p.KB >= 12 || p.NTtot <= 3)) return hipErrorNotSupported;
-  bool two = mtsel == 2 && p.dw_stride == 1;
+  // Per-layer measurements (edge_n, B = 64, us; dwh = yl_conv_dwh_kernel, <mt><wl> = this kernel):
+  //   K=N=96 dw3 80x80:  dwh 143 | 10: 163 | 11: 137 | 20: 147 | 21: 141        K=96 N=48 dw3: dwh 32.9 | 11: 29.2
+  //   K=256 N=64 dw5:    dwh 49.7 | 10: 35.1 | 11: 49.3 | 20: 34.9             K=32 N=96 dw5 s2: dwh 76 | 11: 70
+  // -> one m-tile per wave (the 4x8 tile needs ~190 VGPRs: 2 waves per SIMD), LDS weight image while it is <= 36 KB.
+  // YL_DWT = "<mt><wl>" forces one configuration on every supported layer (ablation; mt 2 needs -DYL_DWT_MT2),
+  // "0" disables the kernel.
+  static const char* force = getenv("YL_DWT");
+  if (force && force[0] == '0') return hipErrorNotSupported;
+  bool two = false, wl = p.KB * p.NTtot <= 36;
+  if (force) { two = force[0] == '2' && p.dw_stride == 1; wl = force[1] == '1'; }
   for (int k = 0; k < m.n; ++k) {
     if ((m.p[k].OH & 3) || (m.p[k].OW & 3)) return hipErrorNotSupported;
     if (m.p[k].OW & 7) two = false;
@@ -740,13 +846,7 @@ hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st) {
   const int nts[5] = {1, 2, 3, 4, 6};
   int NT = 6;
   for (int i = 0; i < 5; ++i) if (nts[i] >= p.NTtot) { NT = nts[i]; break; }
-  switch (NT) {
-    case 1: return two ? dwt_dk<1, 2>(m, st) : dwt_dk<1, 1>(m, st);
-    case 2: return two ? dwt_dk<2, 2>(m, st) : dwt_dk<2, 1>(m, st);
-    case 3: return two ? dwt_dk<3, 2>(m, st) : dwt_dk<3, 1>(m, st);
-    case 4: return two ? dwt_dk<4, 2>(m, st) : dwt_dk<4, 1>(m, st);
-    default: return two ? dwt_dk<6, 2>(m, st) : dwt_dk<6, 1>(m, st);
-  }
+  return dwt_any(m, NT, st, two, wl, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1008,6 +1108,7 @@ hipError_t yl_convc_init() {
   hipError_t e = kxk_go<7, 1, 4>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<7, 2, 4>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<7, 1, 8>(q, 1, nullptr, true);
+  if (e == hipSuccess) e = dwt_any(m, 0, nullptr, false, false, true);
   if (e != hipSuccess) return e;
   return dwc_any(m, 0, 0, 0, 0, 0, nullptr, true, nullptr);
 }
