@@ -39,6 +39,7 @@
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
 #define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
+#define yl_launch_conv_dwk yl_launch_conv_dwk_bf16
 #define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
 #endif
 #include <stdio.h>
@@ -1142,6 +1143,11 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   if (n == 1 && p.dw_k == 0 && p.k > 1 && tile_hint != 6) {
     const hipError_t ek = yl_launch_conv_kxk(p, st);
     if (ek != hipErrorNotSupported) return ek;
+  }
+  // depthwise 3x3 -> wide 1x1 whose weight image is beyond LDS: streamed weights, taps from L1/L2 (yl_convc.hip)
+  if (n == 1 && p.dw_k == 3 && tile_hint != 6 && tile_hint != 3) {
+    const hipError_t ed = yl_launch_conv_dwk(p, st);
+    if (ed != hipErrorNotSupported) return ed;
   }
   // depthwise prologue with LDS-staged halo tiles (4x4 output pixels per wave)
   bool halo = p.dw_k > 0 && (p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2) && (p.N & 3) == 0 &&

@@ -33,6 +33,8 @@
 #define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
 #define yl_conv_dwt_kernel yl_conv_dwt_kernel_bf16
 #define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
+#define yl_conv_dwk_kernel yl_conv_dwk_kernel_bf16
+#define yl_launch_conv_dwk yl_launch_conv_dwk_bf16
 #define yl_conv_kxk_kernel yl_conv_kxk_kernel_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #endif
@@ -1049,6 +1051,202 @@ hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depthwise 3x3 -> 1x1 convolution whose 1x1 weights do not fit LDS (edge_m's 244-channel and yololite_m's
+// 328-channel neck / head blocks, model_v2.py:24-41: 240-430 KB packed).  yl_conv_dwh_kernel cannot hold the image and
+// the layer fell to yl_conv_mfma_kernel's streamed mode (48 TFLOP/s: fill / use barriers, 21 n-tiles as 8 + 8 + 5).
+// Same machinery as yl_conv_kxk_kernel: NT = 7 or 8 n-tiles per workgroup item, the weight stream double-buffered
+// through LDS in chunks of three k-steps with one barrier per chunk, (n-group, m-tile) items dealt group-major in XCD
+// bands.  The B operand of k-step kb is the depthwise result of the lane's pixel for 4 channels of block kb: nine
+// float4 taps straight from L1/L2 (requested one k-step ahead), bias + 9 fma in the tap order of
+// yl_conv_dwh_kernel, activation -- no halo patch in LDS.  Each n-group recomputes the depthwise part (36 fma per
+// 28-32 MFMAs).  Same k order and epilogues as the kernels it replaces: bit-identical.
+// GW = n-groups held by ONE wave (accumulators GW x NT x 4 VGPRs): 1 = every (n-group, m-tile) pair is its own item
+// and the depthwise part is recomputed per group; GW = all groups = no recomputation, 2 waves per SIMD.
+template <int NT, int GW, int NW>
+__global__ __launch_bounds__(NW * 64, GW == 1 ? 3 : 2) void yl_conv_dwk_kernel(YlConvP p) {
+  constexpr int S = GW == 1 ? 3 : 1;                         // k-steps per weight chunk
+  constexpr int PCS = S * GW * NT;                           // 1 KiB pieces per chunk
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int KB = p.KB, NTtot = p.NTtot;
+  const int Cin = p.Cin, H = p.H, W = p.W, DS = p.dw_stride, pad_t = p.dw_pad_t, pad_l = p.dw_pad_l;
+  const int ohw = p.OH * p.OW, OW = p.OW, M = p.M;
+  const float* const xin = p.x;
+  const long zdelta = p.zeros - p.x;
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][S][GW][NT][64] float4
+  float* dwl = yl_clds + (size_t)2 * PCS * 256;              // [9][Cin] taps, [Cin] bias
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
+  const int NC = (KB + S - 1) / S;                           // chunks per item
+  const int G = NTtot / (NT * GW);                           // item groups (1 when the wave holds every n-group)
+  const int bx = blockIdx.x, gx = gridDim.x;                 // gx % 8 == 0
+  const int per = gx >> 3, slot = bx >> 3;
+  const int tpx = (p.ntiles + 7) >> 3;
+  const int band0 = (bx & 7) * tpx;
+  const int band1 = (band0 + tpx) < p.ntiles ? (band0 + tpx) : p.ntiles;
+  const int bt = band1 > band0 ? band1 - band0 : 0;
+  const int nitems = bt * G;
+  const int nmine = slot < nitems ? (nitems - 1 - slot) / per + 1 : 0;
+  const long total_chunks = (long)nmine * NC;
+  auto load_chunk = [&](int g, int c, int buf) {
+    for (int i = wave; i < PCS; i += NW) {
+      const int j = i / (GW * NT), nt = i - j * (GW * NT);
+      const int kb = c * S + j;
+      if (kb < KB) yl_glds16(wg + ((size_t)kb * NTtot + g * (GW * NT) + nt) * 64 + lane, wl + ((size_t)buf * PCS + i) * 64);
+    }
+  };
+  if (total_chunks > 0) load_chunk(slot / bt, 0, 0);
+  {
+    const int nw = 9 * Cin;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, NW * 64);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cin, tid, NW * 64);
+    else for (int i = tid; i < Cin; i += NW * 64) dwl[nw + i] = 0.0f;
+  }
+  long gchunk = 0;
+  __syncthreads();
+  const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE;
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const int dw_act = p.dw_act;
+
+  for (int wi = 0; wi < nmine; ++wi) {
+    const int item = slot + wi * per;
+    const int g = item / bt;
+    const int nt0 = g * (GW * NT);
+    const int tile = band0 + item - g * bt;
+    YlPix px[1];
+    {
+      size_t lin = ((size_t)tile * NW + wave) * 16 + pl;
+      px[0].valid = lin < (size_t)M;
+      if (!px[0].valid) lin = (size_t)M - 1;
+      px[0].lin = lin;
+      const int b = (int)(lin / ohw);
+      const int rem = (int)(lin - (size_t)b * ohw);
+      px[0].b = b;
+      px[0].oy = rem / OW;
+      px[0].ox = rem - px[0].oy * OW;
+    }
+    f32x4 acc[GW][1][NT];
+#pragma unroll
+    for (int gw = 0; gw < GW; ++gw)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[gw][0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pre_add) {
+      const size_t obase = px[0].lin * p.N;
+      size_t up_off = 0;
+      if (p.up) {
+        const int uy = (px[0].oy * p.UH) / p.OH, ux = (px[0].ox * p.UW) / p.OW;
+        up_off = (((size_t)px[0].b * p.UH + uy) * p.UW + ux) * p.N;
+      }
+#pragma unroll
+      for (int gw = 0; gw < GW; ++gw)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = (nt0 + gw * NT + nt) * 16 + 4 * kq;
+          if (n < p.N) {
+            if (p.res) acc[gw][0][nt] = yl_ld4(p.res + obase + n);
+            if (p.up) acc[gw][0][nt] += yl_ld4(p.up + up_off + n);
+          }
+        }
+    }
+    // nine tap pointers of the lane's pixel (the zero buffer where a tap falls outside the image, marked in `inb`)
+    const float* tp[9];
+    unsigned inb = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = px[0].oy * DS - pad_t + tap / 3, ix = px[0].ox * DS - pad_l + tap % 3;
+      const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      tp[tap] = xin + (in ? ((((long)px[0].b * H + iy) * W + ix) * Cin + 4 * kq) : zdelta);
+      inb |= in ? (1u << tap) : 0u;
+    }
+    auto fetch = [&](f32x4 (&dst)[9], int kb) {
+      const bool tail = kb * 16 + 4 * kq >= Cin;                  // channel tail of the last block: zeros
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float* q = tp[tap] + (((inb >> tap) & 1u) ? kb * 16 : 0);
+        dst[tap] = yl_ld4(tail ? xin + zdelta : q);
+      }
+    };
+    f32x4 xt[9];
+    fetch(xt, 0);
+    for (int c = 0; c < NC; ++c, ++gchunk) {
+      const int buf = (int)(gchunk & 1);
+      if (gchunk + 1 < total_chunks) {
+        if (c + 1 < NC) load_chunk(g, c + 1, buf ^ 1);
+        else load_chunk((item + per) / bt, 0, buf ^ 1);
+      }
+      const f32x4* wb = wl + (size_t)buf * PCS * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        const int kb = c * S + j;
+        if (kb < KB) {
+          // depthwise result of block kb (tap order of yl_conv_dwh_kernel), then the next block's taps are requested
+          const int cc = kb * 16 + 4 * kq;
+          const int cs = cc < Cin ? cc : Cin - 4;
+          const float* tapw = dwl + cs;
+          f32x4 xq[1];
+          xq[0] = yl_ld4(tapw + 9 * Cin);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const f32x4 w = yl_ld4(tapw + tap * Cin);
+            xq[0].x = fmaf(xt[tap].x, w.x, xq[0].x); xq[0].y = fmaf(xt[tap].y, w.y, xq[0].y);
+            xq[0].z = fmaf(xt[tap].z, w.z, xq[0].z); xq[0].w = fmaf(xt[tap].w, w.w, xq[0].w);
+          }
+          xq[0] = yl_actc(xq[0], dw_act, dlo, dhi);
+          if (kb + 1 < KB) fetch(xt, kb + 1);
+#pragma unroll
+          for (int gw = 0; gw < GW; ++gw) {
+            f32x4 wq[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wq[nt] = wb[((j * GW + gw) * NT + nt) * 64];
+            yl_mma_step<NT, 1>(wq, xq, acc[gw]);
+          }
+        }
+      }
+      __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
+    }
+#pragma unroll
+    for (int gw = 0; gw < GW; ++gw) {
+      if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, 1>(p, acc[gw], px, nt0 + gw * NT, kq);
+      else yl_epi_fast<NT, 1>(p, acc[gw], px, nt0 + gw * NT, kq, lo, hi, true);
+    }
+  }
+}
+
+template <int NT, int GW, int NW>
+static hipError_t dwk_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_dwk_kernel<NT, GW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  YlConvP p = p0;
+  p.ntiles = (int)(((long)p.M + 16 * NW - 1) / (16 * NW));
+  const size_t lds = (size_t)2 * (GW == 1 ? 3 : 1) * GW * NT * 1024 + (((size_t)10 * p.Cin + 3) & ~(size_t)3) * 4;
+  if (lds > 96 * 1024) return hipErrorNotSupported;
+  const int res = yl_resident_blocks_n(yl_conv_dwk_kernel<NT, GW, NW>, NW * 64, lds);
+  const int G = p.NTtot / (NT * GW);
+  int gx = res & ~7;
+  while (gx > 8 && gx - 8 >= p.ntiles * G) gx -= 8;
+  hipLaunchKernelGGL((yl_conv_dwk_kernel<NT, GW, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
+  return hipGetLastError();
+}
+
+// depthwise 3x3 (stride 1 / 2) -> 1x1 with K >= 192, N % 4 == 0 and an n-tile count that is a multiple of 7 or 8,
+// single problem.  hipErrorNotSupported otherwise (yl_conv_mfma_kernel's streamed mode then runs the layer).
+hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
+  if (p.dw_k != 3 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.KB < 12 || p.NTtot <= 8) return hipErrorNotSupported;
+  // YL_DWK: 0 = off, 1 = one n-group per item (depthwise recomputed per group), 2 = a wave holds every n-group
+  static const int sel = getenv("YL_DWK") ? atoi(getenv("YL_DWK")) : 2;
+  if (sel == 0) return hipErrorNotSupported;
+  if (p.NTtot == 21) return sel == 2 ? dwk_go<7, 3, 4>(p, st, false) : dwk_go<7, 1, 4>(p, st, false);
+  if (p.NTtot == 16) return sel == 2 ? dwk_go<8, 2, 4>(p, st, false) : dwk_go<8, 1, 4>(p, st, false);
+  if (p.NTtot % 7 == 0) return dwk_go<7, 1, 4>(p, st, false);
+  if (p.NTtot % 8 == 0) return dwk_go<8, 1, 4>(p, st, false);
+  return hipErrorNotSupported;
+}
+
+// ------------------------------------------------------------------------------------------------
 namespace {
 
 template <typename K>
@@ -1109,6 +1307,10 @@ hipError_t yl_convc_init() {
   if (e == hipSuccess) e = kxk_go<7, 2, 4>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<7, 1, 8>(q, 1, nullptr, true);
   if (e == hipSuccess) e = dwt_any(m, 0, nullptr, false, false, true);
+  if (e == hipSuccess) e = dwk_go<7, 1, 4>(q, nullptr, true);
+  if (e == hipSuccess) e = dwk_go<7, 3, 4>(q, nullptr, true);
+  if (e == hipSuccess) e = dwk_go<8, 1, 4>(q, nullptr, true);
+  if (e == hipSuccess) e = dwk_go<8, 2, 4>(q, nullptr, true);
   if (e != hipSuccess) return e;
   return dwc_any(m, 0, 0, 0, 0, 0, nullptr, true, nullptr);
 }

@@ -152,6 +152,9 @@ hipError_t yl_launch_conv_kxk_bf16(const YlConvP& p, hipStream_t st);
 // wave-autonomous depthwise -> 1x1 kernel (yl_convc.hip); hipErrorNotSupported = shape outside its limits
 hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st);
 hipError_t yl_launch_conv_dwt_bf16(YlConvMulti& m, hipStream_t st);
+// streamed-weight depthwise 3x3 -> 1x1 kernel for K >= 192 and more than 8 n-tiles (yl_convc.hip)
+hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv_dwk_bf16(const YlConvP& p, hipStream_t st);
 hipError_t yl_convc_init();
 hipError_t yl_convc_init_bf16();
 // bf16-MFMA builds of yl_conv.hip / yl_stemblock.hip (compiled a second time with -DYL_BF16=1, see yl_dev.h)
