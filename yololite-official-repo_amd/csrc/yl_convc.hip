@@ -606,11 +606,19 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
     const int hr = hp / HPX, hc = hp - hr * HPX;
     s_lo[j] = hr * PITCHF + hc * 16 + quad * 4;
   }
+  // (image, tile row, tile column) of the wave's current tile, advanced by the decomposition of wstride with two
+  // carries: no integer division per tile (each one is ~25 VALU instructions, and fp32 VALU time is MFMA time)
+  int tb = 0, tyi = 0, txi = 0;
+  if (tile < tend) {
+    tb = tile / tiles_img;
+    const int trem = tile - tb * tiles_img;
+    tyi = trem / twn; txi = trem - tyi * twn;
+  }
+  const int sdb = wstride / tiles_img, sdrem = wstride - sdb * tiles_img;
+  const int sdy = sdrem / twn, sdx = sdrem - sdy * twn;
   long goff[NSLOT];
-  auto tile_geom = [&](int t) {
-    const int b = t / tiles_img;
-    const int trem = t - b * tiles_img;
-    const int tyi = trem / twn, txi = trem - tyi * twn;
+  auto tile_geom = [&]() {
+    const int b = tb;
     const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * MT * txi * DS - p.dw_pad_l;
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   f32x4 stg[NSLOT];
   bool primed = false;
   if (tile < tend) {                       // first tile's first halo block: in flight together with the LDS fills
-    tile_geom(tile);
+    tile_geom();
     stage_load(0, stg);
     primed = true;
   }
@@ -657,9 +665,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   const bool pre_add = p.res != nullptr && p.up == nullptr && p.act == YL_ACT_NONE;
   const int rbase = ((pl >> 2) * DS) * PITCHF + ((pl & 3) * DS) * 16 + 4 * kq;
   for (; tile < tend; tile += wstride) {
-    const int b = tile / tiles_img;
-    const int trem = tile - b * tiles_img;
-    const int tyi = trem / twn, txi = trem - tyi * twn;
+    const int b = tb;
     YlPix px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
         if (pre_add && n < N) acc[mt][nt] = yl_ld4(p.res + px[mt].lin * N + n);
       }
     if (!primed) {
-      tile_geom(tile);
+      tile_geom();
       stage_load(0, stg);
     }
     primed = false;
@@ -746,6 +752,11 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
     }
     if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
+    txi += sdx;
+    if (txi >= twn) { txi -= twn; ++tyi; }
+    tyi += sdy;
+    if (tyi >= thn) { tyi -= thn; ++tb; }
+    tb += sdb;
   }
 }
 
