@@ -269,6 +269,25 @@ def bench_tracker(args):
     print(json.dumps(out))
 
 
+def kernel_family(L):
+    """Kernel the dispatcher (yl_launch_conv_multi, yl_conv.hip / yl_convc.hip) picks for a fused layer of the program:
+    a label for the roofline object, the rocprofv3 summaries under profiles/ carry the exact instantiation."""
+    if L.op == 3:
+        return "yl_stemblock_kernel"
+    if L.op != 1:
+        return "yl_stem_mfma_kernel" if L.op == 0 else "yl_dw_kernel"
+    nt, kb = -(-L.cout // 16), -(-L.cin // 16)
+    if L.dw_k == 0:
+        if L.k == 1:
+            return "yl_conv_pwt_kernel"
+        return "yl_conv_kxk_kernel" if (L.k == 3 and nt % 7 == 0 and L.k * L.k * kb * 7 > 96) else "yl_conv_mfma_kernel"
+    if nt <= 6:
+        return "yl_conv_dwt_kernel"
+    if L.dw_k == 3 and kb >= 12 and nt > 8 and (nt % 7 == 0 or nt % 8 == 0):
+        return "yl_conv_dwk_kernel"
+    return "yl_conv_dwh_kernel"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -453,8 +472,7 @@ def main():
                                           "factors from profiles/r02_fetch_calibration.json (independent known-byte-count kernels)")
         except (OSError, KeyError, ValueError, StopIteration):
             pass
-        roof["kernel"] = f"layer {k} {L.name} (yl_conv_mfma_kernel, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})" \
-            if L.op == 1 else f"layer {k} {L.name}"
+        roof["kernel"] = f"layer {k} {L.name} ({kernel_family(L)}, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})"
         roof["avg_launch_ms"] = round(float(lay[k]), 4)
         roof["algorithmic_flops_per_launch"] = flops
         roof["algorithmic_bytes_per_launch"] = byts
