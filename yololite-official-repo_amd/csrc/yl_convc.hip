@@ -1046,15 +1046,21 @@ static hipError_t kxk_go(const YlConvP& p0, int gy, hipStream_t st, bool attr_on
   return hipGetLastError();
 }
 
-// dense k x k (k > 1) layers with N % 4 == 0 whose weight image exceeds the LDS budget and whose n-tile count is a
-// multiple of 7.  hipErrorNotSupported otherwise (yl_conv_mfma_kernel then runs the layer).
+// dense 3x3 layers with N % 4 == 0 whose weight image exceeds the LDS budget and whose n-tile count is a multiple of 7
+// (yololite_m's 328-channel FPN) or exactly 4 (the 64-channel prototype branch of the seg head: two m-tiles per wave
+// so that a weight fragment read feeds 8 MFMAs).  hipErrorNotSupported otherwise (yl_conv_mfma_kernel runs the layer).
 hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
-  if (p.k != 3 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.NTtot % 7 != 0) return hipErrorNotSupported;
+  if (p.k != 3 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0) return hipErrorNotSupported;
+  static const int NWsel = getenv("YL_KXK_NW") ? atoi(getenv("YL_KXK_NW")) : 0;
+  static const int MTsel = getenv("YL_KXK_MT") ? atoi(getenv("YL_KXK_MT")) : 1;
+  if (p.NTtot == 4) {
+    if ((size_t)p.TK * 4 * 1024 <= 96 * 1024 || NWsel < 0) return hipErrorNotSupported;
+    return NWsel == 8 ? kxk_go<4, 1, 8>(p, 1, st, false) : kxk_go<4, 2, 4>(p, 1, st, false);
+  }
+  if (p.NTtot % 7 != 0) return hipErrorNotSupported;
   if ((size_t)p.TK * 7 * 1024 <= 96 * 1024) return hipErrorNotSupported;      // small enough to stay resident: other kernel
   // 8 waves per workgroup share each weight chunk (half the LDS-DMA issue work per MFMA: 107 -> 114 TFLOP/s on
   // yololite_m's 80x80 level) when there are enough 128-pixel items to keep the tail short; 4 otherwise
-  static const int NWsel = getenv("YL_KXK_NW") ? atoi(getenv("YL_KXK_NW")) : 0;
-  static const int MTsel = getenv("YL_KXK_MT") ? atoi(getenv("YL_KXK_MT")) : 1;
   const int gy = p.NTtot / 7;
   const bool eight = NWsel ? NWsel == 8 : ((long)p.M / 128) * gy >= 2 * 2 * YL_NUM_CU;
   if (eight) return kxk_go<7, 1, 8>(p, gy, st, false);
@@ -1317,6 +1323,8 @@ hipError_t yl_convc_init() {
   hipError_t e = kxk_go<7, 1, 4>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<7, 2, 4>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<7, 1, 8>(q, 1, nullptr, true);
+  if (e == hipSuccess) e = kxk_go<4, 1, 8>(q, 1, nullptr, true);
+  if (e == hipSuccess) e = kxk_go<4, 2, 4>(q, 1, nullptr, true);
   if (e == hipSuccess) e = dwt_any(m, 0, nullptr, false, false, true);
   if (e == hipSuccess) e = dwk_go<7, 1, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<7, 3, 4>(q, nullptr, true);
