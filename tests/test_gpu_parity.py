@@ -211,6 +211,35 @@ def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
                 assert torch.equal(u, v), hint
 
 
+def test_tiled_depthwise_kernel_is_bitwise_the_per_output_kernel(tmp_path):
+    """yl_dw_tile_kernel (register-tiled stand-alone depthwise, yololite_m's backbone) accumulates every output's taps
+    in the (dy, dx) order of yl_dw_kernel -> identical bits.  The switch is a process-wide environment variable
+    (YL_DW_TILE=0), so the two variants run in two interpreters."""
+    import subprocess
+    import sys
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_gpu_parity import zoo_meta, synth_state_dict, _hip_for, _x, DEV\n"
+        "outs = []\n"
+        "for S, B in ((256, 2), (224, 1)):\n"
+        "    meta = zoo_meta('yololite_m', 80, S)\n"
+        "    m = _hip_for(meta, synth_state_dict(meta, seed=4))\n"
+        "    outs += [t.cpu().numpy() for t in m(_x(B, S, seed=11).to(DEV))]\n"
+        "np.savez(sys.argv[1], *outs)\n" % (ROOT, os.path.join(ROOT, "tests")))
+    res = []
+    for v in ("0", "1"):
+        f = str(tmp_path / f"dw{v}.npz")
+        env = dict(os.environ, YL_DW_TILE=v)
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, cwd=ROOT, timeout=600)
+        z = np.load(f)
+        res.append([z[k] for k in z.files])
+    assert len(res[0]) == len(res[1]) and len(res[0]) >= 6
+    for a, b in zip(*res):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
 def test_forward_batch_invariance_and_determinism_full_size():
     """BASELINE config 2 (edge_n 640x640 B=64): bitwise repeatable, and image i of the batch equals the
     same image run alone (size-independent property; the oracle is too slow at this size)."""

@@ -28,6 +28,7 @@
 #define yl_uib_kernel yl_uib_kernel_bf16
 #define yl_stem_mfma_kernel yl_stem_mfma_kernel_bf16
 #define yl_dw_kernel yl_dw_kernel_bf16
+#define yl_dw_tile_kernel yl_dw_tile_kernel_bf16
 #define yl_launch_conv yl_launch_conv_bf16
 #define yl_launch_conv_multi yl_launch_conv_multi_bf16
 #define yl_launch_stem yl_launch_stem_bf16
@@ -893,6 +894,120 @@ __global__ __launch_bounds__(256) void yl_dw_kernel(YlConvP p) {
   *reinterpret_cast<f32x4*>(p.out + o) = s;
 }
 
+// Register-tiled stand-alone depthwise K x K (stride S): a lane owns 4 channels of a 4 x 2 block of output pixels and
+// streams the (3S+K) x (S+K) input window row by row through registers, so an input value is fetched once per
+// 8 outputs x the window overlap (6 float4 loads per output at 5x5 stride 1) instead of once per tap (25): the
+// one-output-per-lane kernel above is L2-bandwidth-bound (0.34 ms = 0.87 TB/s of HBM-side traffic for yololite_m's
+// 720-channel 5x5 layers at 40x40, 11 TB/s out of L2).  Consecutive lanes = consecutive channel quads of the same
+// pixels (coalesced 16-byte loads); a workgroup = 64 channel quads x 4 pixel blocks, persistent over the pixel
+// blocks with its K*K x 256 tap weights (+ bias) in LDS.  Taps outside the image read the zero buffer and are
+// accumulated in the same (dy, dx) order as yl_dw_kernel: bit-identical.
+template <int K, int S>
+__global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
+  constexpr int TX = 4, TY = 2;
+  constexpr int COLS = (TX - 1) * S + K, ROWS = (TY - 1) * S + K;
+  __shared__ __attribute__((aligned(16))) float wl[(K * K + 1) * 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // block coordinates below stay in SGPRs
+  const int C = p.Cin;
+  const int cbase = blockIdx.x * 256;
+  for (int i = threadIdx.x; i < (K * K + 1) * 256; i += 256) {
+    const int t = i >> 8, c = cbase + (i & 255);
+    float v = 0.0f;
+    if (c < C) v = t < K * K ? p.wp[t * C + c] : (p.bias ? p.bias[c] : 0.0f);
+    wl[i] = v;
+  }
+  __syncthreads();
+  const int c = cbase + lane * 4;
+  if (c >= C) return;
+  const int H = p.H, W = p.W, OH = p.OH, OW = p.OW;
+  const int bxn = (OW + TX - 1) / TX, byn = (OH + TY - 1) / TY;
+  const long nblk = (long)p.B * byn * bxn;
+  const long zdelta = p.zeros - p.x;
+  const float* wq = wl + lane * 4;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(wq + K * K * 256);
+  for (long blk = (long)blockIdx.y * 4 + wave; blk < nblk; blk += (long)gridDim.y * 4) {
+    const int b = (int)(blk / (byn * bxn));
+    const int r0 = (int)(blk - (long)b * byn * bxn);
+    const int by = r0 / bxn, bx = r0 - by * bxn;
+    const int oy0 = by * TY, ox0 = bx * TX;
+    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+    f32x4 acc[TY][TX];
+#pragma unroll
+    for (int t = 0; t < TY; ++t)
+#pragma unroll
+      for (int j = 0; j < TX; ++j) acc[t][j] = bias;
+    // addresses: wave-uniform 64-bit base per (row, column) (SALU) + the lane's 32-bit channel offset; a tap outside
+    // the image selects the zero buffer with offset 0
+    const char* xb = reinterpret_cast<const char*>(p.x + (size_t)b * H * W * C);
+    const unsigned coff = (unsigned)c * 4u;
+    const long zoff = reinterpret_cast<const char*>(p.zeros) - xb;
+    // window rows double-buffered in registers: row r + 1 is requested before the FMAs of row r (the scheduling
+    // barriers keep the compiler from hoisting all ROWS x COLS loads to the top: 192 VGPRs and spills at 5x5)
+    auto load_row = [&](int r, f32x4 (&row)[COLS]) {
+      const int iy = iy0 + r;
+      const bool yok = iy >= 0 && iy < H;
+#pragma unroll
+      for (int q = 0; q < COLS; ++q) {
+        const int ix = ix0 + q;
+        const bool ok = yok && ix >= 0 && ix < W;
+        const long m = -(long)ok;                                     // branch-free select (uniform: SALU and/or)
+        const long off = ((((long)iy * W + ix) * C * 4) & m) | (zoff & ~m);
+        row[q] = *reinterpret_cast<const f32x4*>(xb + off + (coff & (unsigned)m));
+      }
+    };
+    // 5x5: the 25 tap weights must be re-read from LDS per block (an opaque zero in their address stops the compiler
+    // from hoisting 100 VGPRs of them out of the persistent loop); 3x3: the 9 hoisted weights stay in registers
+    int wz = 0;
+    if (K > 3) asm volatile("" : "+s"(wz));
+    const float* wqb = wq + wz;
+    f32x4 rows[2][COLS];
+    load_row(0, rows[0]);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (r + 1 < ROWS) load_row(r + 1, rows[(r + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+        const int dy = r - t * S;
+        if (dy < 0 || dy >= K) continue;
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(wqb + (dy * K + dx) * 256);
+#pragma unroll
+          for (int j = 0; j < TX; ++j) {
+            const f32x4 v = rows[r & 1][j * S + dx];
+            acc[t][j].x = fmaf(v.x, w.x, acc[t][j].x); acc[t][j].y = fmaf(v.y, w.y, acc[t][j].y);
+            acc[t][j].z = fmaf(v.z, w.z, acc[t][j].z); acc[t][j].w = fmaf(v.w, w.w, acc[t][j].w);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // pin the accumulators here: without it LLVM sinks every output's 25-FMA chain into its guarded store block
+    // below, which keeps the whole ROWS x COLS window (192 VGPRs at 5x5) alive until then
+#pragma unroll
+    for (int t = 0; t < TY; ++t)
+#pragma unroll
+      for (int j = 0; j < TX; ++j)
+        asm volatile("" : "+v"(acc[t][j].x), "+v"(acc[t][j].y), "+v"(acc[t][j].z), "+v"(acc[t][j].w));
+#pragma unroll
+    for (int t = 0; t < TY; ++t) {
+      const int oy = oy0 + t;
+      if (oy >= OH) continue;
+#pragma unroll
+      for (int j = 0; j < TX; ++j) {
+        const int ox = ox0 + j;
+        if (ox >= OW) continue;
+        f32x4 s4 = yl_act4(acc[t][j], p.act);
+        const size_t o = (((size_t)b * OH + oy) * OW + ox) * p.N + c;
+        if (p.res) s4 += yl_ld4(p.res + o);
+        *reinterpret_cast<f32x4*>(p.out + o) = s4;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 #define YL_CONV_LDS_MAX (128 * 1024)
 
@@ -1259,7 +1374,25 @@ hipError_t yl_launch_stem(const YlConvP& p0, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int K, int S>
+static hipError_t yl_launch_dw_tile(const YlConvP& p, hipStream_t st) {
+  const int gx = (p.Cin + 255) / 256;
+  const long nblk = (long)p.B * ((p.OH + 1) / 2) * ((p.OW + 3) / 4);
+  long gy = (long)8 * YL_NUM_CU / gx;                         // ~8 workgroups per CU in flight, persistent over the rest
+  if (gy > (nblk + 3) / 4) gy = (nblk + 3) / 4;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL((yl_dw_tile_kernel<K, S>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
 hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st) {
+  static const bool tile_off = getenv("YL_DW_TILE") && atoi(getenv("YL_DW_TILE")) == 0;
+  if (!tile_off && (p.Cin & 3) == 0 && p.N == p.Cin) {
+    if (p.k == 3 && p.stride == 1) return yl_launch_dw_tile<3, 1>(p, st);
+    if (p.k == 3 && p.stride == 2) return yl_launch_dw_tile<3, 2>(p, st);
+    if (p.k == 5 && p.stride == 1) return yl_launch_dw_tile<5, 1>(p, st);
+    if (p.k == 5 && p.stride == 2) return yl_launch_dw_tile<5, 2>(p, st);
+  }
   const size_t total = (size_t)p.M * (p.Cin >> 2);
   hipLaunchKernelGGL(yl_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
   return hipGetLastError();
