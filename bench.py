@@ -280,7 +280,8 @@ def kernel_family(L):
     if L.dw_k == 0:
         if L.k == 1:
             return "yl_conv_pwt_kernel"
-        return "yl_conv_kxk_kernel" if (L.k == 3 and nt % 7 == 0 and L.k * L.k * kb * 7 > 96) else "yl_conv_mfma_kernel"
+        streamed = L.k == 3 and ((nt % 7 == 0 and 9 * kb * 7 > 96) or (nt == 4 and 9 * kb * 4 > 96))
+        return "yl_conv_kxk_kernel" if streamed else "yl_conv_mfma_kernel"
     if nt <= 6:
         return "yl_conv_dwt_kernel"
     if L.dw_k == 3 and kb >= 12 and nt > 8 and (nt % 7 == 0 or nt % 8 == 0):
