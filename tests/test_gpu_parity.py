@@ -110,11 +110,13 @@ def test_forward_reference_fixture_weights(golden_dir):
             assert err <= 1e-4 + 1e-4 * np.abs(r).max(), (tag, j, err)
 
 
-@pytest.mark.parametrize("name,B,S", [("edge_n", 2, 640), ("edge_m", 1, 320), ("yololite_m", 1, 256)])
+@pytest.mark.parametrize("name,B,S", [("edge_n", 2, 640), ("edge_m", 1, 320), ("yololite_m", 1, 256),
+                                      ("edge_n", 1, 416), ("yololite_m", 1, 224), ("edge_m", 2, 352)])
 @pytest.mark.parametrize("uib", [False, True])
 def test_forward_zoo_models(name, B, S, uib):
     """BASELINE configs 2-4 backbones/necks/heads at reduced batch; uib=True also runs the inverted-residual
-    blocks as single fused launches (expand -> depthwise -> project)."""
+    blocks as single fused launches (expand -> depthwise -> project).  416 / 224 / 352: level grids of 13, 7, 11 pixels
+    (not multiples of the 4x4 / 4x2 tiles of the depthwise kernels: partial tiles and the fallback kernels)."""
     meta = zoo_meta(name, 80, S)
     sd = synth_state_dict(meta, seed=0)
     x = _x(B, S)
