@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   // global-load latency hides behind tile t's 3x3 / 1x1 MFMAs.
   float xv[SB_MT1][KS];
   int nb = 0, ntyi = 0, ntxi = 0;                    // decode of the tile whose gather is in flight
+  int gb = 0, gty = 0, gtx = 0, sdb = 0, sdy = 0, sdx = 0;   // next gather tile and the decomposition of the tile stride
   auto gather = [&](int tile) {
     if (SB_EXP == 1) {
 #pragma unroll
@@ -138,10 +139,14 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
         for (int s = 0; s < KS; ++s) xv[m][s] = (float)(tile + m + s);
       return;
     }
-    const int b = tile / tiles_img;
-    const int trem = tile - b * tiles_img;
-    const int tyi = trem / tpr, txi = trem - tyi * tpr;
+    (void)tile;                                       // (image, tile row, tile column) of `tile` are carried in gb/gty/gtx
+    const int b = gb, tyi = gty, txi = gtx;
     nb = b; ntyi = tyi; ntxi = txi;
+    gtx += sdx;                                       // advance to the tile of the NEXT call (tile + wstride2): two
+    if (gtx >= tpr) { gtx -= tpr; ++gty; }            // carries instead of two integer divisions (~50 VALU ops, and
+    gty += sdy;                                       // fp32 VALU time is MFMA time in this kernel)
+    if (gty >= tpc) { gty -= tpc; ++gb; }
+    gb += sdb;
     const int sy0 = 2 * tyi * SB_TR - 1, sx0 = 2 * txi * SB_TC - 1;
     const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;
     const float* xb = p.x + (size_t)b * 3 * plane;
@@ -182,7 +187,15 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #ifdef SB_STAGGER
   if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(SB_STAGGER);   // de-phase the two co-resident blocks of a CU
 #endif
-  if (tile0 < tend) gather(tile0);
+  if (tile0 < tend) {
+    gb = tile0 / tiles_img;
+    const int trem = tile0 - gb * tiles_img;
+    gty = trem / tpr; gtx = trem - gty * tpr;
+    sdb = wstride2 / tiles_img;
+    const int srem = wstride2 - sdb * tiles_img;
+    sdy = srem / tpr; sdx = srem - sdy * tpr;
+    gather(tile0);
+  }
 
   for (int tile = tile0; tile < tend; tile += wstride2) {
     const int b = nb, tyi = ntyi, txi = ntxi;
