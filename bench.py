@@ -318,6 +318,8 @@ def main():
     ap.add_argument("--fuse-decode", type=int, default=1, help="decode inside the head-output conv epilogue")
     ap.add_argument("--lanes", type=int, default=0, help="side-stream lane for the coarse-level neck/head layers")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16-MFMA compute mode (f4; NOT the headline: reduced precision)")
+    ap.add_argument("--winograd", type=int, default=0, help="1: dense 3x3 stride-1 convs (>= 64 channels) as Winograd F(2x2,3x3): "
+                    "2.25x fewer MACs, results within 1e-4 of the direct convolution but not bit-identical")
     ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3) | track (tracker bank, f4)")
     args = ap.parse_args()
 
@@ -358,6 +360,7 @@ def main():
     ctx.set_option("batch_levels", args.batch_levels)
     ctx.set_option("hybrid", args.hybrid)
     ctx.set_option("nms_groups", args.nms_groups)
+    ctx.set_option("winograd", args.winograd)
     max_out = MAX_OUT                                    # packed result rows per image
     gat = None
     if world > 1 or force_coll:

@@ -213,6 +213,31 @@ def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
                 assert torch.equal(u, v), hint
 
 
+@pytest.mark.parametrize("name,B,S", [("yololite_m", 2, 256), ("yololite_m", 1, 224)])
+def test_winograd_option_matches_direct_convolution(name, B, S):
+    """Option "winograd": the dense 3x3 stride-1 FPN convs (>= 64 channels) as Winograd F(2x2,3x3).  Not bit-identical
+    (the transforms round differently); the raw head logits must stay within the oracle bound of the direct path
+    (_cmp_levels: 2e-4 abs / decoded scores 1e-4) and within 1e-4 of the direct HIP result.  224: odd level grids
+    (7x7: a partial last Winograd tile row / column)."""
+    meta = zoo_meta(name, 80, S)
+    sd = synth_state_dict(meta, seed=5)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    x = _x(B, S, seed=3)
+    direct = [t.clone() for t in m(x.to(DEV))]
+    ctx.set_option("winograd", 1)
+    wino = [t.clone() for t in m(x.to(DEV))]
+    ctx.set_option("winograd", 0)
+    again = m(x.to(DEV))
+    for u, v, w in zip(direct, wino, again):
+        assert torch.equal(u, w)                                   # the switch is clean
+        assert not torch.equal(u, v)                               # ... and really selects another kernel
+        assert float((u - v).abs().max()) <= 1e-4, float((u - v).abs().max())
+    with torch.no_grad():
+        ref = _oracle_for(meta, sd)(x)
+    _cmp_levels(wino, ref, C=80)
+
+
 def test_tiled_depthwise_kernel_is_bitwise_the_per_output_kernel(tmp_path):
     """yl_dw_tile_kernel (register-tiled stand-alone depthwise, yololite_m's backbone) accumulates every output's taps
     in the (dy, dx) order of yl_dw_kernel -> identical bits.  The switch is a process-wide environment variable

@@ -26,6 +26,7 @@ struct DevLayer {
   float* b2 = nullptr;
   float* w3p = nullptr;
   float* b3 = nullptr;
+  float* wino = nullptr; // Winograd F(2x2,3x3) weight image of a dense 3x3 stride-1 conv (pack_wino), or nullptr
   int in_h = 0, in_w = 0, out_h = 0, out_w = 0;
   int head_anchor = -1;  // head layers: anchor index handled by this layer
 };
@@ -90,6 +91,8 @@ struct yl_ctx {
   int small_lo = 0, small_hi = 0;   // that run: layers [small_lo, small_hi)
   int opt_batch_levels = 1;  // runs of independent, identically shaped layers (FPN smooth / head trunk / head out of all
                              // levels) go out as ONE launch (YlConvMulti)
+  int opt_winograd = 0;      // dense 3x3 stride-1 layers with >= 64 channels through Winograd F(2x2,3x3) (2.25x fewer MACs;
+                             // NOT bit-identical to the direct convolution: fp32 rounding of the transforms)
   int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
   int opt_bf16 = 0;   // 1: conv / stem-block launches use the bf16-MFMA builds (fp32 storage, fp32 accumulate)
   // batch chunks run on `opt_streams` internal streams (fork/join around every call): the
@@ -166,6 +169,33 @@ void pack_conv(const float* w, int cout, int cin, int k, std::vector<float>& out
             if (n < cout && c < cin)
               out[((((size_t)tap * KB + kb) * NT + nt) * 64 + lane) * 4 + s] =
                   w[((size_t)n * cin + c) * taps + tap];
+          }
+}
+
+// Winograd F(2x2,3x3): U = G g G^T (4x4 per (cout, cin)), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], in the MFMA
+// fragment order of pack_conv per transform position xi = 4i + j, grouped so that one (n-group of 2 n-tiles, k-block)
+// chunk is 32 KiB contiguous: [ngroup][kblock][xi][nt 0..1][lane][s]   (yl_conv_wino_kernel)
+void pack_wino(const float* w, int cout, int cin, std::vector<float>& out) {
+  const int KB = cdiv(cin, 16), NG = cdiv(cdiv(cout, 16), 2);
+  static const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  out.assign((size_t)NG * KB * 16 * 2 * 256, 0.0f);
+  for (int ng = 0; ng < NG; ++ng)
+    for (int kb = 0; kb < KB; ++kb)
+      for (int t = 0; t < 2; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            const int n = (ng * 2 + t) * 16 + (lane & 15);
+            const int c = kb * 16 + 4 * (lane >> 4) + s;
+            if (n >= cout || c >= cin) continue;
+            const float* g = w + ((size_t)n * cin + c) * 9;
+            float tmp[4][3];
+            for (int i = 0; i < 4; ++i)
+              for (int b = 0; b < 3; ++b) tmp[i][b] = G[i][0] * g[0 * 3 + b] + G[i][1] * g[1 * 3 + b] + G[i][2] * g[2 * 3 + b];
+            for (int i = 0; i < 4; ++i)
+              for (int j = 0; j < 4; ++j) {
+                const float u = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                out[(((((size_t)ng * KB + kb) * 16 + (i * 4 + j)) * 2 + t) * 64 + lane) * 4 + s] = u;
+              }
           }
 }
 
@@ -400,6 +430,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   memset(&p, 0, sizeof(p));
   const yl_layer& d = L.d;
   p.wp = L.wp; p.bias = L.bias; p.dw_w = L.dw_w; p.dw_b = L.dw_b;
+  p.wino = c->opt_winograd ? L.wino : nullptr;
   p.zeros = c->zeros;
   p.B = B; p.H = L.in_h; p.W = L.in_w; p.Cin = d.cin;
   p.OH = L.out_h; p.OW = L.out_w; p.N = d.cout;
@@ -750,7 +781,8 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = tru
   memcpy(key.data(), &j, sizeof(Job));
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
   const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10) |
-                     (c->opt_batch_levels << 11) | (c->opt_hybrid << 12) | (c->opt_nms_groups << 13);
+                     (c->opt_batch_levels << 11) | (c->opt_hybrid << 12) | (c->opt_nms_groups << 13) |
+                     (c->opt_winograd << 17);
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
@@ -854,7 +886,7 @@ void yl_destroy(yl_ctx* c) {
   hipFree(c->ws_nms_gkeys);
   for (auto& L : c->layers) {
     hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b);
-    hipFree(L.w2p); hipFree(L.b2); hipFree(L.w3p); hipFree(L.b3);
+    hipFree(L.w2p); hipFree(L.b2); hipFree(L.w3p); hipFree(L.b3); hipFree(L.wino);
   }
   delete c;
 }
@@ -1024,6 +1056,12 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       pack_conv(l.w, l.cout, l.cin, l.k, wp);
       bias.assign((size_t)cdiv(l.cout, 16) * 16 + 128, 0.0f);
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
+      if (l.k == 3 && l.stride == 1 && l.dw_k == 0 && l.c2 == 0 && l.pad_t == 1 && l.pad_l == 1 && l.in_shift == 0 &&
+          l.cin >= 64 && l.cout >= 64 && (l.cout & 3) == 0 && l.head_level < 0 && l.res_slot < 0 && l.up_slot < 0) {
+        std::vector<float> wn;
+        pack_wino(l.w, l.cout, l.cin, wn);
+        if ((s = upload(c, wn, &L.wino)) != YL_OK) return s;
+      }
       if (l.c2 > 0) {       // expansion conv of a fused inverted-residual block: [cin][c2][1][1]
         std::vector<float> w2, b2v((size_t)cdiv(l.cin, 16) * 16, 0.0f);
         pack_conv(l.w2, l.cin, l.c2, 1, w2);
@@ -1079,6 +1117,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!strcmp(name, "hybrid")) { c->opt_hybrid = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "batch_levels")) { c->opt_batch_levels = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "fuse_decode")) { c->opt_fuse_decode = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "winograd")) { c->opt_winograd = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "lanes")) { c->opt_lanes = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }

@@ -40,6 +40,7 @@
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
 #define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
+#define yl_launch_conv_wino yl_launch_conv_wino_bf16
 #define yl_launch_conv_dwk yl_launch_conv_dwk_bf16
 #define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
 #endif
@@ -1253,6 +1254,11 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
     // (also the head-output layers of all levels in one launch when their decode runs in the epilogue)
     const hipError_t ep = yl_launch_conv_pwt_multi(ps, n, st);
     if (ep != hipErrorNotSupported) return ep;
+  }
+  // Winograd F(2x2,3x3) (option "winograd": the layer then carries p.wino)
+  if (n == 1 && p.wino && tile_hint != 6) {
+    const hipError_t ew = yl_launch_conv_wino(p, st);
+    if (ew != hipErrorNotSupported) return ew;
   }
   // dense k x k with a weight image beyond LDS: double-buffered weight stream (yl_convc.hip); tile_hint 6 = off
   if (n == 1 && p.dw_k == 0 && p.k > 1 && tile_hint != 6) {

@@ -35,6 +35,8 @@
 #define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
 #define yl_conv_dwk_kernel yl_conv_dwk_kernel_bf16
 #define yl_launch_conv_dwk yl_launch_conv_dwk_bf16
+#define yl_conv_wino_kernel yl_conv_wino_kernel_bf16
+#define yl_launch_conv_wino yl_launch_conv_wino_bf16
 #define yl_conv_kxk_kernel yl_conv_kxk_kernel_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #endif
@@ -1264,6 +1266,171 @@ hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense 3x3 stride-1 convolution as Winograd F(2x2,3x3): Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A -- 16 multiplications
+// per 2x2 output tile and channel pair instead of 36 (2.25x fewer MFMAs; option "winograd", off by default: the
+// transforms round differently from the direct convolution, so the result is not bit-identical to it).
+// One wave owns 16 Winograd tiles (lane pl = tile, 4 channels 4kq..4kq+3 of a 16-channel block) and 2 n-tiles, and
+// holds ALL 16 transform positions' accumulators (16 x 2 x 4 = 128 VGPRs), so the loop is channel-block outer:
+//   per k-block:  4x4 input patch of the lane's tile (16 float4 from L1/L2, zero buffer outside the image)
+//                 column transform in place (16 float4 ops), then per position xi one row-transform op -> B operand,
+//                 two A fragments of U_xi from the LDS chunk, 8 MFMAs
+// The U image ([n-group][k-block][xi][2][64][4], pack_wino in yl_api.hip) streams through LDS in 32 KiB chunks,
+// double-buffered, one barrier per k-block, 8 waves (128 tiles = 512 output pixels) share a chunk; (n-group, m-tile)
+// items group-major in XCD bands like yl_conv_kxk_kernel.  Output transform, bias, ReLU-family clamp and the four
+// NHWC float4 stores per n-tile in the epilogue (ReLU-family clamp or SiLU).
+__global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
+  constexpr int NW = 8, NT = 2;
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int KB = p.KB, Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N;
+  const int TW = (OW + 1) >> 1, TH = (OH + 1) >> 1;
+  const int timg = TW * TH;
+  const long T = (long)p.B * timg;                            // Winograd tiles
+  const float* const xin = p.x;
+  const long zdelta = p.zeros - p.x;
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][16][NT][64] float4
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wino);
+  const int G = (p.NTtot + NT - 1) / NT;
+  const int bx = blockIdx.x, gx = gridDim.x;                 // gx % 8 == 0
+  const int per = gx >> 3, slot = bx >> 3;
+  const int tpx = (p.ntiles + 7) >> 3;
+  const int band0 = (bx & 7) * tpx;
+  const int band1 = (band0 + tpx) < p.ntiles ? (band0 + tpx) : p.ntiles;
+  const int bt = band1 > band0 ? band1 - band0 : 0;
+  const int nitems = bt * G;
+  const int nmine = slot < nitems ? (nitems - 1 - slot) / per + 1 : 0;
+  const long total_chunks = (long)nmine * KB;
+  auto load_chunk = [&](int g, int kb, int buf) {
+    for (int i = wave; i < 16 * NT; i += NW)
+      yl_glds16(wg + (((size_t)g * KB + kb) * 16 * NT + i) * 64 + lane, wl + ((size_t)buf * 16 * NT + i) * 64);
+  };
+  if (total_chunks > 0) load_chunk(slot / bt, 0, 0);
+  long gchunk = 0;
+  __syncthreads();
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+
+  for (int wi = 0; wi < nmine; ++wi) {
+    const int item = slot + wi * per;
+    const int g = item / bt;
+    const int mtile = band0 + item - g * bt;
+    long t = ((long)mtile * NW + wave) * 16 + pl;
+    const bool tvalid = t < T;
+    if (!tvalid) t = T - 1;
+    const int b = (int)(t / timg);
+    const int trem = (int)(t - (long)b * timg);
+    const int ty = trem / TW, tx = trem - ty * TW;
+    // patch offsets (floats from p.x; the launcher guarantees the tensor is < 2^31 floats): 16 pixels, rows 2ty-1 ..
+    // 2ty+2, columns 2tx-1 .. 2tx+2; bit e of `inb` clear = outside the image (zero buffer)
+    const int pbase = ((b * H + 2 * ty - 1) * W + 2 * tx - 1) * Cin + 4 * kq;   // patch origin (may lie outside: masked)
+    unsigned inb = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
+        inb |= (iy >= 0 && iy < H && ix >= 0 && ix < W) ? (1u << (r * 4 + q)) : 0u;
+      }
+    auto load_row = [&](int kb, int r, f32x4 (&dst)[16]) {
+      const bool tail = kb * 16 + 4 * kq >= Cin;                  // channel tail of the last block: zeros
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = r * 4 + q;
+        const int off = pbase + (r * W + q) * Cin + kb * 16;      // (r * W + q) * Cin + kb * 16: wave-uniform
+        dst[e] = yl_ld4((((inb >> e) & 1u) && !tail) ? xin + off : xin + zdelta);
+      }
+    };
+    f32x4 acc[16][1][NT];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[xi][0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < KB; ++kb, ++gchunk) {
+      const int buf = (int)(gchunk & 1);
+      if (gchunk + 1 < total_chunks) {
+        if (kb + 1 < KB) load_chunk(g, kb + 1, buf ^ 1);
+        else load_chunk((item + per) / bt, 0, buf ^ 1);
+      }
+      f32x4 d[16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) load_row(kb, r, d);
+      // column transform B^T d (rows of B^T: d0-d2, d1+d2, d2-d1, d1-d3), in place per column
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 d0 = d[q], d1 = d[4 + q], d2 = d[8 + q], d3 = d[12 + q];
+        d[q] = d0 - d2; d[4 + q] = d1 + d2; d[8 + q] = d2 - d1; d[12 + q] = d1 - d3;
+      }
+      const f32x4* wb = wl + (size_t)buf * 16 * NT * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 t0 = d[i * 4], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 xq[1];
+          xq[0] = j == 0 ? t0 - t2 : j == 1 ? t1 + t2 : j == 2 ? t2 - t1 : t1 - t3;
+          f32x4 wq[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) wq[nt] = wb[((i * 4 + j) * NT + nt) * 64];
+          yl_mma_step<NT, 1>(wq, xq, acc[i * 4 + j]);
+        }
+      }
+      __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
+    }
+    // output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), bias, clamp, store the 2x2 pixels
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = (g * NT + nt) * 16 + 4 * kq;
+      f32x4 r0[4], r1[4];                                         // A^T M : two rows x four columns
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r0[j] = acc[j][0][nt] + acc[4 + j][0][nt] + acc[8 + j][0][nt];
+        r1[j] = acc[4 + j][0][nt] - acc[8 + j][0][nt] - acc[12 + j][0][nt];
+      }
+      f32x4 y[2][2];
+      y[0][0] = r0[0] + r0[1] + r0[2]; y[0][1] = r0[1] - r0[2] - r0[3];
+      y[1][0] = r1[0] + r1[1] + r1[2]; y[1][1] = r1[1] - r1[2] - r1[3];
+      if (tvalid && n < N) {
+        const f32x4 bias = yl_ld4(p.bias + n);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const int oy = 2 * ty + a, ox = 2 * tx + c2;
+            if (oy < OH && ox < OW)
+              *reinterpret_cast<f32x4*>(p.out + (((size_t)b * OH + oy) * OW + ox) * N + n) = yl_actc(y[a][c2] + bias, p.act, lo, hi);
+          }
+      }
+    }
+  }
+}
+
+static hipError_t wino_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  YlConvP p = p0;
+  const long T = (long)p.B * ((p.OH + 1) >> 1) * ((p.OW + 1) >> 1);
+  p.ntiles = (int)((T + 127) / 128);
+  const size_t lds = (size_t)2 * 16 * 2 * 1024;
+  const int res = yl_resident_blocks_n(yl_conv_wino_kernel, 512, lds);
+  const int G = (p.NTtot + 1) / 2;
+  int gx = res & ~7;
+  while (gx > 8 && gx - 8 >= p.ntiles * G) gx -= 8;
+  hipLaunchKernelGGL(yl_conv_wino_kernel, dim3(gx), dim3(512), lds, st, p);
+  return hipGetLastError();
+}
+
+// dense 3x3 stride-1 pad-1 layers that carry a Winograd image (yl_api.hip builds it for >= 64 channels, plain
+// ReLU-family epilogue; layer_params hands it over only under option "winograd").
+hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st) {
+  if (!p.wino || p.k != 3 || p.stride != 1 || p.dw_k > 0 || p.res || p.up || p.dec_boxes || p.C1 > 0 || (p.N & 3) ||
+      p.in_shift || (size_t)p.B * p.H * p.W * p.Cin >= ((size_t)1 << 31))
+    return hipErrorNotSupported;
+  return wino_go(p, st, false);
+}
+
+// ------------------------------------------------------------------------------------------------
 namespace {
 
 template <typename K>
@@ -1326,6 +1493,7 @@ hipError_t yl_convc_init() {
   if (e == hipSuccess) e = kxk_go<4, 1, 8>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<4, 2, 4>(q, 1, nullptr, true);
   if (e == hipSuccess) e = dwt_any(m, 0, nullptr, false, false, true);
+  if (e == hipSuccess) e = wino_go(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<7, 1, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<7, 3, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<8, 1, 4>(q, nullptr, true);

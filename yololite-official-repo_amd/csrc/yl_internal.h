@@ -102,6 +102,9 @@ struct YlConvP {
   // level-batched launches (YlConvMulti): this problem owns blocks [blk0, blk0 + nblk) of grid.x; nblk == 0
   // means the whole grid (single-problem launch)
   int blk0, nblk;
+  // Winograd F(2x2,3x3) image of a dense 3x3 stride-1 conv (yl_conv_wino_kernel, option "winograd"), or nullptr:
+  // U = G g G^T per (cout, cin), packed [n-group of 32 couts][k-block][xi 0..15][2 n-tiles][64 lanes][4]
+  const float* wino;
 };
 
 // Up to 4 independent convolutions of identical kernel configuration in ONE launch (the FPN smooth blocks,
@@ -155,6 +158,9 @@ hipError_t yl_launch_conv_dwt_bf16(YlConvMulti& m, hipStream_t st);
 // streamed-weight depthwise 3x3 -> 1x1 kernel for K >= 192 and more than 8 n-tiles (yl_convc.hip)
 hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_dwk_bf16(const YlConvP& p, hipStream_t st);
+// Winograd F(2x2,3x3) dense 3x3 (yl_convc.hip); hipErrorNotSupported = not this layer
+hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv_wino_bf16(const YlConvP& p, hipStream_t st);
 hipError_t yl_convc_init();
 hipError_t yl_convc_init_bf16();
 // bf16-MFMA builds of yl_conv.hip / yl_stemblock.hip (compiled a second time with -DYL_BF16=1, see yl_dev.h)
