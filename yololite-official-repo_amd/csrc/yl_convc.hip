@@ -1306,7 +1306,21 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
     for (int i = wave; i < 16 * NT; i += NW)
       yl_glds16(wg + (((size_t)g * KB + kb) * 16 * NT + i) * 64 + lane, wl + ((size_t)buf * 16 * NT + i) * 64);
   };
-  if (total_chunks > 0) load_chunk(slot / bt, 0, 0);
+  // item -> (n-group g, m-tile): n-groups in blocks of GBS, inside a block m-tile-major with the GBS groups innermost,
+  // so the workgroups of an XCD (consecutive items) read the SAME 128-tile input window for GBS n-groups at a time
+  // and stream only GBS / G of the U image: both stay in the XCD's 4 MB L2 (group-major order re-read the input
+  // from HBM / Infinity Cache once per n-group: 11 x 269 MB per launch at 80x80)
+  constexpr int GBS = 4;
+  const int nbf = G / GBS;
+  auto item_g = [&](int item, int& mt) {
+    int gb = item / (bt * GBS), cnt = GBS;
+    if (gb >= nbf) { gb = nbf; cnt = G - nbf * GBS; }
+    const int rem = item - gb * bt * GBS;
+    mt = rem / cnt;
+    return gb * GBS + (rem - mt * cnt);
+  };
+  int mt0 = 0;
+  if (total_chunks > 0) load_chunk(item_g(slot, mt0), 0, 0);
   long gchunk = 0;
   __syncthreads();
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
@@ -1314,8 +1328,9 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
 
   for (int wi = 0; wi < nmine; ++wi) {
     const int item = slot + wi * per;
-    const int g = item / bt;
-    const int mtile = band0 + item - g * bt;
+    int mtl = 0;
+    const int g = item_g(item, mtl);
+    const int mtile = band0 + mtl;
     long t = ((long)mtile * NW + wave) * 16 + pl;
     const bool tvalid = t < T;
     if (!tvalid) t = T - 1;
@@ -1351,7 +1366,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
       const int buf = (int)(gchunk & 1);
       if (gchunk + 1 < total_chunks) {
         if (kb + 1 < KB) load_chunk(g, kb + 1, buf ^ 1);
-        else load_chunk((item + per) / bt, 0, buf ^ 1);
+        else { int mtn = 0; load_chunk(item_g(item + per, mtn), 0, buf ^ 1); }
       }
       f32x4 d[16];
 #pragma unroll
