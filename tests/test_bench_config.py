@@ -161,6 +161,23 @@ def test_full_size_configs_3_and_4(name, seg):
         _assert_north_star(_rows(d1, c1, cand[i]), exp, i)
     got_s = _score_tensor([t[cand].cpu() for t in la])
     assert float((got_s - _score_tensor(det_lv)).abs().max()) <= 1e-4
+    # option "winograd" (dense 3x3 stride-1 convs with >= 64 channels as Winograd F(2x2,3x3): yololite_m's six FPN
+    # convs, the seg prototype branch): another rounding of the same sums, held to the SAME north_star bounds at
+    # full size -- all candidate scores within 1e-4 of the oracle, sampled detections equal after rounding
+    ctx.set_option("winograd", 1)
+    ctx.set_option("graph", 1); ctx.set_option("streams", 2)
+    w = model(x)
+    lw = w[0] if seg else w
+    if seg:                                                        # edge_m: only the prototype branch has eligible convs
+        assert not torch.equal(a[1], w[1]) and float((a[1] - w[1]).abs().max()) <= 1e-4
+    else:
+        assert any(not torch.equal(u, v) for u, v in zip(la, lw))  # the option really selects the other kernel
+    assert float((_score_tensor([t[cand].cpu() for t in lw]) - _score_tensor(det_lv)).abs().max()) <= 1e-4
+    dw_, cw_ = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
+    selw = _safe_images(_score_tensor(det_lv), None, 0.4, range(len(cand)), need=2)
+    for i in selw:
+        _assert_north_star(_rows(dw_, cw_, cand[i]), exp, i)
+    ctx.set_option("winograd", 0)
     if seg:
         # config 4: image-resolution masks (640 x 640 input grid, no back-map) of the sampled images vs the oracle's
         # restatement on the ORACLE's own levels / prototypes, mask IoU >= 0.999 (north_star); packed == unpacked
