@@ -269,7 +269,7 @@ def bench_tracker(args):
     print(json.dumps(out))
 
 
-def kernel_family(L):
+def kernel_family(L, winograd=False):
     """Kernel the dispatcher (yl_launch_conv_multi, yl_conv.hip / yl_convc.hip) picks for a fused layer of the program:
     a label for the roofline object, the rocprofv3 summaries under profiles/ carry the exact instantiation."""
     if L.op == 3:
@@ -277,6 +277,9 @@ def kernel_family(L):
     if L.op != 1:
         return "yl_stem_mfma_kernel" if L.op == 0 else "yl_dw_kernel"
     nt, kb = -(-L.cout // 16), -(-L.cin // 16)
+    if (winograd and L.dw_k == 0 and L.k == 3 and L.stride == 1 and L.cin >= 64 and L.cout >= 64 and L.cout % 4 == 0
+            and L.res_slot < 0 and L.up_slot < 0 and L.head_level < 0):
+        return "yl_conv_wino_kernel (Winograd F(2x2,3x3): TFLOP/s counts the direct convolution's MACs)"
     if L.dw_k == 0:
         if L.k == 1:
             return "yl_conv_pwt_kernel"
@@ -476,7 +479,7 @@ def main():
                                           "factors from profiles/r02_fetch_calibration.json (independent known-byte-count kernels)")
         except (OSError, KeyError, ValueError, StopIteration):
             pass
-        roof["kernel"] = f"layer {k} {L.name} ({kernel_family(L)}, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})"
+        roof["kernel"] = f"layer {k} {L.name} ({kernel_family(L, bool(args.winograd))}, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})"
         roof["avg_launch_ms"] = round(float(lay[k]), 4)
         roof["algorithmic_flops_per_launch"] = flops
         roof["algorithmic_bytes_per_launch"] = byts
@@ -489,6 +492,7 @@ def main():
             "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 operands / f32 accumulate and storage (reduced-precision mode, not the headline)" if args.bf16 else "f32",
+            "options": {"winograd": int(args.winograd)},
             "data": "synthetic",
             "config": {"workload": f"{args.model} {'detector+instance-seg head' if args.seg else 'detector'} 640x640 C=80 batch={B}/GPU, forward+decode+per-class NMS{'+masks' if args.seg else ''} "
                                    f"(conf {args.conf}, iou {args.iou}), input resident in HBM"

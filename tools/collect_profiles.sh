@@ -16,6 +16,9 @@ for N in yololite_m edge_m_seg; do
   cp $S/layers_$N.txt $D/${TAG}_layer_table_${N}_b32.txt
   cp $S/bench_$N.json $D/${TAG}_bench_${N}_b32.json
 done
+cp $S/bench_yololite_m_winograd.json $D/${TAG}_bench_yololite_m_b32_winograd.json
+cp $S/layers_yololite_m_winograd.txt $D/${TAG}_layer_table_yololite_m_b32_winograd.txt
+cp $S/bench_edge_m_seg_winograd.json $D/${TAG}_bench_edge_m_seg_b32_winograd.json
 cp $S/bench_eval.json $D/${TAG}_bench_eval.json
 cp $S/bench_track.json $D/${TAG}_bench_track.json
 cp $S/calib/fetch_calibration.json $D/${TAG}_fetch_calibration.json

@@ -31,6 +31,9 @@ python bench.py --steps 30 --warmup 5 --layers > $OUT/bench.json 2> $OUT/layers.
 python bench.py --steps 30 --warmup 5 --stress 1 --no-cpu-baseline > $OUT/bench_stress.json 2> /dev/null
 python bench.py --model yololite_m --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --layers > $OUT/bench_yololite_m.json 2> $OUT/layers_yololite_m.txt
 python bench.py --model edge_m --seg 1 --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --layers > $OUT/bench_edge_m_seg.json 2> $OUT/layers_edge_m_seg.txt
+# option "winograd" (not the parity default): same configs, dense 3x3 stride-1 convs as Winograd F(2x2,3x3)
+python bench.py --model yololite_m --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --winograd 1 --layers > $OUT/bench_yololite_m_winograd.json 2> $OUT/layers_yololite_m_winograd.txt
+python bench.py --model edge_m --seg 1 --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --winograd 1 > $OUT/bench_edge_m_seg_winograd.json 2> /dev/null
 python bench.py --workload eval > $OUT/bench_eval.json 2> /dev/null
 python bench.py --workload track > $OUT/bench_track.json 2> /dev/null
 {
