@@ -1379,27 +1379,24 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
       }
       const f32x4* wb = wl + (size_t)buf * 16 * NT * 64 + lane;
       // A fragments of position xi + 1 are requested before the MFMAs of position xi (explicit double buffer, order
-      // pinned with sched_group_barrier: left alone the compiler issued the two ds_read_b128 right in front of the
-      // MFMAs that need them and every position waited out an LDS round trip)
+      // pinned with sched_barrier: left alone the compiler issued the two ds_read_b128 right in front of the MFMAs
+      // that need them and every position waited out an LDS round trip)
       f32x4 wq[2][NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wq[0][nt] = wb[nt * 64];
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) {
         const int i = xi >> 2, j = xi & 3;
+        const f32x4 t0 = d[i * 4], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
+        f32x4 xq[1];
+        xq[0] = j == 0 ? t0 - t2 : j == 1 ? t1 + t2 : j == 2 ? t2 - t1 : t1 - t3;
         if (xi + 1 < 16) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) wq[(xi + 1) & 1][nt] = wb[((xi + 1) * NT + nt) * 64];
         }
-        const f32x4 t0 = d[i * 4], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
-        f32x4 xq[1];
-        xq[0] = j == 0 ? t0 - t2 : j == 1 ? t1 + t2 : j == 2 ? t2 - t1 : t1 - t3;
+        __builtin_amdgcn_sched_barrier(0);                         // reads of position xi + 1 stay above ...
         yl_mma_step<NT, 1>(wq[xi & 1], xq, acc[xi]);
-#if !(defined(YL_BF16) && YL_BF16)
-        if (xi + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);    // DS reads of position xi + 1
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                      // the row-transform VALU ops
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                 // MFMAs of position xi
-#endif
+        __builtin_amdgcn_sched_barrier(0);                         // ... the MFMAs of position xi
       }
       __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
     }
