@@ -279,7 +279,7 @@ def kernel_family(L, winograd=False):
     nt, kb = -(-L.cout // 16), -(-L.cin // 16)
     if (winograd and L.dw_k == 0 and L.k == 3 and L.stride == 1 and L.cin >= 64 and L.cout >= 64 and L.cout % 4 == 0
             and L.res_slot < 0 and L.up_slot < 0 and L.head_level < 0):
-        return "yl_conv_wino_kernel (Winograd F(2x2,3x3): TFLOP/s counts the direct convolution's MACs)"
+        return "yl_conv_wino_kernel"
     if L.dw_k == 0:
         if L.k == 1:
             return "yl_conv_pwt_kernel"
@@ -444,6 +444,10 @@ def main():
         k = int(np.argmax(lay))
         L = prog.layers[k]
         flops = 2.0 * L.macs * B
+        wino = "yl_conv_wino_kernel" in kernel_family(L, bool(args.winograd))
+        flops_direct = flops
+        if wino:                      # Winograd F(2x2,3x3) executes 16 multiplications where the direct conv has 36
+            flops = flops * 16.0 / 36.0
         byts = float(L.bytes_in + L.bytes_out) * B
         ai = flops / byts
         dur = lay[k] * 1e-3
@@ -480,6 +484,8 @@ def main():
         except (OSError, KeyError, ValueError, StopIteration):
             pass
         roof["kernel"] = f"layer {k} {L.name} ({kernel_family(L, bool(args.winograd))}, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})"
+        if wino:
+            roof["direct_conv_equivalent_tflops"] = round(flops_direct / dur / 1e12, 3)
         roof["avg_launch_ms"] = round(float(lay[k]), 4)
         roof["algorithmic_flops_per_launch"] = flops
         roof["algorithmic_bytes_per_launch"] = byts
