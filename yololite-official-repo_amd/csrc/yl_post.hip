@@ -922,13 +922,22 @@ hipError_t yl_launch_masks(const YlLevels& lv, int B, const float* proto, int PH
 // detection, sigmoid(mc . proto) on the prototype grid, bilinear (align_corners = false, edge-replicating like
 // F.interpolate) sampling at the centre of every pixel of the ORIGINAL image mapped through the letterbox, crop to the
 // detection's box, threshold -- one pass, no intermediate full-resolution probability map.
-// Work split: a workgroup owns a 64 x 4 pixel tile of one image's output grid for ALL detections of that image.
-// The prototype vectors the tile can touch (its bilinear footprint, a few dozen prototype pixels) are staged in LDS
-// once; per detection that intersects the tile the workgroup evaluates the probabilities on that footprint (one
-// prototype pixel per thread: NM MACs + one sigmoid), then every thread interpolates its pixel from 4 LDS values.
-// Detections that miss the tile cost a zero store.  Output: uint8 per pixel, or bit-packed rows (32 pixels per
-// uint32, LSB = leftmost) -- 1/8 of the bytes, the form the benchmark uses.
-#define YL_MI_MAXPATCH 160
+//
+// The kernel is bound by the WRITE of the mask tensor (640 x 640 bit-packed: 51 KB per detection, ~330 detections per
+// image), so the work is detection-major and every store is part of a contiguous run:
+//   * work item = (detection, row part) -- `parts` = 1 unless the batch is small; block g of image b walks the items
+//     g, g + gridDim.x, ...;
+//   * the rows of the item above and below the box are ONE contiguous byte range each and are zero-filled straight
+//     from registers with 16-byte stores;
+//   * the rows that intersect the box are produced in tiles of <= 8 KB (whole rows; a row wider than 8 KB is cut into
+//     column segments): the tile is zeroed in LDS at the SAME 16-byte phase as its global address, the probabilities
+//     of the tile's prototype footprint (a few dozen prototype pixels: NM MACs + one sigmoid each, one per thread) go to
+//     LDS, every half-wave takes one (row, 32-pixel word) unit -- a lane interpolates its pixel from 4 LDS values,
+//     `__ballot` packs the word -- and the finished tile leaves with 16-byte stores.
+// Round 2's kernel was tile-major (a workgroup owned 64 x 4 pixels and looped over every detection): 4-byte words at
+// a 51 KB stride, 3.8x write amplification, 3.1 ms per B = 32 launch.  The per-pixel arithmetic is unchanged.
+#define YL_MI_TILE 8192          // bytes of one output tile staged in LDS
+#define YL_MI_PCAP 4096          // probabilities of a tile's prototype footprint held in LDS
 struct YlMaskImgP {
   const float* proto; int PH, PW, NM;          // [B][PH][PW][NM]
   int S;                                        // network input size
@@ -937,98 +946,178 @@ struct YlMaskImgP {
   const int* out_hw;                            // [B][2] output height, width
   const long long* mask_off;                    // [B] byte offset of image b's masks
   unsigned char* masks; float thr; int packed;
+  int parts;                                    // row parts per detection (work items per detection)
 };
+
+__device__ __forceinline__ float yl_rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// zero `len` bytes at g with the whole workgroup: bytes up to the first 16-byte boundary, 16-byte stores, tail bytes
+__device__ __forceinline__ void yl_mi_zero(unsigned char* g, size_t len, int tid) {
+  const size_t head = min((size_t)((16u - (unsigned)((uintptr_t)g & 15u)) & 15u), len);
+  if ((size_t)tid < head) g[tid] = 0;
+  const size_t body = (len - head) >> 4;
+  uint4* gb = reinterpret_cast<uint4*>(g + head);
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = tid; i < body; i += 256) gb[i] = z;
+  const size_t tail = len - head - (body << 4);
+  if ((size_t)tid < tail) g[head + (body << 4) + tid] = 0;
+}
 
 __global__ __launch_bounds__(256) void yl_masks_image_kernel(YlLevels lv, YlMaskImgP p) {
 #pragma clang fp contract(off)
-  extern __shared__ __attribute__((aligned(16))) float mi_lds[];
-  const int b = blockIdx.z;
+  extern __shared__ __attribute__((aligned(16))) unsigned char mi_smem[];
+  float* coef = reinterpret_cast<float*>(mi_smem);                               // [64]
+  float* pbuf = coef + 64;                                                       // [YL_MI_PCAP]
+  unsigned char* tile = reinterpret_cast<unsigned char*>(pbuf + YL_MI_PCAP);     // [YL_MI_TILE + 32]
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int H = p.out_hw[2 * b], W = p.out_hw[2 * b + 1];
-  const int x0t = blockIdx.x * 64, y0t = blockIdx.y * 4;
-  if (x0t >= W || y0t >= H) return;
-  const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
-  const int x = x0t + lane, y = y0t + row;
-  const int NM = p.NM;
+  const int n = min(p.counts[b], p.max_out);
+  if (n <= 0 || H <= 0 || W <= 0) return;
+  const int NM = p.NM, PW = p.PW, PH = p.PH;
   float sx = 1.0f, padx = 0.0f, pady = 0.0f;
   if (p.backmap) { padx = p.backmap[5 * b]; pady = p.backmap[5 * b + 1]; sx = p.backmap[5 * b + 2]; }
-  const float kx = (float)p.PW / (float)p.S, ky = (float)p.PH / (float)p.S;
+  const float kx = (float)PW / (float)p.S, ky = (float)PH / (float)p.S;
   // prototype-grid coordinate of a pixel centre: letterbox coordinate (c + 0.5) * scale + pad, then the
-  // align_corners = false source index of a PW/S resize, clamped at 0 (F.interpolate)
-  auto src_u = [&](int c, float pad, float k) { return fmaxf(((float)c + 0.5f) * sx + pad, 0.0f) * k - 0.5f; };
-  const int xl = min(x0t + 63, W - 1), yl_ = min(y0t + 3, H - 1);
-  const int pu0 = max(min((int)floorf(fmaxf(src_u(x0t, padx, kx), 0.0f)), p.PW - 1), 0);
-  const int pv0 = max(min((int)floorf(fmaxf(src_u(y0t, pady, ky), 0.0f)), p.PH - 1), 0);
-  const int pu1 = min(min((int)floorf(fmaxf(src_u(xl, padx, kx), 0.0f)), p.PW - 1) + 1, p.PW - 1);
-  const int pv1 = min(min((int)floorf(fmaxf(src_u(yl_, pady, ky), 0.0f)), p.PH - 1) + 1, p.PH - 1);
-  const int pw = pu1 - pu0 + 1, ph = pv1 - pv0 + 1, np = pw * ph;
-  const bool staged = np <= YL_MI_MAXPATCH;               // else (extreme up-scaling): prototypes straight from memory
-  float* coef = mi_lds;                                   // [64]
-  float* pbuf = mi_lds + 64;                              // [YL_MI_MAXPATCH] probabilities of the footprint
-  float* patch = pbuf + YL_MI_MAXPATCH;                   // [np][NM]
-  const float* pimg = p.proto + (size_t)b * p.PH * p.PW * NM;
-  if (staged) {
-    for (int i = tid; i < np * NM; i += 256) {
-      const int q = i / NM, k = i - q * NM;
-      const int v = pv0 + q / pw, u = pu0 + q % pw;
-      patch[i] = pimg[((size_t)v * p.PW + u) * NM + k];
-    }
-  }
-  // this pixel's bilinear taps
-  const bool live = x < W && y < H;
-  const float fu_ = fmaxf(src_u(x, padx, kx), 0.0f), fv_ = fmaxf(src_u(y, pady, ky), 0.0f);
-  const int u0 = min((int)floorf(fu_), p.PW - 1), v0 = min((int)floorf(fv_), p.PH - 1);
-  const int u1 = min(u0 + 1, p.PW - 1), v1 = min(v0 + 1, p.PH - 1);
-  const float lu = fu_ - (float)u0, lv_ = fv_ - (float)v0;
-  const int n = min(p.counts[b], p.max_out);
+  // align_corners = false source index of a PW/S resize, clamped at 0 (F.interpolate); i0 / i1 = the two taps
+  auto taps = [&](int c, float pad, float k, int lim, int& i0, int& i1, float& w) {
+    const float f = fmaxf(fmaxf(((float)c + 0.5f) * sx + pad, 0.0f) * k - 0.5f, 0.0f);
+    i0 = min((int)floorf(f), lim - 1);
+    i1 = min(i0 + 1, lim - 1);
+    w = f - (float)i0;
+  };
+  const int wrow = p.packed ? ((W + 31) >> 5) << 2 : W;                          // bytes per mask row
+  const int nsegs = (wrow + YL_MI_TILE - 1) / YL_MI_TILE;                        // column segments of a row (1 unless huge)
+  const int RB = nsegs > 1 ? 1 : max(1, YL_MI_TILE / wrow);                      // rows per tile
   unsigned char* mb = p.masks + p.mask_off[b];
-  const size_t wrow = p.packed ? (size_t)((W + 31) >> 5) * 4 : (size_t)W;      // bytes per mask row
-  for (int d = 0; d < n; ++d) {
+  const float* pimg = p.proto + (size_t)b * PH * PW * NM;
+  const int items = n * p.parts;
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int d = it / p.parts, part = it - d * p.parts;
+    const int R0 = (int)((long long)H * part / p.parts), R1 = (int)((long long)H * (part + 1) / p.parts);   // rows [R0, R1)
+    if (R0 >= R1) continue;
     const float* dr = p.dets + ((size_t)b * p.max_out + d) * 6;
-    const float x1 = dr[0], y1 = dr[1], x2 = dr[2], y2 = dr[3];
-    // tile / box intersection (same predicate as the per-pixel test below)
-    const bool hit = (float)min(x0t + 63, W - 1) >= x1 && (float)x0t < x2 && (float)min(y0t + 3, H - 1) >= y1 && (float)y0t < y2;
-    bool on = false;
-    if (hit) {                                            // workgroup-uniform
-      __syncthreads();                                    // previous detection's pbuf / coef reads are done
-      if (tid < NM) {
-        const int cand = p.keep_idx[(size_t)b * p.max_out + d];
-        const int l = yl_level_of(lv, cand);
-        const int nl = lv.A[l] * lv.S[l] * lv.S[l];
-        coef[tid] = lv.ptr[l][((size_t)b * nl + (cand - lv.off[l])) * lv.E + 5 + lv.C + tid];
-      }
-      __syncthreads();
-      if (staged) {
-        if (tid < np) {
-          float acc = 0.0f;
-          for (int k = 0; k < NM; ++k) acc = fmaf(coef[k], patch[tid * NM + k], acc);
-          pbuf[tid] = yl_sigmoid(acc);
-        }
-        __syncthreads();
-      }
-      if (live && (float)x >= x1 && (float)x < x2 && (float)y >= y1 && (float)y < y2) {
-        float p00, p01, p10, p11;
-        if (staged) {
-          p00 = pbuf[(v0 - pv0) * pw + (u0 - pu0)]; p01 = pbuf[(v0 - pv0) * pw + (u1 - pu0)];
-          p10 = pbuf[(v1 - pv0) * pw + (u0 - pu0)]; p11 = pbuf[(v1 - pv0) * pw + (u1 - pu0)];
-        } else {
-          auto prob = [&](int v, int u) {
-            const float* q = pimg + ((size_t)v * p.PW + u) * NM;
-            float acc = 0.0f;
-            for (int k = 0; k < NM; ++k) acc = fmaf(coef[k], q[k], acc);
-            return yl_sigmoid(acc);
-          };
-          p00 = prob(v0, u0); p01 = prob(v0, u1); p10 = prob(v1, u0); p11 = prob(v1, u1);
-        }
-        const float top = p00 + (p01 - p00) * lu, bot = p10 + (p11 - p10) * lu;
-        on = (top + (bot - top) * lv_) > p.thr;
-      }
+    const float x1 = yl_rfl(dr[0]), y1 = yl_rfl(dr[1]), x2 = yl_rfl(dr[2]), y2 = yl_rfl(dr[3]);
+    unsigned char* md = mb + (size_t)d * H * wrow;
+    // integer hull of the box (a superset: the per-pixel predicate below decides, so NaN / huge values are harmless)
+    const int xlo = (int)fminf(fmaxf(floorf(x1), 0.0f), (float)W), xhi = (int)fminf(fmaxf(floorf(x2), -1.0f), (float)(W - 1));
+    const int ylo = (int)fminf(fmaxf(floorf(y1), 0.0f), (float)H), yhi = (int)fminf(fmaxf(floorf(y2), -1.0f), (float)(H - 1));
+    const int ya = max(R0, ylo), yb = min(R1 - 1, yhi);
+    if (ya > yb || xlo > xhi) {                                                  // no box pixel in these rows
+      yl_mi_zero(md + (size_t)R0 * wrow, (size_t)(R1 - R0) * wrow, tid);
+      continue;
     }
-    unsigned char* mrow = mb + ((size_t)d * H + y) * wrow;
-    if (p.packed) {
-      const unsigned long long bits = __ballot(on);
-      if (y < H && (lane & 31) == 0 && x < W) *reinterpret_cast<unsigned*>(mrow + (size_t)(x >> 5) * 4) = (unsigned)(bits >> (lane & 32));
-    } else if (live) {
-      mrow[x] = on ? 1 : 0;
+    if (ya > R0) yl_mi_zero(md + (size_t)R0 * wrow, (size_t)(ya - R0) * wrow, tid);
+    if (yb + 1 < R1) yl_mi_zero(md + (size_t)(yb + 1) * wrow, (size_t)(R1 - 1 - yb) * wrow, tid);
+    if (tid < NM) {           // safe: every earlier read of coef[] is followed by a workgroup barrier
+      const int cand = p.keep_idx[(size_t)b * p.max_out + d];
+      const int l = yl_level_of(lv, cand);
+      const int nl = lv.A[l] * lv.S[l] * lv.S[l];
+      coef[tid] = lv.ptr[l][((size_t)b * nl + (cand - lv.off[l])) * lv.E + 5 + lv.C + tid];
+    }
+    for (int seg = 0; seg < nsegs; ++seg) {
+      const int c0 = seg * YL_MI_TILE, c1 = min(c0 + YL_MI_TILE, wrow) - 1;      // bytes [c0, c1] of every row
+      const int px0 = p.packed ? c0 * 8 : c0, px1 = min(p.packed ? c1 * 8 + 7 : c1, W - 1);
+      const int xa = max(px0, xlo), xb = min(px1, xhi);
+      if (xa > xb) {                                                             // only with nsegs > 1
+        for (int r = ya; r <= yb; ++r) yl_mi_zero(md + (size_t)r * wrow + c0, (size_t)(c1 - c0 + 1), tid);
+        continue;
+      }
+      int pu0, pu1, tmp; float tw;
+      taps(xa, padx, kx, PW, pu0, tmp, tw);
+      taps(xb, padx, kx, PW, tmp, pu1, tw);
+      const int pw = pu1 - pu0 + 1;
+      const int w0 = xa >> 5, nw = (xb >> 5) - w0 + 1;                           // 32-pixel words that hold box pixels
+      const float rnw = 1.0f / (float)nw;
+      for (int t0 = ya; t0 <= yb;) {
+        int t1 = min(yb, t0 + RB - 1);
+        int pv0, pv1;
+        taps(t0, pady, ky, PH, pv0, tmp, tw);
+        bool direct = false;
+        for (;;) {                                                               // shrink the row group until its footprint fits
+          taps(t1, pady, ky, PH, tmp, pv1, tw);
+          if ((pv1 - pv0 + 1) * pw <= YL_MI_PCAP) break;
+          if (t1 == t0) { direct = true; break; }
+          t1 = t0 + ((t1 - t0) >> 1);
+        }
+        const int np = (pv1 - pv0 + 1) * pw;
+        unsigned char* g0 = md + (size_t)t0 * wrow + c0;
+        const int len = nsegs > 1 ? (c1 - c0 + 1) : (t1 - t0 + 1) * wrow;
+        const int mis = (int)((uintptr_t)g0 & 15u);
+        __syncthreads();                                  // A: the previous tile has left LDS; coef[] is written
+        for (int i = tid; i < ((mis + len + 15) >> 4); i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (!direct) {
+          const float rpw = 1.0f / (float)pw;
+          for (int t = tid; t < np; t += 256) {
+            int q = (int)((float)t * rpw);
+            int r = t - q * pw;
+            if (r < 0) { --q; r += pw; } else if (r >= pw) { ++q; r -= pw; }
+            const float4* pp = reinterpret_cast<const float4*>(pimg + ((size_t)(pv0 + q) * PW + (pu0 + r)) * NM);
+            float acc = 0.0f;
+            if ((NM & 3) == 0) {
+              for (int k = 0; k < NM; k += 4) {
+                const float4 v = pp[k >> 2];
+                acc = fmaf(coef[k], v.x, acc); acc = fmaf(coef[k + 1], v.y, acc);
+                acc = fmaf(coef[k + 2], v.z, acc); acc = fmaf(coef[k + 3], v.w, acc);
+              }
+            } else {
+              const float* ps = reinterpret_cast<const float*>(pp);
+              for (int k = 0; k < NM; ++k) acc = fmaf(coef[k], ps[k], acc);
+            }
+            pbuf[t] = yl_sigmoid(acc);
+          }
+        }
+        __syncthreads();                                  // B: probabilities + zeroed tile visible
+        const int nunits = (t1 - t0 + 1) * nw;
+        for (int ub = (tid >> 6) * 2; ub < nunits; ub += 8) {                    // wave-uniform: __ballot below
+          const int u = ub + (lane >> 5);
+          const bool valid = u < nunits;
+          int q = (int)((float)u * rnw);
+          int r = u - q * nw;
+          if (r < 0) { --q; r += nw; } else if (r >= nw) { ++q; r -= nw; }
+          const int y = t0 + q, xw = w0 + r, x = (xw << 5) + (lane & 31);
+          bool on = false;
+          if (valid && x <= px1 && (float)x >= x1 && (float)x < x2 && (float)y >= y1 && (float)y < y2) {
+            int u0, u1, v0, v1; float lu, lv_;
+            taps(x, padx, kx, PW, u0, u1, lu);
+            taps(y, pady, ky, PH, v0, v1, lv_);
+            float p00, p01, p10, p11;
+            if (!direct) {
+              const float* r0p = pbuf + (v0 - pv0) * pw - pu0;
+              const float* r1p = pbuf + (v1 - pv0) * pw - pu0;
+              p00 = r0p[u0]; p01 = r0p[u1]; p10 = r1p[u0]; p11 = r1p[u1];
+            } else {                                      // footprint of ONE row beyond the LDS budget (PW > 2048)
+              auto prob = [&](int v, int uu) {
+                const float* qp = pimg + ((size_t)v * PW + uu) * NM;
+                float acc = 0.0f;
+                for (int k = 0; k < NM; ++k) acc = fmaf(coef[k], qp[k], acc);
+                return yl_sigmoid(acc);
+              };
+              p00 = prob(v0, u0); p01 = prob(v0, u1); p10 = prob(v1, u0); p11 = prob(v1, u1);
+            }
+            const float top = p00 + (p01 - p00) * lu, bot = p10 + (p11 - p10) * lu;
+            on = (top + (bot - top) * lv_) > p.thr;
+          }
+          unsigned char* trow = tile + mis + (size_t)(y - t0) * (nsegs > 1 ? 0 : wrow) - c0;
+          if (p.packed) {
+            const unsigned long long bits = __ballot(on);
+            if (valid && (lane & 31) == 0) *reinterpret_cast<unsigned*>(trow + (xw << 2)) = (unsigned)(bits >> (lane & 32));
+          } else if (valid && x <= px1) {
+            trow[x] = on ? 1 : 0;
+          }
+        }
+        __syncthreads();                                  // C: tile complete
+        {
+          const int head = min((16 - mis) & 15, len);
+          if (tid < head) g0[tid] = tile[mis + tid];
+          const int body = (len - head) >> 4;
+          const uint4* src = reinterpret_cast<const uint4*>(tile + mis + head);
+          uint4* gb = reinterpret_cast<uint4*>(g0 + head);
+          for (int i = tid; i < body; i += 256) gb[i] = src[i];
+          const int tail = len - head - (body << 4);
+          if (tid < tail) g0[head + (body << 4) + tid] = tile[mis + head + (body << 4) + tid];
+        }
+        t0 = t1 + 1;
+      }
     }
   }
 }
@@ -1042,9 +1131,20 @@ hipError_t yl_launch_masks_image(const YlLevels& lv, int B, const float* proto, 
   p.proto = proto; p.PH = PH; p.PW = PW; p.NM = NM; p.S = S; p.dets = dets; p.counts = counts; p.keep_idx = keep_idx;
   p.max_out = max_out; p.backmap = backmap; p.out_hw = out_hw; p.mask_off = mask_off; p.masks = masks; p.thr = thr;
   p.packed = packed;
-  const size_t lds = (size_t)(64 + YL_MI_MAXPATCH + YL_MI_MAXPATCH * NM) * sizeof(float);
-  dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, B);
-  hipLaunchKernelGGL(yl_masks_image_kernel, grid, dim3(256), lds, st, lv, p);
+  // small batches: cut every detection's rows into parts so that a handful of detections still spreads over the chip
+  p.parts = B >= 16 ? 1 : min(max(32 / B, 1), min(16, max_h));
+  static int blocks_total = 0;
+  if (!blocks_total) {
+    const char* e = getenv("YL_MI_BLOCKS");
+    blocks_total = e ? atoi(e) : 1536;              // 6 workgroups (25 KB of LDS each) per CU
+    if (blocks_total < 1) blocks_total = 1536;
+  }
+  long long gx = (blocks_total + B - 1) / B;
+  const long long most = (long long)max_out * p.parts;
+  if (gx > most) gx = most;
+  if (gx < 1) gx = 1;
+  const size_t lds = (size_t)(64 + YL_MI_PCAP) * sizeof(float) + YL_MI_TILE + 32;
+  hipLaunchKernelGGL(yl_masks_image_kernel, dim3((unsigned)gx, B), dim3(256), lds, st, lv, p);
   return hipGetLastError();
 }
 
