@@ -374,11 +374,16 @@ def main():
         dets = torch.empty((B, max_out, 6), device=dev, dtype=torch.float32)
         counts = torch.empty((B,), device=dev, dtype=torch.int32)
 
+    mask_arena = (torch.empty((B * max_out * S * ((S + 31) // 32) * 4,), device=dev, dtype=torch.uint8)
+                  if args.seg else None)
+
     def step():
         if args.seg:
             _, _, idx = ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
                                     out=(dets, counts), want_idx=True)
-            ctx.masks_image(dets, counts, idx, packed=True)        # image-resolution (640 x 640) masks, bit-packed rows
+            # image-resolution (640 x 640) masks, bit-packed rows, into a fixed-capacity arena: asynchronous like the
+            # detections themselves (no host read of the counts inside the step)
+            ctx.masks_image(dets, counts, idx, packed=True, arena=mask_arena)
             return dets, counts
         if gat is not None:      # results go straight into the gather slot; its all-gather overlaps the next step
             ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,

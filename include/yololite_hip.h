@@ -273,7 +273,11 @@ yl_status yl_masks(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, c
  *     mask(y,x) = m > thr  and  x1 <= x < x2  and  y1 <= y < y2
  * Output of image b starts at masks_dev + mask_off_dev[b] bytes: [min(counts[b], max_out)][h_b][row] with row = w_b
  * uint8 (packed = 0) or ceil(w_b / 32) uint32 words, bit k of word j = pixel 32 j + k (packed = 1).
- * max_h / max_w: the largest h_b / w_b of the batch (grid size).  The caller sizes masks_dev from the counts. */
+ * max_h / max_w: the largest h_b / w_b of the batch.  The caller sizes masks_dev from the counts, or gives every
+ * image a fixed capacity of max_out masks (mask_off_dev[b] = b * max_out * h * row: no host read of the counts, the
+ * call stays asynchronous).  packed = 1 needs mask_off_dev[b] % 4 == 0; 16-byte aligned offsets give full-width
+ * stores.  Limits: prototype width PW <= 1024 (img_size <= 4096), batch <= 8192 (YL_ERR_HIP / invalid value beyond).
+ * Every byte of the [min(counts[b], max_out)][h_b][row] block of image b is written (zeros outside the boxes). */
 yl_status yl_masks_image(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, const float* dets_dev,
                          const int32_t* counts_dev, const int32_t* keep_idx_dev, int32_t max_out, float thr,
                          const float* backmap_dev, const int32_t* out_hw_dev, const int64_t* mask_off_dev, int32_t max_h,

@@ -923,21 +923,25 @@ hipError_t yl_launch_masks(const YlLevels& lv, int B, const float* proto, int PH
 // F.interpolate) sampling at the centre of every pixel of the ORIGINAL image mapped through the letterbox, crop to the
 // detection's box, threshold -- one pass, no intermediate full-resolution probability map.
 //
-// The kernel is bound by the WRITE of the mask tensor (640 x 640 bit-packed: 51 KB per detection, ~330 detections per
+// The op is bound by the WRITE of the mask tensor (640 x 640 bit-packed: 51 KB per detection, ~330 detections per
 // image), so the work is detection-major and every store is part of a contiguous run:
-//   * work item = (detection, row part) -- `parts` = 1 unless the batch is small; block g of image b walks the items
-//     g, g + gridDim.x, ...;
-//   * the rows of the item above and below the box are ONE contiguous byte range each and are zero-filled straight
-//     from registers with 16-byte stores;
-//   * the rows that intersect the box are produced in tiles of <= 8 KB (whole rows; a row wider than 8 KB is cut into
-//     column segments): the tile is zeroed in LDS at the SAME 16-byte phase as its global address, the probabilities
-//     of the tile's prototype footprint (a few dozen prototype pixels: NM MACs + one sigmoid each, one per thread) go to
-//     LDS, every half-wave takes one (row, 32-pixel word) unit -- a lane interpolates its pixel from 4 LDS values,
-//     `__ballot` packs the word -- and the finished tile leaves with 16-byte stores.
+//   * work item = (image, detection, row part) -- `parts` = 1 unless the batch is small; ONE item list over the whole
+//     batch (prefix of the per-image counts in LDS), workgroup g walks the items g, g + gridDim.x, ...: an image with
+//     many detections is not the launch's tail;
+//   * TWO launches of the same template walk the list.  BOXES = false: the rows of the item above and below the box
+//     are ONE contiguous byte range each and are zero-filled straight from registers with 16-byte stores (16 VGPRs,
+//     detection rows through the scalar cache: the waves never wait for their own stores; 545 MB in ~80 us at B = 32);
+//   * BOXES = true: the rows that intersect the box are produced in tiles of <= 4 KB (whole rows; a row wider than the
+//     tile is cut into column segments): the tile is zeroed in LDS at the SAME 16-byte phase as its global address, the
+//     probabilities of the tile's prototype footprint (a few dozen prototype pixels: NM MACs + one sigmoid each, one
+//     per thread) go to LDS, every half-wave takes one (row, 32-pixel word) unit -- a lane interpolates its pixel from
+//     4 LDS values, `__ballot` packs the word -- and the finished tile leaves with 16-byte stores.
 // Round 2's kernel was tile-major (a workgroup owned 64 x 4 pixels and looped over every detection): 4-byte words at
-// a 51 KB stride, 3.8x write amplification, 3.1 ms per B = 32 launch.  The per-pixel arithmetic is unchanged.
-#define YL_MI_TILE 8192          // bytes of one output tile staged in LDS
-#define YL_MI_PCAP 4096          // probabilities of a tile's prototype footprint held in LDS
+// a 51 KB stride, 3.8x write amplification, 3.1 ms per B = 32 launch; this pair takes 0.21 ms (box rows ~0.125 ms:
+// a latency chain of ~6 us per detection at 5 workgroups per CU; zero fill ~0.08 ms).  The per-pixel arithmetic is
+// unchanged (bitwise equal outputs, tools/masks_ab.py).
+#define YL_MI_PCAP 2048          // probabilities of a tile's prototype footprint held in LDS
+#define YL_MI_ROWS 128           // rows of a tile whose vertical taps are tabulated in LDS
 struct YlMaskImgP {
   const float* proto; int PH, PW, NM;          // [B][PH][PW][NM]
   int S;                                        // network input size
@@ -947,9 +951,18 @@ struct YlMaskImgP {
   const long long* mask_off;                    // [B] byte offset of image b's masks
   unsigned char* masks; float thr; int packed;
   int parts;                                    // row parts per detection (work items per detection)
+  int tile;                                     // bytes of one output tile staged in LDS (multiple of 32)
+  int B;
 };
 
-__device__ __forceinline__ float yl_rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// loads through the constant address space: a wave-uniform address becomes a scalar (SMEM) load
+#define YL_CONST_AS __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const T YL_CONST_AS* yl_as_const(const T* q) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (const T YL_CONST_AS*)q;
+#pragma clang diagnostic pop
+}
 
 // zero `len` bytes at g with the whole workgroup: bytes up to the first 16-byte boundary, 16-byte stores, tail bytes
 __device__ __forceinline__ void yl_mi_zero(unsigned char* g, size_t len, int tid) {
@@ -963,20 +976,79 @@ __device__ __forceinline__ void yl_mi_zero(unsigned char* g, size_t len, int tid
   if ((size_t)tid < tail) g[head + (body << 4) + tid] = 0;
 }
 
-__global__ __launch_bounds__(256) void yl_masks_image_kernel(YlLevels lv, YlMaskImgP p) {
+#ifdef YL_MI_STAMP
+// profiling aid (variant builds only: tools/build_variant.sh mistamp yl_post.hip -DYL_MI_STAMP): 100 MHz wall-clock ticks
+// at the phase boundaries of the first items of ONE box-role and ONE fill-role workgroup
+__device__ unsigned long long yl_mi_stamps[2 * 16 * 12];
+__device__ unsigned long long yl_mi_blk[4096 * 2];        // start / end of every workgroup
+extern "C" int yl_debug_mi_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_mi_stamps), sizeof(yl_mi_stamps));
+}
+extern "C" int yl_debug_mi_blocks(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_mi_blk), sizeof(yl_mi_blk));
+}
+#define YL_MIS(i) do { if (tid == 0 && role_i == 7 && nit < 16) yl_mi_stamps[((BOXES ? 0 : 1) * 16 + nit) * 12 + (i)] = wall_clock64(); } while (0)
+#else
+#define YL_MIS(i) do { } while (0)
+#endif
+template <bool BOXES>
+__global__ __launch_bounds__(256, BOXES ? 5 : 8) void yl_masks_image_kernel(YlLevels lv, YlMaskImgP p) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) unsigned char mi_smem[];
   float* coef = reinterpret_cast<float*>(mi_smem);                               // [64]
   float* pbuf = coef + 64;                                                       // [YL_MI_PCAP]
-  unsigned char* tile = reinterpret_cast<unsigned char*>(pbuf + YL_MI_PCAP);     // [YL_MI_TILE + 32]
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int H = p.out_hw[2 * b], W = p.out_hw[2 * b + 1];
-  const int n = min(p.counts[b], p.max_out);
-  if (n <= 0 || H <= 0 || W <= 0) return;
+  float* rtab = pbuf + YL_MI_PCAP;                                               // [YL_MI_ROWS][4] vertical taps of the tile's rows
+  unsigned char* tile = reinterpret_cast<unsigned char*>(rtab + 4 * YL_MI_ROWS); // [tile + 32]
+  // level table in LDS: indexing the by-value YlLevels dynamically keeps the whole struct in SGPRs (106 SGPRs, 88 of
+  // them spilled into VGPR lanes -> 106 VGPRs -> 4 workgroups per CU instead of 8)
+  const float** lptr = reinterpret_cast<const float**>(tile + p.tile + 32);      // [YL_MAX_LEVELS]
+  int* lnl = reinterpret_cast<int*>(lptr + YL_MAX_LEVELS);                       // [YL_MAX_LEVELS] A * S * S
+  int* loff = lnl + YL_MAX_LEVELS;                                               // [YL_MAX_LEVELS + 1]
+  int* pre = loff + YL_MAX_LEVELS + 1;                                           // [B + 1] first item of every image
+  if (BOXES && threadIdx.x == 0) {
+#pragma unroll
+    for (int l = 0; l < YL_MAX_LEVELS; ++l) {
+      lptr[l] = lv.ptr[l]; lnl[l] = lv.A[l] * lv.S[l] * lv.S[l];
+      loff[l] = l <= lv.L ? lv.off[l] : 0x7fffffff;
+    }
+    loff[YL_MAX_LEVELS] = lv.L == YL_MAX_LEVELS ? lv.off[YL_MAX_LEVELS] : 0x7fffffff;
+    for (int l = lv.L + 1; l <= YL_MAX_LEVELS; ++l) loff[l] = 0x7fffffff;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef YL_MI_STAMP
+  if (tid == 0 && blockIdx.x < 2048) yl_mi_blk[2 * (blockIdx.x + (BOXES ? 2048 : 0))] = wall_clock64();
+#endif
   const int NM = p.NM, PW = p.PW, PH = p.PH;
-  float sx = 1.0f, padx = 0.0f, pady = 0.0f;
-  if (p.backmap) { padx = p.backmap[5 * b]; pady = p.backmap[5 * b + 1]; sx = p.backmap[5 * b + 2]; }
   const float kx = (float)PW / (float)p.S, ky = (float)PH / (float)p.S;
+  // items of every image -> exclusive prefix in LDS (one wave scans it; B is small).  Walking the images one scalar
+  // load chain at a time cost every workgroup ~1.5 us per image (B = 32: 50 us of a 240 us launch)
+  for (int i = tid; i < p.B; i += 256) {
+    const int h = p.out_hw[2 * i], w = p.out_hw[2 * i + 1];
+    pre[i + 1] = (h > 0 && w > 0) ? max(min(p.counts[i], p.max_out), 0) * p.parts : 0;
+  }
+  if (tid == 0) pre[0] = 0;
+  __syncthreads();
+  if (tid < 64) {
+    int carry = 0;
+    for (int c0 = 0; c0 < p.B; c0 += 64) {
+      int v = (c0 + lane < p.B) ? pre[c0 + lane + 1] : 0;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+      }
+      v += carry;
+      if (c0 + lane < p.B) pre[c0 + lane + 1] = v;
+      carry = __shfl(v, 63);
+    }
+  }
+  __syncthreads();
+  const long long total = pre[p.B];
+  // per-image state (workgroup-uniform), refreshed when the item walk enters another image
+  int b = -1, base = 0;                         // image, first global item of image b
+  int H = 0, W = 0, wrow = 0, nsegs = 1, RB = 1;
+  float sx = 1.0f, padx = 0.0f, pady = 0.0f;
+  unsigned char* mb = nullptr;
+  const float* pimg = nullptr;
   // prototype-grid coordinate of a pixel centre: letterbox coordinate (c + 0.5) * scale + pad, then the
   // align_corners = false source index of a PW/S resize, clamped at 0 (F.interpolate); i0 / i1 = the two taps
   auto taps = [&](int c, float pad, float k, int lim, int& i0, int& i1, float& w) {
@@ -985,37 +1057,67 @@ __global__ __launch_bounds__(256) void yl_masks_image_kernel(YlLevels lv, YlMask
     i1 = min(i0 + 1, lim - 1);
     w = f - (float)i0;
   };
-  const int wrow = p.packed ? ((W + 31) >> 5) << 2 : W;                          // bytes per mask row
-  const int nsegs = (wrow + YL_MI_TILE - 1) / YL_MI_TILE;                        // column segments of a row (1 unless huge)
-  const int RB = nsegs > 1 ? 1 : max(1, YL_MI_TILE / wrow);                      // rows per tile
-  unsigned char* mb = p.masks + p.mask_off[b];
-  const float* pimg = p.proto + (size_t)b * PH * PW * NM;
-  const int items = n * p.parts;
-  for (int it = blockIdx.x; it < items; it += gridDim.x) {
-    const int d = it / p.parts, part = it - d * p.parts;
+  // ONE item list over the whole batch (image-major, then detection, then row part), dealt round-robin to the
+  // workgroups.  Why two instantiations instead of one kernel doing both (the first version): the uniform state of
+  // the two paths together needed 106 SGPRs + 88 spilled into VGPR lanes (4 workgroups per CU), and gfx9 counts loads
+  // and stores in ONE in-order counter (vmcnt), so a workgroup's box path (detection row -> candidate index ->
+  // coefficients, prototype footprint -> LDS -> stores) waited for the acknowledgement of its own 51 KB of zero
+  // stores: 0.24-0.26 ms per B = 32 launch.  The two launches write disjoint bytes.
+  constexpr bool boxes = BOXES, fill = !BOXES;
+  const long long role_i = blockIdx.x, role_n = gridDim.x;
+  {
+  int nit = -1;
+  for (long long it = role_i; it < total; it += role_n) {
+    ++nit;
+    YL_MIS(0);
+    if (b < 0 || it >= pre[b + 1]) {            // another image: its geometry through the scalar cache
+      do { ++b; } while (it >= pre[b + 1]);
+      base = pre[b];
+      H = yl_as_const(p.out_hw)[2 * b]; W = yl_as_const(p.out_hw)[2 * b + 1];
+      wrow = p.packed ? ((W + 31) >> 5) << 2 : W;                                // bytes per mask row
+      nsegs = max((wrow + p.tile - 1) / p.tile, 1);                              // column segments of a row (1 unless huge)
+      RB = nsegs > 1 ? 1 : min(max(1, p.tile / max(wrow, 1)), YL_MI_ROWS);       // rows per tile
+      sx = 1.0f; padx = 0.0f; pady = 0.0f;
+      if (p.backmap) {
+        const float YL_CONST_AS* bm = yl_as_const(p.backmap + 5 * b);
+        padx = bm[0]; pady = bm[1]; sx = bm[2];
+      }
+      mb = p.masks + yl_as_const(p.mask_off)[b];
+      pimg = p.proto + (size_t)b * PH * PW * NM;
+    }
+    const int li = (int)(it - base);
+    const int d = li / p.parts, part = li - d * p.parts;
     const int R0 = (int)((long long)H * part / p.parts), R1 = (int)((long long)H * (part + 1) / p.parts);   // rows [R0, R1)
     if (R0 >= R1) continue;
-    const float* dr = p.dets + ((size_t)b * p.max_out + d) * 6;
-    const float x1 = yl_rfl(dr[0]), y1 = yl_rfl(dr[1]), x2 = yl_rfl(dr[2]), y2 = yl_rfl(dr[3]);
+    // the detection row through the SCALAR cache (uniform address): lgkmcnt, not vmcnt, so the fill role never waits
+    // for its own stores
+    const float YL_CONST_AS* dr = yl_as_const(p.dets + ((size_t)b * p.max_out + d) * 6);
+    const float x1 = dr[0], y1 = dr[1], x2 = dr[2], y2 = dr[3];
     unsigned char* md = mb + (size_t)d * H * wrow;
     // integer hull of the box (a superset: the per-pixel predicate below decides, so NaN / huge values are harmless)
     const int xlo = (int)fminf(fmaxf(floorf(x1), 0.0f), (float)W), xhi = (int)fminf(fmaxf(floorf(x2), -1.0f), (float)(W - 1));
     const int ylo = (int)fminf(fmaxf(floorf(y1), 0.0f), (float)H), yhi = (int)fminf(fmaxf(floorf(y2), -1.0f), (float)(H - 1));
     const int ya = max(R0, ylo), yb = min(R1 - 1, yhi);
-    if (ya > yb || xlo > xhi) {                                                  // no box pixel in these rows
-      yl_mi_zero(md + (size_t)R0 * wrow, (size_t)(R1 - R0) * wrow, tid);
-      continue;
+    const bool hit = ya <= yb && xlo <= xhi;
+    YL_MIS(1);
+    if (fill) {
+      if (!hit) {                                                                // no box pixel in these rows
+        yl_mi_zero(md + (size_t)R0 * wrow, (size_t)(R1 - R0) * wrow, tid);
+      } else {
+        if (ya > R0) yl_mi_zero(md + (size_t)R0 * wrow, (size_t)(ya - R0) * wrow, tid);
+        if (yb + 1 < R1) yl_mi_zero(md + (size_t)(yb + 1) * wrow, (size_t)(R1 - 1 - yb) * wrow, tid);
+      }
     }
-    if (ya > R0) yl_mi_zero(md + (size_t)R0 * wrow, (size_t)(ya - R0) * wrow, tid);
-    if (yb + 1 < R1) yl_mi_zero(md + (size_t)(yb + 1) * wrow, (size_t)(R1 - 1 - yb) * wrow, tid);
+    YL_MIS(2);
+    if (!boxes || !hit) continue;
     if (tid < NM) {           // safe: every earlier read of coef[] is followed by a workgroup barrier
-      const int cand = p.keep_idx[(size_t)b * p.max_out + d];
-      const int l = yl_level_of(lv, cand);
-      const int nl = lv.A[l] * lv.S[l] * lv.S[l];
-      coef[tid] = lv.ptr[l][((size_t)b * nl + (cand - lv.off[l])) * lv.E + 5 + lv.C + tid];
+      const int cand = yl_as_const(p.keep_idx)[(size_t)b * p.max_out + d];
+      int l = 0;
+      while (cand >= loff[l + 1]) ++l;
+      coef[tid] = lptr[l][((size_t)b * lnl[l] + (cand - loff[l])) * lv.E + 5 + lv.C + tid];
     }
     for (int seg = 0; seg < nsegs; ++seg) {
-      const int c0 = seg * YL_MI_TILE, c1 = min(c0 + YL_MI_TILE, wrow) - 1;      // bytes [c0, c1] of every row
+      const int c0 = seg * p.tile, c1 = min(c0 + p.tile, wrow) - 1;      // bytes [c0, c1] of every row
       const int px0 = p.packed ? c0 * 8 : c0, px1 = min(p.packed ? c1 * 8 + 7 : c1, W - 1);
       const int xa = max(px0, xlo), xb = min(px1, xhi);
       if (xa > xb) {                                                             // only with nsegs > 1
@@ -1027,33 +1129,47 @@ __global__ __launch_bounds__(256) void yl_masks_image_kernel(YlLevels lv, YlMask
       taps(xb, padx, kx, PW, tmp, pu1, tw);
       const int pw = pu1 - pu0 + 1;
       const int w0 = xa >> 5, nw = (xb >> 5) - w0 + 1;                           // 32-pixel words that hold box pixels
-      const float rnw = 1.0f / (float)nw;
       for (int t0 = ya; t0 <= yb;) {
         int t1 = min(yb, t0 + RB - 1);
         int pv0, pv1;
         taps(t0, pady, ky, PH, pv0, tmp, tw);
-        bool direct = false;
-        for (;;) {                                                               // shrink the row group until its footprint fits
-          taps(t1, pady, ky, PH, tmp, pv1, tw);
-          if ((pv1 - pv0 + 1) * pw <= YL_MI_PCAP) break;
-          if (t1 == t0) { direct = true; break; }
+        for (;;) {                                  // shrink the row group until its footprint fits (one row always
+          taps(t1, pady, ky, PH, tmp, pv1, tw);     // does: 2 * PW <= YL_MI_PCAP is checked by the launcher)
+          if ((pv1 - pv0 + 1) * pw <= YL_MI_PCAP || t1 == t0) break;
           t1 = t0 + ((t1 - t0) >> 1);
         }
         const int np = (pv1 - pv0 + 1) * pw;
         unsigned char* g0 = md + (size_t)t0 * wrow + c0;
         const int len = nsegs > 1 ? (c1 - c0 + 1) : (t1 - t0 + 1) * wrow;
         const int mis = (int)((uintptr_t)g0 & 15u);
+        YL_MIS(3);
         __syncthreads();                                  // A: the previous tile has left LDS; coef[] is written
+        YL_MIS(4);
         for (int i = tid; i < ((mis + len + 15) >> 4); i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (!direct) {
+        if (tid < t1 - t0 + 1) {                          // vertical taps of the tile's rows, as pbuf row offsets
+          int v0, v1; float lvw;
+          taps(t0 + tid, pady, ky, PH, v0, v1, lvw);
+          reinterpret_cast<float4*>(rtab)[tid] = make_float4(__int_as_float((v0 - pv0) * pw - pu0), __int_as_float((v1 - pv0) * pw - pu0),
+                                                             lvw, 0.0f);
+        }
+        {
           const float rpw = 1.0f / (float)pw;
-          for (int t = tid; t < np; t += 256) {
+          for (int t = tid; t < np && tid < 192; t += 192) {          // waves 0-2 (wave 3 is the store wave, see below)
             int q = (int)((float)t * rpw);
             int r = t - q * pw;
             if (r < 0) { --q; r += pw; } else if (r >= pw) { ++q; r -= pw; }
             const float4* pp = reinterpret_cast<const float4*>(pimg + ((size_t)(pv0 + q) * PW + (pu0 + r)) * NM);
             float acc = 0.0f;
-            if ((NM & 3) == 0) {
+            if (NM == 32) {                               // the build's default: all eight loads in flight at once
+              float4 v[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) v[k] = pp[k];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                acc = fmaf(coef[4 * k], v[k].x, acc); acc = fmaf(coef[4 * k + 1], v[k].y, acc);
+                acc = fmaf(coef[4 * k + 2], v[k].z, acc); acc = fmaf(coef[4 * k + 3], v[k].w, acc);
+              }
+            } else if ((NM & 3) == 0) {
               for (int k = 0; k < NM; k += 4) {
                 const float4 v = pp[k >> 2];
                 acc = fmaf(coef[k], v.x, acc); acc = fmaf(coef[k + 1], v.y, acc);
@@ -1066,85 +1182,92 @@ __global__ __launch_bounds__(256) void yl_masks_image_kernel(YlLevels lv, YlMask
             pbuf[t] = yl_sigmoid(acc);
           }
         }
+        YL_MIS(5);
         __syncthreads();                                  // B: probabilities + zeroed tile visible
+        YL_MIS(6);
         const int nunits = (t1 - t0 + 1) * nw;
+        // half-wave h of wave w takes the units 2w + h, 2w + h + 8, ...: (row q, word r) advanced incrementally
+        int u = (tid >> 6) * 2 + (lane >> 5);
+        int q = u / nw, r = u - q * nw;
+        const int dq = 8 / nw, dr_ = 8 - dq * nw;
         for (int ub = (tid >> 6) * 2; ub < nunits; ub += 8) {                    // wave-uniform: __ballot below
-          const int u = ub + (lane >> 5);
           const bool valid = u < nunits;
-          int q = (int)((float)u * rnw);
-          int r = u - q * nw;
-          if (r < 0) { --q; r += nw; } else if (r >= nw) { ++q; r -= nw; }
           const int y = t0 + q, xw = w0 + r, x = (xw << 5) + (lane & 31);
           bool on = false;
           if (valid && x <= px1 && (float)x >= x1 && (float)x < x2 && (float)y >= y1 && (float)y < y2) {
-            int u0, u1, v0, v1; float lu, lv_;
+            int u0, u1; float lu;
             taps(x, padx, kx, PW, u0, u1, lu);
-            taps(y, pady, ky, PH, v0, v1, lv_);
-            float p00, p01, p10, p11;
-            if (!direct) {
-              const float* r0p = pbuf + (v0 - pv0) * pw - pu0;
-              const float* r1p = pbuf + (v1 - pv0) * pw - pu0;
-              p00 = r0p[u0]; p01 = r0p[u1]; p10 = r1p[u0]; p11 = r1p[u1];
-            } else {                                      // footprint of ONE row beyond the LDS budget (PW > 2048)
-              auto prob = [&](int v, int uu) {
-                const float* qp = pimg + ((size_t)v * PW + uu) * NM;
-                float acc = 0.0f;
-                for (int k = 0; k < NM; ++k) acc = fmaf(coef[k], qp[k], acc);
-                return yl_sigmoid(acc);
-              };
-              p00 = prob(v0, u0); p01 = prob(v0, u1); p10 = prob(v1, u0); p11 = prob(v1, u1);
-            }
+            const float4 rt = reinterpret_cast<const float4*>(rtab)[q];
+            const float lv_ = rt.z;
+            const float* r0p = pbuf + __float_as_int(rt.x);
+            const float* r1p = pbuf + __float_as_int(rt.y);
+            const float p00 = r0p[u0], p01 = r0p[u1], p10 = r1p[u0], p11 = r1p[u1];
             const float top = p00 + (p01 - p00) * lu, bot = p10 + (p11 - p10) * lu;
             on = (top + (bot - top) * lv_) > p.thr;
           }
-          unsigned char* trow = tile + mis + (size_t)(y - t0) * (nsegs > 1 ? 0 : wrow) - c0;
+          unsigned char* trow = tile + mis + (size_t)q * (nsegs > 1 ? 0 : wrow) - c0;
           if (p.packed) {
             const unsigned long long bits = __ballot(on);
             if (valid && (lane & 31) == 0) *reinterpret_cast<unsigned*>(trow + (xw << 2)) = (unsigned)(bits >> (lane & 32));
           } else if (valid && x <= px1) {
             trow[x] = on ? 1 : 0;
           }
+          u += 8; q += dq; r += dr_;
+          if (r >= nw) { r -= nw; ++q; }
         }
+        YL_MIS(7);
         __syncthreads();                                  // C: tile complete
-        {
+        YL_MIS(8);
+        // Only wave 3 stores (and it never issues a vector load): vmcnt counts loads and stores in ONE in-order
+        // counter, so a wave that waits for a load also waits for the acknowledgement of its earlier stores.
+        if (tid >= 192) {
+          const int l = tid - 192;
           const int head = min((16 - mis) & 15, len);
-          if (tid < head) g0[tid] = tile[mis + tid];
+          if (l < head) g0[l] = tile[mis + l];
           const int body = (len - head) >> 4;
           const uint4* src = reinterpret_cast<const uint4*>(tile + mis + head);
           uint4* gb = reinterpret_cast<uint4*>(g0 + head);
-          for (int i = tid; i < body; i += 256) gb[i] = src[i];
+          for (int i = l; i < body; i += 64) gb[i] = src[i];
           const int tail = len - head - (body << 4);
-          if (tid < tail) g0[head + (body << 4) + tid] = tile[mis + head + (body << 4) + tid];
+          if (l < tail) g0[head + (body << 4) + l] = tile[mis + head + (body << 4) + l];
         }
+        YL_MIS(9);
         t0 = t1 + 1;
       }
     }
   }
+  }
+#ifdef YL_MI_STAMP
+  if (tid == 0 && blockIdx.x < 2048) yl_mi_blk[2 * (blockIdx.x + (BOXES ? 2048 : 0)) + 1] = wall_clock64();
+#endif
 }
 
 hipError_t yl_launch_masks_image(const YlLevels& lv, int B, const float* proto, int PH, int PW, int NM, int S,
                                  const float* dets, const int* counts, const int* keep_idx, int max_out, float thr,
                                  const float* backmap, const int* out_hw, const long long* mask_off, int max_h, int max_w,
                                  int packed, unsigned char* masks, hipStream_t st) {
-  if (NM > 64 || max_h < 1 || max_w < 1) return hipErrorInvalidValue;
+  if (NM > 64 || max_h < 1 || max_w < 1 || 2 * PW > YL_MI_PCAP || B > 8192) return hipErrorInvalidValue;
   YlMaskImgP p;
   p.proto = proto; p.PH = PH; p.PW = PW; p.NM = NM; p.S = S; p.dets = dets; p.counts = counts; p.keep_idx = keep_idx;
   p.max_out = max_out; p.backmap = backmap; p.out_hw = out_hw; p.mask_off = mask_off; p.masks = masks; p.thr = thr;
   p.packed = packed;
   // small batches: cut every detection's rows into parts so that a handful of detections still spreads over the chip
   p.parts = B >= 16 ? 1 : min(max(32 / B, 1), min(16, max_h));
-  static int blocks_total = 0;
-  if (!blocks_total) {
-    const char* e = getenv("YL_MI_BLOCKS");
-    blocks_total = e ? atoi(e) : 1536;              // 6 workgroups (25 KB of LDS each) per CU
-    if (blocks_total < 1) blocks_total = 1536;
+  p.B = B;
+  static int blocks_fill = 0, blocks_box = 0;
+  if (!blocks_fill) {
+    const char* e = getenv("YL_MI_BLOCKS");             // tuning aid: "fill:box" workgroups
+    if (!e || sscanf(e, "%d:%d", &blocks_fill, &blocks_box) != 2 || blocks_fill < 1 || blocks_box < 1) {
+      blocks_fill = 2048; blocks_box = 2048;            // 8 x 256 CUs
+    }
   }
-  long long gx = (blocks_total + B - 1) / B;
-  const long long most = (long long)max_out * p.parts;
-  if (gx > most) gx = most;
-  if (gx < 1) gx = 1;
-  const size_t lds = (size_t)(64 + YL_MI_PCAP) * sizeof(float) + YL_MI_TILE + 32;
-  hipLaunchKernelGGL(yl_masks_image_kernel, dim3((unsigned)gx, B), dim3(256), lds, st, lv, p);
+  const long long most = (long long)B * max_out * p.parts;
+  const unsigned gfill = (unsigned)min((long long)blocks_fill, most), gbox = (unsigned)min((long long)blocks_box, most);
+  // bit-packed rows are short (80 B at 640 px): 4 KB tiles hold ~50 rows and keep 8 workgroups per CU; uint8 rows get 16 KB
+  p.tile = packed ? 4096 : 16384;
+  const size_t lds = (size_t)(64 + YL_MI_PCAP + 4 * YL_MI_ROWS) * sizeof(float) + p.tile + 32 + YL_MAX_LEVELS * 12 + 8 + (size_t)(B + 1) * sizeof(int);
+  hipLaunchKernelGGL(yl_masks_image_kernel<true>, dim3(gbox), dim3(256), lds, st, lv, p);
+  hipLaunchKernelGGL(yl_masks_image_kernel<false>, dim3(gfill), dim3(256), lds, st, lv, p);
   return hipGetLastError();
 }
 

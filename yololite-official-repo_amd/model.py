@@ -226,13 +226,19 @@ class HipContext:
         return out
 
     def masks_image(self, dets: torch.Tensor, counts: torch.Tensor, keep_idx: torch.Tensor, backmap=None, out_hw=None,
-                    thr: float = 0.5, packed: bool = False, levels: Optional[Sequence[torch.Tensor]] = None):
+                    thr: float = 0.5, packed: bool = False, levels: Optional[Sequence[torch.Tensor]] = None,
+                    arena: Optional[torch.Tensor] = None):
         """Image-resolution instance masks of the detections of the last predict() (yl_masks_image, build-defined).
         backmap: the [B,5] rows given to predict() (then `dets` are already in original-image coordinates and
         out_hw[b] = (h0, w0)); None: masks on the S x S network-input grid.  Returns a list of B device tensors:
-        uint8 [Ni, h_b, w_b], or with packed=True uint32 [Ni, h_b, ceil(w_b/32)] (bit k of word j = pixel 32j+k)."""
+        uint8 [Ni, h_b, w_b], or with packed=True uint32 (as an int32 view: torch has no uint32 arithmetic)
+        [Ni, h_b, ceil(w_b/32)] (bit k of word j = pixel 32j+k).
+
+        arena: a preallocated uint8 device tensor of at least B*max_out*h*row bytes (all images one output size) makes
+        the call ASYNCHRONOUS -- fixed-capacity layout, image b's masks start at b*max_out*h*row, no host read of
+        `counts`, no allocation; returns ONE view [B, max_out, h, row] whose first counts[b] entries of image b are
+        written (serving loops / the benchmark: the masks travel with the packed detections)."""
         B, max_out = int(dets.shape[0]), int(dets.shape[1])
-        cn = np.minimum(counts.cpu().numpy().astype(np.int64), max_out)
         if out_hw is None:
             if backmap is not None:
                 bmh = np.asarray(backmap.cpu() if torch.is_tensor(backmap) else backmap, dtype=np.float64).reshape(B, 5)
@@ -241,6 +247,32 @@ class HipContext:
                 out_hw = np.full((B, 2), self.img_size)
         hw = np.ascontiguousarray(np.asarray(out_hw).reshape(B, 2), np.int32)
         rowb = (((hw[:, 1].astype(np.int64) + 31) // 32) * 4) if packed else hw[:, 1].astype(np.int64)
+        bm_d = None
+        if backmap is not None:
+            bm_d = (backmap if torch.is_tensor(backmap) else torch.as_tensor(np.asarray(backmap, np.float32)))
+            bm_d = bm_d.to(device=self.device, dtype=torch.float32).contiguous()
+        arr = self._ptr_array(self._check_levels(levels)) if levels is not None else None
+        if arena is not None:
+            if not (hw == hw[0]).all():
+                raise ValueError("masks_image(arena=...) needs one output size for the whole batch")
+            h, row = int(hw[0, 0]), int(rowb[0])
+            per = max_out * h * row
+            if arena.dtype != torch.uint8 or not arena.is_contiguous() or arena.numel() < B * per or arena.data_ptr() % 16:
+                raise ValueError(f"arena must be a contiguous 16-byte aligned uint8 tensor of >= {B * per} bytes")
+            key = (B, max_out, h, int(hw[0, 1]), bool(packed))
+            cached = getattr(self, "_mask_geom", None)
+            if cached is None or cached[0] != key:
+                offs = (np.arange(B, dtype=np.int64) * per)
+                cached = (key, torch.from_numpy(hw).to(self.device), torch.from_numpy(offs).to(self.device))
+                self._mask_geom = cached
+            _lib.check(self.lib.yl_masks_image(self.handle, arr, B, dets.data_ptr(), counts.data_ptr(), keep_idx.data_ptr(),
+                                               max_out, float(thr), bm_d.data_ptr() if bm_d is not None else None,
+                                               cached[1].data_ptr(), cached[2].data_ptr(), h, int(hw[0, 1]),
+                                               1 if packed else 0, arena.data_ptr(), _stream_ptr(self.device)),
+                       self.handle, "yl_masks_image")
+            v = arena[:B * per]
+            return v.view(torch.int32).view(B, max_out, h, row // 4) if packed else v.view(B, max_out, h, row)
+        cn = np.minimum(counts.cpu().numpy().astype(np.int64), max_out)
         sizes = cn * hw[:, 0].astype(np.int64) * rowb
         sizes = (sizes + 15) & ~15
         offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
@@ -248,11 +280,6 @@ class HipContext:
         buf = torch.empty((max(total, 16),), device=self.device, dtype=torch.uint8)
         hw_d = torch.from_numpy(hw).to(self.device)
         off_d = torch.from_numpy(offs).to(self.device)
-        bm_d = None
-        if backmap is not None:
-            bm_d = (backmap if torch.is_tensor(backmap) else torch.as_tensor(np.asarray(backmap, np.float32)))
-            bm_d = bm_d.to(device=self.device, dtype=torch.float32).contiguous()
-        arr = self._ptr_array(self._check_levels(levels)) if levels is not None else None
         _lib.check(self.lib.yl_masks_image(self.handle, arr, B, dets.data_ptr(), counts.data_ptr(), keep_idx.data_ptr(),
                                            max_out, float(thr), bm_d.data_ptr() if bm_d is not None else None,
                                            hw_d.data_ptr(), off_d.data_ptr(), int(hw[:, 0].max()), int(hw[:, 1].max()),
