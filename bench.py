@@ -277,8 +277,10 @@ def kernel_family(L, winograd=False):
     if L.op != 1:
         return "yl_stem_mfma_kernel" if L.op == 0 else "yl_dw_kernel"
     nt, kb = -(-L.cout // 16), -(-L.cin // 16)
-    if (winograd and L.dw_k == 0 and L.k == 3 and L.stride == 1 and L.cin >= 64 and L.cout >= 64 and L.cout % 4 == 0
-            and L.res_slot < 0 and L.up_slot < 0 and L.head_level < 0):
+    # the predicate of yl_create (yl_api.hip: the layers that get a Winograd weight image)
+    if (winograd and L.k == 3 and L.stride == 1 and L.dw_k == 0 and L.c2 == 0 and L.pad_t == 1 and L.pad_l == 1
+            and L.in_shift == 0 and L.cin >= 64 and L.cout >= 64 and L.cout % 4 == 0
+            and L.head_level < 0 and L.res_slot < 0 and L.up_slot < 0):
         return "yl_conv_wino_kernel"
     if L.dw_k == 0:
         if L.k == 1:
@@ -290,6 +292,268 @@ def kernel_family(L, winograd=False):
     if L.dw_k == 3 and kb >= 12 and nt > 8 and (nt % 7 == 0 or nt % 8 == 0):
         return "yl_conv_dwk_kernel"
     return "yl_conv_dwh_kernel"
+
+
+def csrc_digest():
+    """SHA-256 over the kernel sources (csrc/*.hip, *.h and the C header), the key that ties a committed PMC pass to
+    the code it was taken on: tools/pmc_summary.py stores it in profiles/rNN_pmc_traffic*.json and roofline.traffic
+    is null as soon as the sources differ (git is not available on the GPU box, file contents are)."""
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "yololite-official-repo_amd", "csrc")
+    files = sorted(f for f in os.listdir(cs) if f.endswith((".hip", ".h")))
+    for f in [os.path.join(cs, f) for f in files] + [os.path.join(ROOT, "include", "yololite_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+PMC_FILES = {("edge_n", 0, 64): "pmc_traffic.json", ("yololite_m", 0, 32): "pmc_traffic_yololite_m_b32.json",
+             ("edge_m", 1, 32): "pmc_traffic_edge_m_seg_b32.json"}
+
+
+def pmc_traffic(model_name, seg, B, kname, stem_pattern):
+    """HBM-side bytes per launch of kernel `kname` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate runs, tools/profile_round.sh; bench.py cannot run the profiler on itself).  Only a pass taken on EXACTLY
+    these kernel sources counts (csrc_sha256 in the file == csrc_digest()); FETCH_SIZE is corrected with the factor
+    measured on independent kernels of known byte counts (profiles/rNN_fetch_calibration.json: 0.50-0.53)."""
+    tail = PMC_FILES.get((model_name, int(seg), B))
+    if not tail or not kname:
+        return None, "no committed PMC pass for this configuration"
+    cand = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_" + tail)), reverse=True)
+    for f in cand:
+        try:
+            with open(os.path.join(ROOT, "profiles", f)) as fh:
+                j = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if j.get("csrc_sha256") != csrc_digest():
+            continue
+        hit = [v for k, v in j["kernels"].items() if kname in k]
+        if not hit:
+            continue
+        ffac = 0.5
+        for cf in sorted((c for c in os.listdir(os.path.join(ROOT, "profiles")) if c.endswith("_fetch_calibration.json")), reverse=True):
+            try:
+                with open(os.path.join(ROOT, "profiles", cf)) as fh:
+                    ffac = json.load(fh)["kernels"]["calib_x3s8" if stem_pattern else "calib_x4"]["counter_over_actual"]
+                break
+            except (OSError, KeyError, ValueError):
+                continue
+        v = hit[0]
+        return (round((v["FETCH_SIZE_KB_median"] / ffac + v["WRITE_SIZE_KB_median"]) * 1024.0),
+                f"profiles/{f} (csrc_sha256 {j['csrc_sha256']}): median over the full-batch dispatches of FETCH_SIZE / {ffac} + "
+                f"WRITE_SIZE, eager launches; factor from independent known-byte-count kernels")
+    return None, f"no PMC pass under profiles/ was taken on these kernel sources (csrc_sha256 {csrc_digest()})"
+
+
+def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seconds, max_blocks=60):
+    """One configuration of the hot path: build the workload, time per-layer durations eagerly (HIP events around every
+    launch), then time BLOCKS of exactly args.steps steps each -- every block bracketed by barrier +
+    torch.cuda.synchronize() on both sides, max over ranks -- until >= min_seconds of timed steps (the first block alone
+    is ~40 ms at the headline configuration: too short against the DVFS ramp).  Returns the JSON fields."""
+    import torch.distributed as dist
+    from yololite_amd import _lib, dist as ydist
+    S = args.img
+    wl = build_workload(model_name, S, B, seed=(args.seed if args.seed >= 0 else 1), seg=bool(seg), dev=dev, rank=rank,
+                        stress=bool(args.stress),
+                        fuse_dw=(args.fuse_dw if args.fuse_dw in ("auto", "dw3") else bool(int(args.fuse_dw))),
+                        fuse_stem=bool(args.fuse_stem), fuse_uib=bool(args.fuse_uib))
+    meta, sd, ctx, prog, x = wl["meta"], wl["sd"], wl["ctx"], wl["prog"], wl["x"]
+    seed = wl["seed"]
+    if args.tile_m:
+        ctx.set_option("tile_m", args.tile_m)
+    ctx.set_option("streams", args.streams)
+    if args.bf16:
+        ctx.set_option("mfma_bf16", 1)
+    ctx.set_option("lanes", args.lanes)
+    ctx.set_option("fuse_decode", args.fuse_decode)
+    ctx.set_option("batch_levels", args.batch_levels)
+    ctx.set_option("hybrid", args.hybrid)
+    ctx.set_option("nms_groups", args.nms_groups)
+    ctx.set_option("winograd", args.winograd)
+    max_out = MAX_OUT                                    # packed result rows per image
+    gat = None
+    if gather:
+        # equal shards: yl_predict writes into the gather buffer, one collective, no pack/unpack kernels
+        gat = ydist.DetGatherer(B, max_out, dev)
+        dets = counts = None
+    else:
+        dets = torch.empty((B, max_out, 6), device=dev, dtype=torch.float32)
+        counts = torch.empty((B,), device=dev, dtype=torch.int32)
+    mask_arena = (torch.empty((B * max_out * S * ((S + 31) // 32) * 4,), device=dev, dtype=torch.uint8) if seg else None)
+
+    def step():
+        if seg:
+            _, _, idx = ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
+                                    out=(dets, counts), want_idx=True)
+            # image-resolution (640 x 640) masks, bit-packed rows, into a fixed-capacity arena: asynchronous like the
+            # detections themselves (no host read of the counts inside the step)
+            ctx.masks_image(dets, counts, idx, packed=True, arena=mask_arena)
+            return dets, counts
+        if gat is not None:      # results go straight into the gather slot; its all-gather overlaps the next step
+            ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
+                        out=(gat.dets, gat.counts))
+            return gat.gather()
+        ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out, out=(dets, counts))
+        return dets, counts
+
+    # ---- per-layer durations (HIP events on the launch stream), eager launches
+    ctx.set_option("graph", 0)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    reps = 7
+    lay = np.median(np.stack([np.asarray(ctx.forward(x, timed=True)[1]) for _ in range(reps)]), axis=0)   # median: a
+    # host hiccup between two eager launches must not crown a 30 us layer "dominant kernel"
+
+    ctx.set_option("graph", args.graph)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if gat is not None:
+        gat.flush()
+
+    def block():
+        """exactly args.steps steps between barrier + synchronize on both sides; max over ranks"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(args.steps):
+            step()
+            ev[i + 1].record()
+        if gat is not None:
+            gat.flush()                    # every step's exchange has completed inside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el_local = time.perf_counter() - t0
+        el = el_local
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, el_local, [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+
+    els, step_ms, el_locals = [], [], []
+    el, ell, sm = block()
+    els.append(el); el_locals.append(ell); step_ms += sm
+    # number of further blocks: the same on every rank (derived from the all-reduced first block)
+    more = int(min(max_blocks - 1, max(0, np.ceil((min_seconds - el) / max(el, 1e-6)))))
+    for _ in range(more):
+        el, ell, sm = block()
+        els.append(el); el_locals.append(ell); step_ms += sm
+    els = np.asarray(els)
+    rates = world * B * args.steps / els
+    k_med = int(np.argsort(els)[len(els) // 2])          # the median block: value and ms_per_step come from ONE block
+    if gat is not None:
+        counts = gat.flush()[1][rank if world > 1 else 0]
+        drows = gat.flush()[0][rank if world > 1 else 0]
+    else:
+        drows = dets
+    ndet = float(counts.float().mean().item())
+    dropped = int((counts.to(torch.int64) - max_out).clamp(min=0).sum().item())
+    cn_host = counts.cpu().numpy()
+    ncls = float(np.mean([len(np.unique(drows[b, :min(int(cn_host[b]), max_out), 5].cpu().numpy())) for b in range(min(B, 8))]))
+    # the workload must exercise NMS: a synthetic model without detections would time an idle post-processing;
+    # and the result must be the reference's result for this input: nothing dropped by the packed-row capacity
+    assert ndet >= 50.0 or os.environ.get("YL_BENCH_ALLOW_EMPTY") == "1", \
+        f"benchmark workload produced {ndet:.1f} detections / image at conf {args.conf}: pick another --seed"
+    assert args.stress or dropped == 0, f"{dropped} detections dropped by max_out={max_out}"
+    extra = {}
+    if world > 1 or gat is not None:
+        extra["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
+        if dist.is_initialized():
+            t = torch.tensor([el_locals[k_med] / args.steps * 1e3], device=dev, dtype=torch.float64)
+            allt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(allt, t)
+            extra["ms_per_step_per_rank"] = [round(float(v.item()), 4) for v in allt]
+            # the exchange alone: synchronous all-gathers of the packed [dets | counts] row on an idle GPU
+            loc, out_ = gat._loc[0], gat._out[0].view(-1)
+            for _ in range(3):
+                dist.all_gather_into_tensor(out_, loc)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dist.all_gather_into_tensor(out_, loc)
+            e1.record()
+            torch.cuda.synchronize()
+            extra["allgather_ms"] = round(e0.elapsed_time(e1) / 20.0, 4)
+            extra["allgather_bytes_per_rank"] = int(loc.numel() * 4)
+    if rank != 0:
+        return None
+
+    # dominant kernel = the fused layer with the largest median duration
+    k = int(np.argmax(lay))
+    L = prog.layers[k]
+    flops = 2.0 * L.macs * B
+    fam = kernel_family(L, bool(args.winograd))
+    wino = "yl_conv_wino_kernel" in fam
+    flops_direct = flops
+    if wino:                      # Winograd F(2x2,3x3) executes 16 multiplications where the direct conv has 36
+        flops = flops * 16.0 / 36.0
+    byts = float(L.bytes_in + L.bytes_out) * B
+    ai = flops / byts
+    dur = lay[k] * 1e-3
+    if ai >= RIDGE:
+        roof = {"bound": "mfma", "achieved": round(flops / dur / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": round(byts / dur / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(model_name, seg, B, fam, L.op == 3)
+    roof["kernel"] = f"layer {k} {L.name} ({fam}, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})"
+    if wino:
+        roof["direct_conv_equivalent_tflops"] = round(flops_direct / dur / 1e12, 3)
+    roof["avg_launch_ms"] = round(float(lay[k]), 4)
+    roof["algorithmic_flops_per_launch"] = flops
+    roof["algorithmic_bytes_per_launch"] = byts
+    # executed multiplications of the whole forward: Winograd layers count 16/36 of their direct-conv MACs
+    net_macs = sum(l.macs * (16.0 / 36.0 if "yl_conv_wino_kernel" in kernel_family(l, bool(args.winograd)) else 1.0)
+                   for l in prog.layers)
+    net_flops = 2.0 * net_macs * B
+    fwd_ms = float(lay.sum())
+    out = {
+        "metric": "images/sec", "value": round(float(rates[k_med]), 1), "unit": "images/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(els[k_med]) / args.steps * 1e3, 4),
+        "p50_ms_per_frame": round(float(np.median(step_ms)) / B, 5),
+        "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
+        "blocks": {"n": int(len(els)), "steps_each": args.steps, "seconds_timed": round(float(els.sum()), 3),
+                   "images_per_sec_min": round(float(rates.min()), 1), "images_per_sec_median": round(float(rates[k_med]), 1),
+                   "images_per_sec_max": round(float(rates.max()), 1), "images_per_sec_first": round(float(rates[0]), 1)},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 operands / f32 accumulate and storage (reduced-precision mode, not the headline)" if args.bf16 else "f32",
+        "options": {"winograd": int(args.winograd)},
+        "data": "synthetic",
+        "config": {"workload": f"{model_name} {'detector+instance-seg head' if seg else 'detector'} {S}x{S} C=80 batch={B}/GPU, forward+decode+per-class NMS{'+masks' if seg else ''} "
+                               f"(conf {args.conf}, iou {args.iou}), input resident in HBM"
+                               + (", + RCCL all-gather of packed dets" if world > 1 else ""),
+                   "global_batch": B * world, "img_size": S, "parallelism": f"dp{world} (batch sharded, weights replicated)",
+                   "hipgraph": bool(args.graph), "streams": args.streams, "weights_seed": seed,
+                   "head": "NMS stress: uncalibrated N(0,2) head noise (round-1 workload)" if args.stress else
+                           "calibrated (program.calibrate_head)",
+                   "mean_dets_per_image": round(ndet, 1), "mean_classes_per_image": round(ncls, 1),
+                   "max_out": max_out, "dets_dropped": dropped},
+        "roofline": roof,
+        "network": {"conv_gflop_per_image": round(2.0 * prog.macs / 1e9, 4), "launches": len(prog.layers),
+                    "activation_mb": round(ctx.activation_bytes() / 1e6, 1),
+                    "forward_ms_sum_of_layers": round(fwd_ms, 4),
+                    "forward_tflops_executed": round(net_flops / (fwd_ms * 1e-3) / 1e12, 2),
+                    "forward_frac_of_fp32_mfma_peak": round(net_flops / (fwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "step_tflops_executed": round(net_flops / (float(els[k_med]) / args.steps) / 1e12, 2),
+                    "step_frac_of_fp32_mfma_peak": round(net_flops / (float(els[k_med]) / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+    }
+    out.update(extra)
+    if args.layers:
+        for i, (l, ms) in enumerate(zip(prog.layers, lay)):
+            print(f"{i:3d} {l.name:42s} cin{l.cin:4d} cout{l.cout:4d} k{l.k} dw{l.dw_k} {ms:8.4f} ms "
+                  f"{2.0 * l.macs * B / (ms * 1e-3) / 1e12:7.2f} TF {(l.bytes_in + l.bytes_out) * B / (ms * 1e-3) / 1e9:8.1f} GB/s",
+                  file=sys.stderr)
+    out["_cpu"] = (meta, sd)
+    return out
 
 
 def main():
@@ -324,6 +588,10 @@ def main():
     ap.add_argument("--winograd", type=int, default=0, help="1: dense 3x3 stride-1 convs (>= 64 channels) as Winograd F(2x2,3x3): "
                     "2.25x fewer MACs, results within 1e-4 of the direct convolution but not bit-identical")
     ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3) | track (tracker bank, f4)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the block of --steps timed steps until this much "
+                    "step time has been measured (value = the median block)")
+    ap.add_argument("--other-configs", type=int, default=-1, help="append BASELINE configs 3 and 4 (yololite_m B=32, edge_m+seg "
+                    "B=32) as `other_configs`; -1 = only for the default single-GPU headline run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -342,192 +610,27 @@ def main():
     init_only = os.environ.get("YL_BENCH_FORCE_COLLECTIVE") == "2"       # probe: process group initialised, no exchange
     if world > 1 or force_coll or init_only:
         dist.init_process_group("nccl", device_id=dev)
-
     import yololite_amd as ya  # noqa: F401
-    from yololite_amd import _lib, dist as ydist
 
-    B, S = args.batch, args.img
-    wl = build_workload(args.model, S, B, seed=(args.seed if args.seed >= 0 else 1), seg=bool(args.seg), dev=dev, rank=rank,
-                        stress=bool(args.stress),
-                        fuse_dw=(args.fuse_dw if args.fuse_dw in ("auto", "dw3") else bool(int(args.fuse_dw))),
-                        fuse_stem=bool(args.fuse_stem), fuse_uib=bool(args.fuse_uib))
-    meta, sd, model, ctx, prog, x = wl["meta"], wl["sd"], wl["model"], wl["ctx"], wl["prog"], wl["x"]
-    args.seed = wl["seed"]
-    if args.tile_m:
-        ctx.set_option("tile_m", args.tile_m)
-    ctx.set_option("streams", args.streams)
-    if args.bf16:
-        ctx.set_option("mfma_bf16", 1)
-    ctx.set_option("lanes", args.lanes)
-    ctx.set_option("fuse_decode", args.fuse_decode)
-    ctx.set_option("batch_levels", args.batch_levels)
-    ctx.set_option("hybrid", args.hybrid)
-    ctx.set_option("nms_groups", args.nms_groups)
-    ctx.set_option("winograd", args.winograd)
-    max_out = MAX_OUT                                    # packed result rows per image
-    gat = None
-    if world > 1 or force_coll:
-        # equal shards: yl_predict writes into the gather buffer, one collective, no pack/unpack kernels
-        gat = ydist.DetGatherer(B, max_out, dev)
-        dets = counts = None
-    else:
-        dets = torch.empty((B, max_out, 6), device=dev, dtype=torch.float32)
-        counts = torch.empty((B,), device=dev, dtype=torch.int32)
-
-    mask_arena = (torch.empty((B * max_out * S * ((S + 31) // 32) * 4,), device=dev, dtype=torch.uint8)
-                  if args.seg else None)
-
-    def step():
-        if args.seg:
-            _, _, idx = ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
-                                    out=(dets, counts), want_idx=True)
-            # image-resolution (640 x 640) masks, bit-packed rows, into a fixed-capacity arena: asynchronous like the
-            # detections themselves (no host read of the counts inside the step)
-            ctx.masks_image(dets, counts, idx, packed=True, arena=mask_arena)
-            return dets, counts
-        if gat is not None:      # results go straight into the gather slot; its all-gather overlaps the next step
-            ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
-                        out=(gat.dets, gat.counts))
-            return gat.gather()
-        ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out, out=(dets, counts))
-        return dets, counts
-
-    # ---- per-layer durations (HIP events on the launch stream), eager launches
-    ctx.set_option("graph", 0)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    reps = 7
-    lay = np.median(np.stack([np.asarray(ctx.forward(x, timed=True)[1]) for _ in range(reps)]), axis=0)   # median: a
-    # host hiccup between two eager launches must not crown a 30 us layer "dominant kernel"
-
-    ctx.set_option("graph", args.graph)
-    for _ in range(max(args.warmup, 1)):
-        step()
-    if gat is not None:
-        gat.flush()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(args.steps):
-        step()
-        ev[i + 1].record()
-    if gat is not None:
-        gat.flush()                    # every step's exchange has completed inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    step_ms = np.asarray([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
-    if gat is not None:
-        counts = gat.flush()[1][rank if world > 1 else 0]
-    ndet = float(counts.float().mean().item())
-    dropped = int((counts.to(torch.int64) - max_out).clamp(min=0).sum().item())
-    if gat is not None:
-        drows = gat.flush()[0][rank if world > 1 else 0]
-    else:
-        drows = dets
-    cn_host = counts.cpu().numpy()
-    ncls = float(np.mean([len(np.unique(drows[b, :min(int(cn_host[b]), max_out), 5].cpu().numpy())) for b in range(min(B, 8))]))
-    # the workload must exercise NMS: a synthetic model without detections would time an idle post-processing;
-    # and the result must be the reference's result for this input: nothing dropped by the packed-row capacity
-    assert ndet >= 50.0 or os.environ.get("YL_BENCH_ALLOW_EMPTY") == "1", \
-        f"benchmark workload produced {ndet:.1f} detections / image at conf {args.conf}: pick another --seed"
-    assert args.stress or dropped == 0, f"{dropped} detections dropped by max_out={max_out}"
-
+    out = measure_predict(args, args.model, args.batch, args.seg, dev, rank, world, gather=(world > 1 or force_coll),
+                          min_seconds=args.min_seconds)
+    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and not args.winograd
+                and not args.stress and args.img == 640)
+    want_other = args.other_configs == 1 or (args.other_configs == -1 and headline and world == 1 and not force_coll)
     if rank == 0:
-        value = world * B * args.steps / el
-        # dominant kernel = the fused layer with the largest average duration
-        k = int(np.argmax(lay))
-        L = prog.layers[k]
-        flops = 2.0 * L.macs * B
-        wino = "yl_conv_wino_kernel" in kernel_family(L, bool(args.winograd))
-        flops_direct = flops
-        if wino:                      # Winograd F(2x2,3x3) executes 16 multiplications where the direct conv has 36
-            flops = flops * 16.0 / 36.0
-        byts = float(L.bytes_in + L.bytes_out) * B
-        ai = flops / byts
-        dur = lay[k] * 1e-3
-        if ai >= RIDGE:
-            roof = {"bound": "mfma", "achieved": round(flops / dur / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s"}
-        else:
-            roof = {"bound": "hbm", "achieved": round(byts / dur / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
-        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        roof["traffic"] = None
-        # HBM-side bytes per launch from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, separate runs, tools/profile_round.sh): bench.py cannot run the profiler on itself.  The
-        # counters are corrected with factors measured on INDEPENDENT kernels of known byte counts in the same lane
-        # access patterns (tools/fetch_calib.hip -> profiles/r02_fetch_calibration.json): FETCH_SIZE reads 0.50-0.53
-        # of the bytes for 4-, 12- and 16-byte lane reads alike, WRITE_SIZE 1.00.
-        try:
-            pmc_file = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
-                            if os.path.exists(os.path.join(ROOT, "profiles", f)))
-            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                pmc = json.load(f)["kernels"]
-            ffac = 0.5
-            try:
-                with open(os.path.join(ROOT, "profiles", "r02_fetch_calibration.json")) as f:
-                    cal = json.load(f)["kernels"]
-                ffac = cal["calib_x3s8" if L.op == 3 else "calib_x4"]["counter_over_actual"]
-            except (OSError, KeyError, ValueError):
-                pass
-            kname = {3: "yl_stemblock_kernel"}.get(L.op)
-            hit = [v for k, v in pmc.items() if kname and kname in k]
-            if hit and B == 64 and args.model == "edge_n" and S == 640:
-                roof["traffic"] = round((hit[0]["FETCH_SIZE_KB_mean"] / ffac + hit[0]["WRITE_SIZE_KB_mean"]) * 1024.0)
-                roof["traffic_source"] = (f"profiles/{pmc_file}: FETCH_SIZE / {ffac} + WRITE_SIZE, eager full-batch launches; "
-                                          "factors from profiles/r02_fetch_calibration.json (independent known-byte-count kernels)")
-        except (OSError, KeyError, ValueError, StopIteration):
-            pass
-        roof["kernel"] = f"layer {k} {L.name} ({kernel_family(L, bool(args.winograd))}, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})"
-        if wino:
-            roof["direct_conv_equivalent_tflops"] = round(flops_direct / dur / 1e12, 3)
-        roof["avg_launch_ms"] = round(float(lay[k]), 4)
-        roof["algorithmic_flops_per_launch"] = flops
-        roof["algorithmic_bytes_per_launch"] = byts
-        net_flops = 2.0 * prog.macs * B
-        fwd_ms = float(lay.sum())
-        out = {
-            "metric": "images/sec", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
-            "p50_ms_per_frame": round(float(np.median(step_ms)) / B, 5),
-            "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 operands / f32 accumulate and storage (reduced-precision mode, not the headline)" if args.bf16 else "f32",
-            "options": {"winograd": int(args.winograd)},
-            "data": "synthetic",
-            "config": {"workload": f"{args.model} {'detector+instance-seg head' if args.seg else 'detector'} 640x640 C=80 batch={B}/GPU, forward+decode+per-class NMS{'+masks' if args.seg else ''} "
-                                   f"(conf {args.conf}, iou {args.iou}), input resident in HBM"
-                                   + (", + RCCL all-gather of packed dets" if world > 1 else ""),
-                       "global_batch": B * world, "img_size": S, "parallelism": f"dp{world} (batch sharded, weights replicated)",
-                       "hipgraph": bool(args.graph), "streams": args.streams, "weights_seed": args.seed,
-                       "head": "NMS stress: uncalibrated N(0,2) head noise (round-1 workload)" if args.stress else
-                               "calibrated (program.calibrate_head)",
-                       "mean_dets_per_image": round(ndet, 1), "mean_classes_per_image": round(ncls, 1),
-                       "max_out": max_out, "dets_dropped": dropped},
-            "roofline": roof,
-            "network": {"conv_gflop_per_image": round(2.0 * prog.macs / 1e9, 4), "launches": len(prog.layers),
-                        "activation_mb": round(ctx.activation_bytes() / 1e6, 1),
-                        "forward_ms_sum_of_layers": round(fwd_ms, 4),
-                        "forward_tflops": round(net_flops / (fwd_ms * 1e-3) / 1e12, 2),
-                        "forward_frac_of_fp32_mfma_peak": round(net_flops / (fwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
-        }
-        if args.layers:
-            for i, (l, ms) in enumerate(zip(prog.layers, lay)):
-                print(f"{i:3d} {l.name:42s} cin{l.cin:4d} cout{l.cout:4d} k{l.k} dw{l.dw_k} {ms:8.4f} ms "
-                      f"{2.0 * l.macs * B / (ms * 1e-3) / 1e12:7.2f} TF {(l.bytes_in + l.bytes_out) * B / (ms * 1e-3) / 1e9:8.1f} GB/s",
-                      file=sys.stderr)
+        meta, sd = out.pop("_cpu")
+        if want_other:
+            # BASELINE configs 3 and 4 through the same harness (parity path: winograd 0), each a few seconds
+            others = {}
+            for name, (m, b, sg) in {"yololite_m_b32": ("yololite_m", 32, 0), "edge_m_seg_b32": ("edge_m", 32, 1)}.items():
+                o = measure_predict(args, m, b, sg, dev, 0, 1, gather=False, min_seconds=min(args.min_seconds, 0.5), max_blocks=8)
+                o.pop("_cpu")
+                others[name] = {k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "p50_ms_per_frame", "blocks", "dtype",
+                                                  "options", "config", "roofline", "network")}
+                torch.cuda.empty_cache()
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(meta, sd, S, args.conf, args.iou)
+            out["cpu_baseline"] = cpu_baseline(meta, sd, args.img, args.conf, args.iou)
     if world > 1 or force_coll or init_only:
         dist.destroy_process_group()
     if rank == 0:

@@ -22,6 +22,12 @@ def test_bench_under_torchrun_one_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and "roofline" in d
+    # what the first multi-GPU run reports about itself: ranks in the communicator, per-rank step
+    # time, the exchange's own HIP-event time; every timed block is exactly --steps steps
+    assert d["rccl_ranks"] == 1 and len(d["ms_per_step_per_rank"]) == 1 and d["allgather_ms"] > 0
+    assert d["allgather_bytes_per_rank"] == (8 * 1024 * 6 + 8) * 4
+    assert d["blocks"]["steps_each"] == 3 and d["blocks"]["n"] >= 1
+    assert d["blocks"]["images_per_sec_min"] <= d["value"] <= d["blocks"]["images_per_sec_max"]
 
 
 def test_c_abi_allgather_dets_with_a_raw_rccl_communicator():

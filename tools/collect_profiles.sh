@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the summaries of tools/profile_round.sh from gpurun_out/prof_$TAG into profiles/ (tracked):  tools/collect_profiles.sh r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 S=gpurun_out/prof_$TAG
 D=profiles
 cp $S/kernel_stats.csv $D/${TAG}_kernel_stats_bench_edge_n_b64.csv

@@ -3,9 +3,17 @@
 import csv, sys, collections, json
 
 if len(sys.argv) > 1 and sys.argv[1] == "--json":
-    # --json FETCH.csv WRITE.csv : per-kernel mean KB per dispatch of both counters (profiles/rNN_pmc_traffic.json)
+    # --json [--label TEXT] FETCH.csv WRITE.csv : per-kernel KB per dispatch of both counters (profiles/rNN_pmc_traffic*.json).
+    # mean AND median: the benchmark run also dispatches every kernel once on the B=8 head-calibration batch, which the
+    # median ignores.  csrc_sha256 ties the pass to the kernel sources it was taken on (bench.csrc_digest).
+    import os, statistics
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    argv = sys.argv[2:]
+    label = "B=64 edge_n 640x640"
+    if argv and argv[0] == "--label":
+        label, argv = argv[1], argv[2:]
     out = collections.defaultdict(dict)
-    for path in sys.argv[2:]:
+    for path in argv:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         with open(path) as f:
             for r in csv.DictReader(f):
@@ -13,10 +21,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "--json":
         for k, d in acc.items():
             for c, v in d.items():
                 out[k][c + "_KB_mean"] = sum(v) / len(v)
+                out[k][c + "_KB_median"] = statistics.median(v)
                 out[k]["dispatches"] = len(v)
-    print(json.dumps({"note": "rocprofv3 --pmc, separate passes, eager launches (--graph 0 --streams 1), B=64 edge_n 640x640; "
+    try:
+        from bench import csrc_digest
+        sha = csrc_digest()
+    except Exception:
+        sha = None
+    print(json.dumps({"note": "rocprofv3 --pmc, separate passes, eager launches (--graph 0 --streams 1), " + label + "; "
                               "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 of their bytes (MI355X_MICROARCH.md HBM section)",
-                      "kernels": out}, indent=1))
+                      "csrc_sha256": sha, "kernels": out}, indent=1))
     sys.exit(0)
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(sys.argv[1]) as f:

@@ -5,26 +5,26 @@
 #   2. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE, SQ set
 #   3. un-profiled bench line + per-layer table; NMS-stress line; configs 3 and 4 (kernel stats + bench + layer table)
 #   4. FETCH_SIZE / WRITE_SIZE calibration on independent kernels (tools/fetch_calib.sh)
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --other-configs 0 --min-seconds 0"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $BENCH > $OUT/stats.log 2>&1
 # same, one internal stream: every conv launch is the full-batch one that bench.py's roofline.avg_launch_ms times
 rocprofv3 --kernel-trace --stats -d $OUT/stats1 -o s --output-format csv -- $BENCH --streams 1 > $OUT/stats1.log 2>&1
-PM="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --graph 0 --streams 1"
+PM="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 --other-configs 0 --min-seconds 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $PM > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $PM > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o p --output-format csv -- $PM > $OUT/pmc_sq.log 2>&1
 for cfg in "yololite_m 0" "edge_m 1"; do
   set -- $cfg
   N=$1; [ "$2" == "1" ] && N=${1}_seg
-  rocprofv3 --kernel-trace --stats -d $OUT/stats_$N -o s --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --streams 1 > $OUT/stats_$N.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcf_$N -o p --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 > $OUT/pmcf_$N.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcw_$N -o p --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 > $OUT/pmcw_$N.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/stats_$N -o s --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --streams 1 --min-seconds 0 > $OUT/stats_$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcf_$N -o p --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 --min-seconds 0 > $OUT/pmcf_$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcw_$N -o p --output-format csv -- python $ROOT/bench.py --model $1 --seg $2 --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 --min-seconds 0 > $OUT/pmcw_$N.log 2>&1
 done
 cd $ROOT
 python bench.py --steps 30 --warmup 5 --layers > $OUT/bench.json 2> $OUT/layers.txt
@@ -44,12 +44,12 @@ python bench.py --workload track > $OUT/bench_track.json 2> /dev/null
   echo; echo "# rocprofv3 --pmc SQ_* (per dispatch, mean)"
   python tools/pmc_summary.py $(find $OUT/pmc_sq -name '*counter_collection.csv' | head -1)
 } > $OUT/pmc_summary.txt
-python tools/pmc_summary.py --json $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) > $OUT/pmc_traffic.json
+python tools/pmc_summary.py --json --label "B=64 edge_n 640x640" $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) > $OUT/pmc_traffic.json
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/stats1 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_streams1.csv
 for N in yololite_m edge_m_seg; do
   cp $(find $OUT/stats_$N -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_$N.csv
-  python tools/pmc_summary.py --json $(find $OUT/pmcf_$N -name '*counter_collection.csv' | head -1) $(find $OUT/pmcw_$N -name '*counter_collection.csv' | head -1) > $OUT/pmc_traffic_$N.json
+  python tools/pmc_summary.py --json --label "B=32 $N 640x640" $(find $OUT/pmcf_$N -name '*counter_collection.csv' | head -1) $(find $OUT/pmcw_$N -name '*counter_collection.csv' | head -1) > $OUT/pmc_traffic_$N.json
 done
 tools/fetch_calib.sh gpurun_out/prof_$TAG/calib > $OUT/calib.log 2>&1
 # keep the merge-back small: raw traces are not needed
