@@ -76,6 +76,26 @@ def _safe_images(scores, boxes_unused, conf, cand, need=3):
     return ok[:need]
 
 
+def _assert_all_safe_images(dets, counts, exp, ref_scores, conf, images, min_safe, exp_index=None):
+    """north_star on EVERY threshold-safe image of `images` (exp lists are indexed by position unless exp_index maps
+    image -> position).  One image may deviate in its detection LIST (an NMS pair whose IoU sits within the fp32 drift
+    of the threshold flips the greedy walk; conf-threshold flips are excluded by the safety margin) -- it must still
+    agree in count to +-2; every other safe image is held to class ids, 1e-4 scores and rounded boxes."""
+    safe = [b for b in images if float((ref_scores[b if exp_index is None else exp_index[b]] - conf).abs().min()) > 2e-5]
+    assert len(safe) >= min_safe, (len(safe), min_safe)
+    odd = []
+    for b in safe:
+        i = b if exp_index is None else exp_index[b]
+        gb, gs, gc = _rows(dets, counts, b)
+        if gc.tolist() != exp["classes"][i].tolist():
+            assert abs(len(gc) - len(exp["classes"][i])) <= 2, (b, len(gc), len(exp["classes"][i]))
+            odd.append(b)
+            continue
+        _assert_north_star((gb, gs, gc), exp, i)
+    assert len(odd) <= 1, odd
+    return [b for b in safe if b not in odd]
+
+
 def test_bench_configuration_edge_n_b64_parity():
     wl = bench.build_workload("edge_n", 640, 64, seed=1, dev=DEV)
     ctx, x, meta, sd = wl["ctx"], wl["x"], wl["meta"], wl["sd"]
@@ -104,18 +124,17 @@ def test_bench_configuration_edge_n_b64_parity():
         assert torch.equal(c1, c0), rep
         for b in range(64):
             assert torch.equal(d1[b, :cn[b]], d0[b, :cn[b]]), (rep, b)
-    # ---- sampled images against the oracle end to end (oracle forward -> oracle pipeline)
+    # ---- ALL 64 images against the oracle end to end (oracle forward -> oracle pipeline): every image whose candidate
+    # scores keep clear of the confidence threshold must give the oracle's class-id list, scores and rounded boxes
     orc = _oracle(meta, sd)
-    cand = [0, 21, 37, 50, 63]
     with torch.no_grad():
-        ref_lv = orc(x[cand].cpu())
-    sel = _safe_images(_score_tensor(ref_lv), None, 0.4, range(len(cand)))
+        ref_lv = orc(x.cpu())
+    ref_s = _score_tensor(ref_lv)
     exp = opost.pipeline_main(ref_lv, 640, 0.4, 0.5, 300)
-    for i in sel:
-        _assert_north_star(_rows(d1, c1, cand[i]), exp, i)
-    # raw head tensors of the same images: decoded scores within the 1e-4 bar everywhere (not only on survivors)
-    lv = wl["model"](x[cand])
-    got_s, ref_s = _score_tensor([t.cpu() for t in lv]), _score_tensor(ref_lv)
+    _assert_all_safe_images(d1, c1, exp, ref_s, 0.4, range(64), min_safe=32)
+    # raw head tensors: decoded scores within the 1e-4 bar everywhere (not only on survivors), all 64 images
+    lv = wl["model"](x)
+    got_s = _score_tensor([t.cpu() for t in lv])
     assert float((got_s - ref_s).abs().max()) <= 1e-4
 
 
@@ -150,15 +169,15 @@ def test_full_size_configs_3_and_4(name, seg):
         for bb in range(32):
             assert torch.equal(d1[bb, :cn[bb]], d0[bb, :cn[bb]]), (rep, bb)
     orc = _oracle(meta, sd)
-    cand = [0, 13, 31]
+    cand = [0, 4, 9, 13, 18, 22, 27, 31]                               # the oracle forward costs ~1 s per image here
     with torch.no_grad():
         ref = orc(x[cand].cpu())
     ref_lv, ref_pr = (ref if seg else (ref, None))
     det_lv = [t[..., :85] for t in ref_lv]
-    sel = _safe_images(_score_tensor(det_lv), None, 0.4, range(len(cand)), need=2)
     exp = opost.pipeline_main(det_lv, 640, 0.4, 0.5, 300)
-    for i in sel:
-        _assert_north_star(_rows(d1, c1, cand[i]), exp, i)
+    pos = {b: i for i, b in enumerate(cand)}
+    safe = _assert_all_safe_images(d1, c1, exp, _score_tensor(det_lv), 0.4, cand, min_safe=3, exp_index=pos)
+    sel = [pos[b] for b in safe][:2]
     got_s = _score_tensor([t[cand].cpu() for t in la])
     assert float((got_s - _score_tensor(det_lv)).abs().max()) <= 1e-4
     # option "winograd" (dense 3x3 stride-1 convs with >= 64 channels as Winograd F(2x2,3x3): yololite_m's six FPN
@@ -200,6 +219,113 @@ def test_full_size_configs_3_and_4(name, seg):
             bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, 640, -1)[..., :640].astype(bool)
             assert np.array_equal(bits, got)
         assert tot_u > 1000, tot_u
+        # the asynchronous fixed-capacity form the benchmark uses (no host read of the counts): same bits
+        arena = torch.empty((32 * mo * 640 * 80,), device=DEV, dtype=torch.uint8)
+        va = ctx.masks_image(d2, c2, i2, packed=True, arena=arena)
+        assert va.shape == (32, mo, 640, 20)
+        for b in range(32):
+            assert torch.equal(va[b, :int(c2[b])], mp[b]), b
+
+
+def _match_detection_lists(got, exp, max_unmatched):
+    """tolerant comparison of two detection lists of ONE image at evaluation thresholds (thousands of survivors: a
+    handful of decisions sit inside the fp32 drift of the forward pass).  got / exp: (boxes [n,4], scores, classes).
+    Every oracle detection is matched to a detection of the same class whose rounded box is equal; scores of matched
+    pairs within 1e-4; at most `max_unmatched` detections on either side stay unmatched."""
+    gb, gs, gc = got
+    eb, es, ec = exp
+    from collections import defaultdict
+    idx = defaultdict(list)
+    for j in range(len(gc)):
+        idx[(int(gc[j]),) + tuple(np.rint(gb[j]).astype(np.int64).tolist())].append(j)
+    un_e, used = 0, 0
+    for i in range(len(ec)):
+        key = (int(ec[i]),) + tuple(np.rint(eb[i]).astype(np.int64).tolist())
+        c = [j for j in idx.get(key, []) if abs(float(gs[j]) - float(es[i])) <= 1e-4]
+        if c:
+            idx[key].remove(c[0]); used += 1
+        else:
+            un_e += 1
+    un_g = len(gc) - used
+    assert un_e <= max_unmatched and un_g <= max_unmatched, (len(ec), len(gc), un_e, un_g)
+
+
+def test_eval_mode_on_real_levels_at_640():
+    """the evaluation pipeline (conf 0.001 / iou 0.65, no cap: thousands of survivors per image) on a
+    REAL model's levels at 640x640 -- (i) yl_predict(POST_EVAL) == the oracle pipeline run on the HIP forward's own
+    levels: identical detection lists (every threshold / NMS decision), values to the last ulp of expf; (ii) == the oracle end to end (oracle forward) up to the handful of
+    decisions inside the forward pass's fp32 drift."""
+    wl = bench.build_workload("edge_n", 640, 8, seed=1, dev=DEV)
+    ctx, x, meta, sd, model = wl["ctx"], wl["x"], wl["meta"], wl["sd"], wl["model"]
+    lv = [t.cpu() for t in model(x)]
+    dets, counts = ctx.predict(x, _lib.POST_EVAL, 0.001, 0.65, per_class_cap=0, topk=0, max_out=ctx.N)
+    cn = counts.cpu().numpy()
+    assert cn.min() >= 1000, cn                                    # thousands of survivors
+    _, raw = opost.pipeline_eval(lv, 640, 0.001, 0.65)
+    for b in range(8):
+        gb, gs, gc = _rows(dets, counts, b)
+        eb, es, ec = raw[b]
+        assert gc.tolist() == ec.tolist(), b                       # same survivors, same NMS decisions, same order
+        np.testing.assert_allclose(gs, es, rtol=0, atol=1e-6)      # expf of the device vs torch: ulp-level
+        np.testing.assert_allclose(gb, eb, rtol=0, atol=1e-3)
+    orc = _oracle(meta, sd)
+    with torch.no_grad():
+        ref_lv = orc(x.cpu())
+    _, raw2 = opost.pipeline_eval(ref_lv, 640, 0.001, 0.65)
+    for b in range(8):
+        _match_detection_lists(_rows(dets, counts, b), raw2[b], max_unmatched=max(3, len(raw2[b][2]) // 200))
+
+
+def test_cli_evaluate_end_to_end(tmp_path):
+    """tools/evaluate.py end to end on edge_n @640 with 8 images of mixed sizes: detections.json ==
+    oracle(preprocess_albumentations -> forward -> pipeline_eval, conf 0.001 / iou 0.65).  Two comparisons, as in
+    test_eval_mode_on_real_levels_at_640: list-identical against the oracle pipeline on the HIP forward of the ORACLE's
+    pre-processed tensor (pins pre-processing, decode, NMS, [cx,cy,w,h] conversion, category_id, image ids, order),
+    tolerant against the oracle forward."""
+    from PIL import Image
+    from oracle import preproc as opre
+    wl = bench.build_workload("edge_n", 640, 1, seed=1, dev=DEV)
+    meta, sd, model = dict(wl["meta"]), wl["sd"], wl["model"]
+    meta["names"] = [f"c{i}" for i in range(80)]
+    ck = str(tmp_path / "edge_n.pt")
+    torch.save({"state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}, "meta": meta}, ck)
+    rng = np.random.RandomState(11)
+    sizes = [(480, 640), (640, 640), (360, 500), (700, 420), (640, 480), (333, 777), (512, 512), (900, 1200)]
+    (tmp_path / "imgs").mkdir()
+    imgs = []
+    for k, (h, w) in enumerate(sizes):
+        im = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        Image.fromarray(im[..., ::-1]).save(str(tmp_path / "imgs" / f"im{k}.png"))     # files are RGB; arrays are BGR
+        imgs.append(im)
+    for flag in ([], ["--debug-levels"]):                                              # fused yl_predict and the two-call form
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evaluate.py"), "--weights", ck, "--test_folder",
+                            str(tmp_path / "imgs"), "--img_size", "640", "--batch_size", "3"] + flag,
+                           cwd=str(tmp_path), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    with open(tmp_path / "runs" / "evaluate" / "1" / "detections.json") as f:
+        dj = json.load(f)
+    with open(tmp_path / "runs" / "evaluate" / "2" / "detections.json") as f:
+        assert json.load(f) == dj                                                      # the two forms agree exactly
+    orc = _oracle(meta, sd)
+    tot = 0
+    for k, im in enumerate(imgs):                                                      # sorted file order == k order
+        xx, _ = opre.preprocess_albumentations(im, 640)
+        xt = torch.from_numpy(xx[None])
+        got = [d for d in dj if d["image_id"] == k]
+        assert all(d["file_name"] == f"im{k}.png" for d in got)
+        lv = [t.cpu() for t in model(xt.to(DEV))]
+        exp, _ = opost.pipeline_eval(lv, 640, 0.001, 0.65)
+        assert [d["category_id"] for d in got] == [d["category_id"] for d in exp[0]], k
+        np.testing.assert_allclose([d["score"] for d in got], [d["score"] for d in exp[0]], rtol=0, atol=1e-6)
+        np.testing.assert_allclose([d["bbox"] for d in got], [d["bbox"] for d in exp[0]], rtol=0, atol=1e-3)   # 1-2 ulp at 640 px
+        with torch.no_grad():
+            _, raw2 = opost.pipeline_eval(orc(xt), 640, 0.001, 0.65)
+        gb = np.asarray([[d["bbox"][0] - d["bbox"][2] / 2, d["bbox"][1] - d["bbox"][3] / 2,
+                          d["bbox"][0] + d["bbox"][2] / 2, d["bbox"][1] + d["bbox"][3] / 2] for d in got], np.float64)
+        _match_detection_lists((gb, np.asarray([d["score"] for d in got]), np.asarray([d["category_id"] - 1 for d in got])),
+                               raw2[0], max_unmatched=max(3, len(got) // 200))
+        tot += len(got)
+    assert tot >= 8000, tot
 
 
 def test_config1_edge_n_640_batch1_through_cli(tmp_path):

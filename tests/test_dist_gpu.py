@@ -72,3 +72,52 @@ def test_c_abi_allgather_dets_with_a_raw_rccl_communicator():
     assert lib.yl_allgather_dets(ctx.handle, None, local.data_ptr(), row, allb.data_ptr(), st) == -1      # NULL communicator
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+def test_pipelined_gatherer_under_graph_replay_is_self_validating():
+    """the path the 8-GPU run takes -- yl_predict writing into DetGatherer's alternating slots
+    under hipGraph replay (cache of 4 graphs), ONE asynchronous all-gather per step, results read one step late --
+    driven for 60 steps at world 1 with the collective forced; EVERY step's gathered rows must equal the rows of a
+    plain (non-pipelined, eager) run of the same input."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import bench
+    from yololite_amd import _lib, dist as ydist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29741")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        wl = bench.build_workload("edge_n", 320, 8, seed=1, dev="cuda:0")
+        ctx = wl["ctx"]
+        xs = [bench.synth_images(8, 320, seed=100 + k).cuda() for k in range(3)]      # three inputs in rotation
+        mo = 256
+        ctx.set_option("graph", 0); ctx.set_option("streams", 1)
+        ref = []
+        for x in xs:
+            d, c = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
+            ref.append((d.clone(), c.clone()))
+        assert min(int(c.min()) for _, c in ref) > 0
+        ctx.set_option("graph", 1); ctx.set_option("streams", 2)
+        gat = ydist.DetGatherer(8, mo, torch.device("cuda", 0))
+        steps, checked = 60, 0
+        for k in range(steps + 1):
+            if k < steps:
+                ctx.predict(xs[k % 3], _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo, out=(gat.dets, gat.counts))
+                prev = gat.gather()                                 # the PREVIOUS step's result (None on the first)
+            else:
+                prev = gat.flush()
+            if prev is None:
+                continue
+            d, c = prev                                             # [world, b, max_out, 6], [world, b]
+            rd, rc = ref[(k - 1) % 3]
+            torch.cuda.synchronize()
+            assert torch.equal(c[0], rc), k
+            for b in range(8):
+                n = int(rc[b])
+                assert torch.equal(d[0, b, :n], rd[b, :n]), (k, b)
+            checked += 1
+        assert checked == steps
+    finally:
+        dist.destroy_process_group()

@@ -107,7 +107,7 @@ def test_forward_reference_fixture_weights(golden_dir):
         for j, o in enumerate(outs):
             r = z[f"{tag}/out{j}"]
             err = np.abs(o.cpu().numpy() - r).max()
-            assert err <= 1e-4 + 1e-4 * np.abs(r).max(), (tag, j, err)
+            assert err <= 2e-4 + 2e-6 * np.abs(r).max(), (tag, j, err)       # the bound of _cmp_levels (implies 1e-4 on a score)
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_n", 2, 640), ("edge_m", 1, 320), ("yololite_m", 1, 256),
@@ -189,13 +189,13 @@ def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_n", 3, 320), ("edge_n", 2, 640), ("edge_m", 2, 320), ("yololite_m", 1, 256)])
-def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
+def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S, monkeypatch):
     """Alternative kernels of yl_convc.hip sum every output's k blocks in the same order as the kernels they replace
     -> identical bits.  "tile_m" 6: wave-autonomous 1x1 / depthwise kernels and the streamed dense 3x3 kernel OFF; 7:
     producer / consumer depthwise -> 1x1 kernel (opt-in) ON, with YL_DWC_ALL=1 on every layer shape it supports.
     Exception: yl_conv_kxk_kernel (yololite_m's dense 3x3) walks K channel-block-major instead of tap-major (cache
     locality), a different fp32 summation order of the same 2952 products: compared at rounding-noise tolerance."""
-    os.environ["YL_DWC_ALL"] = "1"
+    monkeypatch.setenv("YL_DWC_ALL", "1")          # this test only: the opt-in kernel on every shape it supports
     meta = zoo_meta(name, 80, S)
     sd = synth_state_dict(meta, seed=4)
     m = _hip_for(meta, sd)
@@ -583,6 +583,21 @@ def test_cli_infer_and_evaluate(tmp_path, golden_dir):
                         str(tmp_path / "imgs"), "--batch_size", "2"], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.splitlines()[0])["detections"] > 0
+    # detections.json == the oracle flow of the evaluate path (preprocess_albumentations -> forward ->
+    # pipeline_eval at conf 0.001 / iou 0.65; helpers.py:87-153): identical lists on the HIP forward of the oracle's tensor
+    from oracle import preproc as opre
+    with open(tmp_path / "runs" / "evaluate" / "1" / "detections.json") as f:
+        dj = json.load(f)
+    mdl, _, S0 = ya.load_model_names_imgsize_from_ckpt(ck, torch.device(DEV))
+    for k, name in enumerate(("sq", "wide")):                       # sorted file order
+        xx, _ = opre.preprocess_albumentations(z[f"img_{name}"], S0)
+        lv = [t.cpu() for t in mdl(torch.from_numpy(xx[None]).to(DEV))]
+        exp, _ = opost.pipeline_eval(lv, S0, 0.001, 0.65)
+        got = [d for d in dj if d["image_id"] == k]
+        assert len(got) > 0 and all(d["file_name"] == f"{name}.png" for d in got)
+        assert [d["category_id"] for d in got] == [d["category_id"] for d in exp[0]], name
+        np.testing.assert_allclose([d["score"] for d in got], [d["score"] for d in exp[0]], rtol=0, atol=1e-6)
+        np.testing.assert_allclose([d["bbox"] for d in got], [d["bbox"] for d in exp[0]], rtol=0, atol=1e-3)   # 1-2 ulp at 640 px
     # dataset layout with YOLO labels: images/ + labels/ -> device P/R/F1 curves + confusion matrix stats
     ds = tmp_path / "ds"
     (ds / "images").mkdir(parents=True); (ds / "labels").mkdir()
@@ -652,7 +667,10 @@ def test_preprocess_bit_exact_vs_oracle(S):
             ref, geo = opre.preprocess_albumentations(im, S, resize=not lb)
             np.testing.assert_array_equal(x3[i].cpu().numpy(), ref)
             assert tuple(bm3[i]) == tuple(float(v) for v in geo)
-    assert not np.array_equal(x3[0].cpu().numpy(), x2[0].cpu().numpy()) or True
+    # the two arithmetics really differ ((u8/255 - mean)/std vs (u8 - 255 mean) * (1 / (255 std))): same geometry
+    # (image 0, --no_letterbox), values within float rounding of each other but not all bit-equal
+    a3, a2 = x3[0].cpu().numpy(), x2[0].cpu().numpy()
+    assert not np.array_equal(a3, a2) and float(np.abs(a3 - a2).max()) < 1e-5
     ya.preprocess_batch(ctx, imgs[:1])                                  # back to the infer arithmetic
 
 
@@ -722,3 +740,96 @@ def test_seg_model_forward_and_masks(name, B, S):
     for b in range(B):
         d = dets[b, :cn[b]].cpu().numpy()
         _match(d[:, :4], d[:, 4], d[:, 5].astype(np.int64), exp_det["boxes"][b], exp_det["scores"][b], exp_det["classes"][b])
+
+
+def test_batch_size_changes_keep_buffers_graphs_and_mask_inputs():
+    """activation capacity only grows.  Alternating batch sizes (a tail batch, B = 4 / 16) replay
+    their own cached hipGraphs with unchanged results and unchanged memory; yl_masks_image refuses a batch larger than
+    the last forward's (its level buffers / prototypes would be another batch's), and works again after that batch."""
+    from yololite_amd.program import MODEL_ZOO
+    S = 256
+    meta = make_meta(num_classes=80, img_size=S, seg=True, **MODEL_ZOO["edge_n"])
+    sd = synth_state_dict(meta, seed=3, head_noise=2.0)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    xs = {16: _x(16, S, seed=21).to(DEV), 4: _x(4, S, seed=22).to(DEV), 7: _x(7, S, seed=23).to(DEV)}
+    ctx.set_option("graph", 1)
+    ref, mem = {}, None
+    for rnd in range(3):
+        for B in (16, 4, 7, 16, 4):
+            d, c, i = ctx.predict(xs[B], _lib.POST_MAIN, 0.05, 0.5, per_class_cap=300, want_idx=True)
+            got = (d.clone(), c.clone())
+            if B not in ref:
+                ref[B] = got
+            assert torch.equal(got[1], ref[B][1]), (rnd, B)
+            for b in range(B):
+                n = int(got[1][b])
+                assert torch.equal(got[0][b, :n], ref[B][0][b, :n]), (rnd, B, b)
+            if mem is None:
+                mem = ctx.activation_bytes()                       # allocated for the largest batch first
+            assert ctx.activation_bytes() == mem, (rnd, B)         # a smaller batch re-plans inside the allocation
+            mk = ctx.masks_image(d, c, i, packed=True)             # the batch that just ran: fine
+            assert len(mk) == B
+    d16, c16, i16 = ctx.predict(xs[16], _lib.POST_MAIN, 0.05, 0.5, per_class_cap=300, want_idx=True)
+    m16 = [t.clone() for t in ctx.masks_image(d16, c16, i16, packed=True)]
+    ctx.predict(xs[4], _lib.POST_MAIN, 0.05, 0.5, per_class_cap=300)
+    with pytest.raises(_lib.YoloLiteHipError):                     # level buffers now hold the B = 4 batch
+        ctx.masks_image(d16, c16, i16, packed=True)
+    d16b, c16b, i16b = ctx.predict(xs[16], _lib.POST_MAIN, 0.05, 0.5, per_class_cap=300, want_idx=True)
+    for a, b in zip(m16, ctx.masks_image(d16b, c16b, i16b, packed=True)):
+        assert torch.equal(a, b)
+    ctx.set_option("graph", 0)
+
+
+def test_pip_api_predict_on_a_seg_checkpoint(tmp_path):
+    """YoloLite(path).predict() on a (build-defined) seg checkpoint -- `masks` is a list of
+    [N_i, h0, w0] arrays at the ORIGINAL image sizes (README.md:38-42), equal to the oracle's masks_image_for on the
+    oracle's levels / prototypes through the same letterbox (mask IoU >= 0.999); the shared context is left in its
+    default mode (time_split restored)."""
+    from yololite_amd.api import YoloLite
+    from yololite_amd.program import MODEL_ZOO
+    from oracle import preproc as opre
+    S = 320
+    meta = make_meta(num_classes=80, img_size=S, seg=True, **MODEL_ZOO["edge_n"])
+    meta["names"] = [f"c{i}" for i in range(80)]
+    sd = synth_state_dict(meta, seed=3, head_noise=2.0)
+    for k, v in sd.items():                      # boxes a few strides wide, else the masks are empty
+        if k.endswith(".out.box.bias"):
+            v[2::4] += 3.0
+            v[3::4] += 3.0
+    ck = str(tmp_path / "seg.pt")
+    torch.save({"state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}, "meta": meta}, ck)
+    rng = np.random.RandomState(2)
+    imgs = [rng.randint(0, 256, size=hw + (3,)).astype(np.uint8) for hw in ((240, 320), (400, 250), (320, 320))]
+    yl = YoloLite(ck, device=DEV)
+    res = yl.predict(imgs, conf=0.05)
+    ctx = yl.model._ctx_for(S)
+    assert ctx.get_option("time_split", 0) == 0
+    orc = _oracle_for(meta, sd)
+    tot = 0
+    for im, r in zip(imgs, res):
+        h0, w0 = im.shape[:2]
+        n = len(r["scores"])
+        assert n > 3 and r["masks"].shape == (n, h0, w0) and r["masks"].dtype == np.uint8
+        xx, (padx, pady, scale, _, _) = opre.preprocess(im, S)
+        with torch.no_grad():
+            lv, pr = orc(torch.from_numpy(xx[None]))
+        # the oracle's own detections of this image must be the API's (same candidates -> same coefficients)
+        exp = opost.pipeline_main([t[..., :85] for t in lv], S, 0.05, 0.5, 300)
+        if exp["classes"][0].tolist() != r["classes"].tolist():
+            continue                                               # a threshold / NMS decision inside the fp32 drift
+        dec = opost.decode_levels([t[..., :85] for t in lv], S)
+        sc, _ = opost.score_candidates(dec["obj"][0].squeeze(-1), dec["cls"][0])
+        # candidate index of every detection: match decoded + back-mapped boxes (unique with overwhelming probability)
+        bm_boxes = opost.backmap(dec["box"][0].numpy().copy(), padx, pady, scale, w0, h0)
+        keep = []
+        for bb, ss in zip(r["boxes"], r["scores"]):
+            d = np.abs(bm_boxes - bb[None]).max(1) + np.abs(sc.numpy() - ss)
+            keep.append(int(d.argmin()))
+        em = opost.masks_image_for(lv, pr, 80, S, [np.asarray(keep)], [r["boxes"]], [(h0, w0)],
+                                   backmap=[(padx, pady, scale, w0, h0)])[0].astype(bool)
+        g = r["masks"].astype(bool)
+        inter, union = (g & em).sum(), (g | em).sum()
+        assert union == 0 or inter / union >= 0.999, (inter, union)
+        tot += int(union)
+    assert tot > 100, tot

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--batch_size", type=int, default=8)
     ap.add_argument("--no_letterbox", action="store_true")
     ap.add_argument("--out", default="runs/evaluate")
+    ap.add_argument("--debug-levels", action="store_true", help="model(x) then _decode_batch_to_coco_dets (raw level "
+                    "tensors materialised, as the reference does) instead of ONE fused yl_predict call; same detections")
     args = ap.parse_args()
 
     import yololite_amd as ya
@@ -74,19 +76,23 @@ def main():
                                       "bbox": bb, "area": float(max(0.0, bb[2] * bb[3])), "iscrowd": 0})
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        preds = model(x)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        if args.debug_levels:       # the reference's two calls: raw level tensors, then _decode_batch_to_coco_dets
+            preds = model(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dets = ya._decode_batch_to_coco_dets(preds, S, conf_th=0.001, iou_th=0.65, add_one=True)
+        else:                       # ONE fused yl_predict call (forward + decode + NMS), the path bench.py measures
+            dets = ya.predict_coco_dets(ctx, x, conf_th=0.001, iou_th=0.65, add_one=True)
+            t1 = time.perf_counter()
         if i // args.batch_size >= 2 and len(fwd_ms) < 10:          # evaluate.py:253-303 protocol
             fwd_ms.append((t1 - t0) * 1e3); fwd_imgs += len(chunk)
-        dets = ya._decode_batch_to_coco_dets(preds, S, conf_th=0.001, iou_th=0.65, add_one=True)
         for j, dl in enumerate(dets):
             for d in dl:
                 coco_dets.append(dict(d, image_id=i + j, file_name=os.path.basename(chunk[j])))
     with open(Path(run_dir) / "detections.json", "w") as f:
         json.dump(coco_dets, f)
     summary = {"images": len(paths), "detections": len(coco_dets), "img_size": S,
-               "gpu_forward_ms_per_img": (sum(fwd_ms) / fwd_imgs) if fwd_imgs else None}
+               ("gpu_forward_ms_per_img" if args.debug_levels else "gpu_predict_ms_per_img"): (sum(fwd_ms) / fwd_imgs) if fwd_imgs else None}
     if coco_anns:
         # evaluate.py:480-489: P/R/F1 curves, then the confusion matrix at the best-F1 confidence -- on the device
         from yololite_amd import evalops

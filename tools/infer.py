@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--save_txt", action="store_true")
     ap.add_argument("--no_letterbox", action="store_true")
     ap.add_argument("--batch", type=int, default=16, help="images per HIP launch (the reference runs one at a time)")
+    ap.add_argument("--debug-levels", action="store_true", help="materialise the raw level tensors: model(x) then the "
+                    "post-processing call, as the reference does (default: ONE fused yl_predict call, same detections)")
     args = ap.parse_args()
 
     import yololite_amd as ya
@@ -98,8 +100,11 @@ def main():
         if not imgs:
             continue
         x, bms = ya.preprocess_batch(ctx, imgs, letterbox=not args.no_letterbox)     # letterbox + normalise on the GPU
-        outs = model(x)
-        res = ya.infer_main_postprocess(outs, S, args.conf, args.iou, backmap=bms)
+        if args.debug_levels:
+            outs = model(x)
+            res = ya.infer_main_postprocess(outs, S, args.conf, args.iou, backmap=bms)
+        else:       # the path bench.py measures: decode inside the head-output convs, no raw level tensors
+            res = ya.predict_main(ctx, x, args.conf, args.iou, backmap=bms)
         for j, (pth, (h, w)) in enumerate(ok):
             b, s, c = res["boxes"][j], res["scores"][j], res["classes"][j]
             if args.save_txt and b.size > 0:

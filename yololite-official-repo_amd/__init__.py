@@ -9,7 +9,7 @@ from ._lib import YoloLiteHipError, load as load_library  # noqa: F401
 from .model import (HipContext, YOLOLiteHIP, build_model_from_meta,  # noqa: F401
                     load_model_names_imgsize_from_ckpt)
 from .postprocess import (_decode_batch_to_coco_dets, decode_anchorfree_like_train,  # noqa: F401
-                          decode_preds_anchorfree, infer_main_postprocess, nms)
+                          decode_preds_anchorfree, infer_main_postprocess, nms, predict_coco_dets, predict_main)
 from .preprocess import letterbox_geometry, preprocess_batch  # noqa: F401
 from .program import BACKBONES, Program, build_program  # noqa: F401
 from .evalops import build_curves_from_coco, create_confusion_matrix  # noqa: F401
@@ -17,6 +17,6 @@ from .tracker import KalmanSortTracker, TrackerBank  # noqa: F401
 
 __all__ = ["YoloLiteHipError", "load_library", "HipContext", "YOLOLiteHIP", "build_model_from_meta",
            "load_model_names_imgsize_from_ckpt", "decode_preds_anchorfree", "_decode_batch_to_coco_dets",
-           "decode_anchorfree_like_train", "infer_main_postprocess", "nms", "build_program", "Program", "BACKBONES",
+           "decode_anchorfree_like_train", "infer_main_postprocess", "nms", "predict_main", "predict_coco_dets", "build_program", "Program", "BACKBONES",
            "preprocess_batch", "letterbox_geometry", "build_curves_from_coco", "create_confusion_matrix",
            "KalmanSortTracker", "TrackerBank"]

@@ -41,21 +41,28 @@ class YoloLite:
         bm[:, 2] = np.maximum(bm[:, 2], 1e-6)
         bm = bm.astype(np.float32)
         t1 = time.perf_counter()
+        # "time_split" is a measurement aid on the model's SHARED context (single chunk, eager launches, no overlap):
+        # set for this call only and put back, so that model(x) / ctx.predict callers never inherit it
+        prev_split = ctx.get_option("time_split", 0)
         ctx.set_option("time_split", 1 if profile else 0)
         masks = None
-        if ctx.NM:                                              # build-defined seg model: masks at ORIGINAL image resolution
-            dets, counts, idx = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300,
-                                            backmap=torch.from_numpy(bm), want_idx=True)
-            masks = [m.cpu().numpy() for m in ctx.masks_image(dets, counts, idx, backmap=torch.from_numpy(bm))]
-        else:
-            dets, counts = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300, backmap=torch.from_numpy(bm))
+        try:
+            if ctx.NM:                                          # build-defined seg model: masks at ORIGINAL image resolution
+                dets, counts, idx = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300,
+                                                backmap=torch.from_numpy(bm), want_idx=True)
+                masks = [m.cpu().numpy() for m in ctx.masks_image(dets, counts, idx, backmap=torch.from_numpy(bm))]
+            else:
+                dets, counts = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=300, backmap=torch.from_numpy(bm))
+            timing = ctx.last_timing() if profile else None
+        finally:
+            ctx.set_option("time_split", prev_split)
         cn = counts.cpu().numpy()
         d = dets.cpu().numpy()
         t2 = time.perf_counter()
         n = len(imgs)
         speed = {"pre_ms": (t1 - t0) * 1e3 / n}
         if profile:
-            infer_ms, post_ms = ctx.last_timing()
+            infer_ms, post_ms = timing
             speed.update(infer_ms=infer_ms / n, post_ms=post_ms / n)
             speed["total_ms"] = speed["pre_ms"] + speed["infer_ms"] + speed["post_ms"]
         else:

@@ -50,13 +50,15 @@ struct yl_ctx {
   std::vector<Slot> slots;
   std::vector<DevLayer> layers;
   float* zeros = nullptr;                  // 256 zero bytes (padding source for the conv kernels)
-  int cap_batch = 0;                       // activations are planned for exactly this batch ...
+  int cap_batch = 0;                       // images the pinned slots / level buffers are allocated for (capacity)
+  int act_batch = 0;                       // batch of the last forward: what yl_masks* / yl_read_slot may address
   // Activation memory: ONE arena per batch chunk (chunks run concurrently on their own streams), slots placed by
   // liveness -- a slot's bytes are reused by later tensors once its last consumer (launch group) has run.  edge_n,
   // B = 64: 3.8 GB with one buffer per tensor -> a few hundred MB, so that a chunk's producer -> consumer pairs have
   // a chance to meet in the 256 MB Infinity Cache instead of HBM.  "reuse_slots" 0 keeps every tensor (debugging).
   char* arena[4] = {nullptr, nullptr, nullptr, nullptr};
-  int plan_n = 0;                          // ... split into this many chunks
+  int plan_n = 0;                          // the current job's batch is split into this many chunks
+  int arena_n = 0, arena_cap = 0;          // allocated: arenas, images per arena (capacity; plan_n / plan_cap <= these)
   int plan_b0[5] = {0, 0, 0, 0, 0};        // chunk i covers images [plan_b0[i], plan_b0[i + 1])
   int plan_cap = 0;                        // images of the largest chunk
   size_t arena_unit = 0;                   // arena bytes per image of a chunk (peak of the live set)
@@ -261,7 +263,7 @@ void free_act(yl_ctx* c) {
   for (int i = 0; i < 4; ++i) { hipFree(c->arena[i]); c->arena[i] = nullptr; }
   for (auto& s : c->slots) { hipFree(s.pin); s.pin = nullptr; }
   for (int l = 0; l < YL_MAX_LEVELS; ++l) { hipFree(c->level_buf[l]); c->level_buf[l] = nullptr; }
-  c->cap_batch = 0; c->plan_n = 0;
+  c->cap_batch = 0; c->plan_n = 0; c->arena_n = 0; c->arena_cap = 0; c->act_batch = 0;
 }
 
 int pow2ceil(int v) { int p = 64; while (p < v) p <<= 1; return p; }
@@ -357,28 +359,42 @@ yl_status ensure_act(yl_ctx* c, int B, int n) {
   const bool flat = c->opt_hybrid || c->opt_lanes;
   if (flat) n = 1;
   const bool reuse = c->opt_reuse && !flat;
-  if (B == c->cap_batch && n == c->plan_n && reuse == c->plan_reuse) return YL_OK;
-  free_act(c);
-  c->plan_reuse = reuse;
-  plan_slots(c, reuse);
-  const int base = B / n, rem = B % n;
-  int b0 = 0;
-  c->plan_cap = 0;
-  for (int i = 0; i < n; ++i) {
-    const int bn = base + (i < rem ? 1 : 0);
-    c->plan_b0[i] = b0;
-    b0 += bn;
-    if (bn > c->plan_cap) c->plan_cap = bn;
+  // the chunk split of THIS job
+  int b0s[5] = {0, 0, 0, 0, 0}, cap = 0;
+  {
+    const int base = B / n, rem = B % n;
+    int b0 = 0;
+    for (int i = 0; i < n; ++i) {
+      const int bn = base + (i < rem ? 1 : 0);
+      b0s[i] = b0;
+      b0 += bn;
+      if (bn > cap) cap = bn;
+    }
+    b0s[n] = B;
   }
-  c->plan_b0[n] = B;
-  for (int i = 0; i < n; ++i)
-    if (c->arena_unit) HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)c->plan_cap));
-  for (auto& s : c->slots)
-    if (s.pinned) HIPCHK(c, hipMalloc((void**)&s.pin, s.sz * (size_t)B));
-  for (int l = 0; l < c->L; ++l)
-    HIPCHK(c, hipMalloc((void**)&c->level_buf[l],
-                        (size_t)B * c->level_A[l] * c->level_S[l] * c->level_S[l] * c->E * sizeof(float)));
-  c->cap_batch = B; c->plan_n = n;
+  // CAPACITY only grows: a smaller batch (a tail batch, alternating B = 4 / 16, a "time_split" toggle) re-plans its
+  // chunk ranges inside the existing allocations -- no hipFree (a device sync), no dropped hipGraphs (their keys carry
+  // the batch, so graphs of several batch sizes live side by side in the LRU), and the level buffers / prototypes of
+  // the previous batch stay where yl_masks* reads them.  Slot addresses inside an arena scale with plan_cap
+  // (slot_addr), i.e. a job's addresses are a function of (B, n) as long as the allocation does not move.
+  if (B > c->cap_batch || n > c->arena_n || cap > c->arena_cap || reuse != c->plan_reuse || c->arena_n == 0) {
+    const int newB = B > c->cap_batch ? B : c->cap_batch, newn = n > c->arena_n ? n : c->arena_n;
+    const int newcap = cap > c->arena_cap ? cap : c->arena_cap;
+    free_act(c);                                             // also drops the cached graphs (addresses change)
+    c->plan_reuse = reuse;
+    plan_slots(c, reuse);
+    for (int i = 0; i < newn; ++i)
+      if (c->arena_unit) HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)newcap));
+    for (auto& s : c->slots)
+      if (s.pinned) HIPCHK(c, hipMalloc((void**)&s.pin, s.sz * (size_t)newB));
+    for (int l = 0; l < c->L; ++l)
+      HIPCHK(c, hipMalloc((void**)&c->level_buf[l],
+                          (size_t)newB * c->level_A[l] * c->level_S[l] * c->level_S[l] * c->E * sizeof(float)));
+    c->cap_batch = newB; c->arena_n = newn; c->arena_cap = newcap;
+  }
+  c->plan_n = n; c->plan_cap = cap;
+  for (int i = 0; i <= n; ++i) c->plan_b0[i] = b0s[i];
+  c->act_batch = B;
   return YL_OK;
 }
 
@@ -1171,7 +1187,7 @@ yl_status yl_last_timing(yl_ctx* c, float* infer_ms, float* post_ms) {
 
 int64_t yl_activation_bytes(const yl_ctx* c) {
   if (!c || c->plan_n < 1) return 0;
-  int64_t t = (int64_t)c->arena_unit * c->plan_cap * c->plan_n;
+  int64_t t = (int64_t)c->arena_unit * c->arena_cap * c->arena_n;
   for (const auto& s : c->slots)
     if (s.pinned) t += (int64_t)s.sz * c->cap_batch;
   return t;
@@ -1180,7 +1196,7 @@ int64_t yl_activation_bytes(const yl_ctx* c) {
 yl_status yl_read_slot(yl_ctx* c, int32_t slot, int32_t B, float* dst, void* stream) {
   if (!c || !dst) return YL_ERR_INVALID;
   if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, YL_ERR_INVALID, "bad slot");
-  if (B > c->cap_batch || c->plan_n < 1) return fail(c, YL_ERR_STATE, "no forward has produced this slot");
+  if (B > c->act_batch || c->plan_n < 1) return fail(c, YL_ERR_STATE, "no forward of >= B images has produced this slot");
   HIPCHK(c, hipSetDevice(c->device));
   const Slot& s = c->slots[slot];
   // (with "reuse_slots" on, a tensor that is not an output of the network may have been overwritten by later layers)
@@ -1238,7 +1254,7 @@ yl_status yl_masks(yl_ctx* c, const float* const* levels, int32_t B, const int32
                    int32_t max_out, float thr, uint8_t* masks, void* stream) {
   if (!c || !counts || !keep_idx || !masks || B < 1 || max_out < 1) return YL_ERR_INVALID;
   if (c->NM <= 0 || c->proto_slot < 0) return fail(c, YL_ERR_STATE, "context has no mask branch");
-  if (B > c->cap_batch || B > c->post_cap_batch || !c->slots[c->proto_slot].pin)
+  if (B > c->act_batch || B > c->post_cap_batch || !c->slots[c->proto_slot].pin)
     return fail(c, YL_ERR_STATE, "yl_masks needs a preceding yl_predict / yl_forward+yl_postprocess of this batch");
   HIPCHK(c, hipSetDevice(c->device));
   const float* lp[YL_MAX_LEVELS];
@@ -1258,7 +1274,7 @@ yl_status yl_masks_image(yl_ctx* c, const float* const* levels, int32_t B, const
   if (!c || !dets || !counts || !keep_idx || !out_hw || !mask_off || !masks || B < 1 || max_out < 1 || max_h < 1 || max_w < 1)
     return YL_ERR_INVALID;
   if (c->NM <= 0 || c->proto_slot < 0) return fail(c, YL_ERR_STATE, "context has no mask branch");
-  if (B > c->cap_batch || !c->slots[c->proto_slot].pin)
+  if (B > c->act_batch || !c->slots[c->proto_slot].pin)
     return fail(c, YL_ERR_STATE, "yl_masks_image needs a preceding yl_predict / yl_forward of this batch");
   HIPCHK(c, hipSetDevice(c->device));
   const float* lp[YL_MAX_LEVELS];

@@ -1546,7 +1546,7 @@ hipError_t yl_launch_conv_dwc(YlConvMulti& m, hipStream_t st) {
   // long -- K >= 192 channels on a stride-1 depthwise (28 vs 38 us for 3x3, 44 vs 50 us for 5x5 at 20x20) -- and
   // loses on the short-K layers, where two or three of the four depthwise waves idle and the per-tile barrier costs
   // more than the weight prologue it replaces.  YL_DWC_ALL=1 lifts the restriction (A/B runs).
-  static const bool all = getenv("YL_DWC_ALL") != nullptr;
+  const bool all = getenv("YL_DWC_ALL") != nullptr;     // read per launch: tests set it for ONE case (monkeypatch)
   if (!all && (p.KB < 12 || p.dw_stride != 1)) return hipErrorNotSupported;
   if (!((p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2))) return hipErrorNotSupported;
   const int HP = 3 * p.dw_stride + p.dw_k;

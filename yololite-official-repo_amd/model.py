@@ -122,7 +122,17 @@ class HipContext:
         return out
 
     def set_option(self, name: str, value: int):
+        """yl_set_option.  A value that is already set is not sent again: the library drops its cached hipGraphs on
+        every option write."""
+        opts = self.__dict__.setdefault("_opts", {})
+        if opts.get(name) == int(value):
+            return
         _lib.check(self.lib.yl_set_option(self.handle, name.encode(), int(value)), self.handle, "yl_set_option")
+        opts[name] = int(value)
+
+    def get_option(self, name: str, default: int = 0) -> int:
+        """the value last written through set_option (the library's defaults are 0 for the measurement aids)"""
+        return self.__dict__.get("_opts", {}).get(name, default)
 
     # ---- forward
     def forward(self, x: torch.Tensor, timed: bool = False):

@@ -76,13 +76,10 @@ def decode_anchorfree_like_train(preds, img_size: int, conf_th: float = 0.35, io
             "classes": [torch.from_numpy(r[:, 5].astype(np.int64)).to(dev) for r in rows]}
 
 
-@torch.no_grad()
-def _decode_batch_to_coco_dets(preds, img_size, conf_th=0.001, iou_th=0.65, add_one=True):
-    lv = _levels_list(preds)
-    ctx = context_for(lv, img_size)
-    dets, counts = ctx.postprocess(lv, _lib.POST_EVAL, conf_th, iou_th, per_class_cap=0, topk=0, max_out=ctx.N)
+def _rows_to_coco(rows, add_one=True):
+    """packed detection rows (x1,y1,x2,y2,score,class) per image -> the reference's COCO dicts (helpers.py:139-151)"""
     out = []
-    for r in _split(dets, counts, ctx.N):
+    for r in rows:
         # helpers.py:58-83 `_xyxy_to_xywh` returns [cx, cy, w, h] (sic)
         w = np.maximum(r[:, 2] - r[:, 0], np.float32(0))
         h = np.maximum(r[:, 3] - r[:, 1], np.float32(0))
@@ -92,6 +89,43 @@ def _decode_batch_to_coco_dets(preds, img_size, conf_th=0.001, iou_th=0.65, add_
         out.append([{"category_id": int(c), "bbox": [float(a), float(b), float(c_), float(d)], "score": float(s)}
                     for a, b, c_, d, s, c in zip(cx, cy, w, h, r[:, 4], cid)])
     return out
+
+
+@torch.no_grad()
+def _decode_batch_to_coco_dets(preds, img_size, conf_th=0.001, iou_th=0.65, add_one=True):
+    lv = _levels_list(preds)
+    ctx = context_for(lv, img_size)
+    dets, counts = ctx.postprocess(lv, _lib.POST_EVAL, conf_th, iou_th, per_class_cap=0, topk=0, max_out=ctx.N)
+    return _rows_to_coco(_split(dets, counts, ctx.N), add_one)
+
+
+@torch.no_grad()
+def predict_coco_dets(ctx: HipContext, x: torch.Tensor, conf_th=0.001, iou_th=0.65, add_one=True):
+    """model(x) + _decode_batch_to_coco_dets in ONE call (yl_predict: decode inside the head-output convs, no raw level
+    tensors) -- what tools/evaluate.py runs; same rows as the two-call form (test_fused_decode_epilogue_...)."""
+    dets, counts = ctx.predict(x, _lib.POST_EVAL, conf_th, iou_th, per_class_cap=0, topk=0, max_out=ctx.N)
+    return _rows_to_coco(_split(dets, counts, ctx.N), add_one)
+
+
+def _backmap_tensor(backmap):
+    if backmap is None:
+        return None
+    arr = np.asarray(backmap, dtype=np.float64).reshape(len(backmap), 5).copy()
+    arr[:, 2] = np.maximum(arr[:, 2], 1e-6)
+    return torch.from_numpy(arr.astype(np.float32))
+
+
+@torch.no_grad()
+def predict_main(ctx: HipContext, x: torch.Tensor, conf: float = 0.4, iou: float = 0.5, per_class_cap: int = 300,
+                 backmap: Optional[Sequence[Sequence[float]]] = None):
+    """model(x) + infer_main_postprocess in ONE call (yl_predict) -- what tools/infer.py runs, the path bench.py
+    measures.  Same return value as infer_main_postprocess."""
+    max_out = ctx.default_max_out(_lib.POST_MAIN, per_class_cap, 0)
+    dets, counts = ctx.predict(x, _lib.POST_MAIN, conf, iou, per_class_cap=per_class_cap, max_out=max_out,
+                               backmap=_backmap_tensor(backmap))
+    rows = _split(dets, counts, max_out)
+    return {"boxes": [r[:, :4].copy() for r in rows], "scores": [r[:, 4].copy() for r in rows],
+            "classes": [r[:, 5].astype(np.int64) for r in rows]}
 
 
 @torch.no_grad()
@@ -111,11 +145,7 @@ def infer_main_postprocess(preds, img_size: int, conf: float = 0.4, iou: float =
     Returns {"boxes","scores","classes"} lists of numpy arrays (classes int64)."""
     lv = _levels_list(preds)
     ctx = context_for(lv, img_size, num_masks)
-    bm = None
-    if backmap is not None:
-        arr = np.asarray(backmap, dtype=np.float64).reshape(len(backmap), 5).copy()
-        arr[:, 2] = np.maximum(arr[:, 2], 1e-6)
-        bm = torch.from_numpy(arr.astype(np.float32))
+    bm = _backmap_tensor(backmap)
     max_out = ctx.default_max_out(_lib.POST_MAIN, per_class_cap, 0)
     dets, counts = ctx.postprocess(lv, _lib.POST_MAIN, conf, iou, per_class_cap=per_class_cap, max_out=max_out, backmap=bm)
     rows = _split(dets, counts, max_out)
