@@ -2,7 +2,7 @@
 """Build libyololite_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
 seven translation units (two of them compiled twice: fp32 and bf16-MFMA builds), one shared library with a plain C ABI (include/yololite_hip.h).
 
-    python yololite-official-repo_amd/csrc/build.py [--force]
+    python yololite-official-repo_amd/csrc/build.py [--force | --asan]
 """
 import os
 import subprocess
@@ -47,6 +47,34 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def build_asan(verbose=True):
+    """AddressSanitizer build of the HOST side: libyololite_hip_asan.so next to the normal library --
+    every translation unit compiled with -fsanitize=address on the host pass only (-fno-gpu-sanitize: the gfx950 code
+    objects are the production ones).  Run the host-logic / symbol tests under it with
+        LD_PRELOAD=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so) \
+        ASAN_OPTIONS=detect_leaks=0 YOLOLITE_HIP_LIB=.../libyololite_hip_asan.so python -m pytest tests -m "not gpu"
+    (round 3: 11 host tests clean).  Meant for the host logic on a CPU box: with the HIP runtime live under the ASAN
+    interceptors the -m gpu suite crawls (4 tests in 20 minutes on the MI355X box) -- do not spend GPU time on it.
+    Delete the library afterwards (28 MB; it would travel with every gpurun snapshot)."""
+    hipcc = _hipcc()
+    obj = os.path.join(HERE, "_obj_asan")
+    os.makedirs(obj, exist_ok=True)
+    out = os.path.join(os.path.dirname(HERE), "libyololite_hip_asan.so")
+    san = ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-fno-omit-frame-pointer", "-g"]
+    cmds = [[hipcc] + COMMON + extra + san + ["-c", os.path.join(HERE, src), "-o", os.path.join(obj, oname)]
+            for src, extra, oname in UNITS]
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(run, cmds))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan",
+         "-o", out] + [os.path.join(obj, oname) for _, _, oname in UNITS])
+    return out
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -72,4 +100,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_asan() if "--asan" in sys.argv else build(force="--force" in sys.argv))

@@ -420,23 +420,25 @@ yl_status yl_track_grow(yl_tracker* t, int32_t new_max_tracks) {
   if (hipSetDevice(t->device) != hipSuccess) return YL_ERR_HIP;
   if (hipDeviceSynchronize() != hipSuccess) return YL_ERR_HIP;
   const size_t S = (size_t)t->S, To = (size_t)t->T, Tn = (size_t)new_max_tracks;
-  auto grow = [&](void** ptr, size_t elem_bytes) -> bool {
-    void* nw = nullptr;
-    if (hipMalloc(&nw, S * Tn * elem_bytes) != hipSuccess) return false;
-    if (hipMemset(nw, 0, S * Tn * elem_bytes) != hipSuccess ||
-        hipMemcpy2D(nw, Tn * elem_bytes, *ptr, To * elem_bytes, To * elem_bytes, S, hipMemcpyDeviceToDevice) != hipSuccess) {
-      hipFree(nw);
-      return false;
-    }
-    hipFree(*ptr);
-    *ptr = nw;
-    return true;
-  };
-  for (int k = 0; k < 2; ++k) {
-    if (!grow((void**)&t->x[k], 7 * sizeof(float)) || !grow((void**)&t->P[k], 49 * sizeof(float)) ||
-        !grow((void**)&t->score[k], sizeof(float)) || !grow((void**)&t->meta[k], 5 * sizeof(int)))
-      return YL_ERR_NOMEM;     // arrays already grown keep their (larger) size; T is unchanged, the bank stays valid
+  // all eight new arrays first, the swap only when every allocation and copy has succeeded: on failure the bank is
+  // untouched (arrays grown one by one would leave row pitches Tn and To mixed under an unchanged T -- wrong rows for
+  // every stream >= 1)
+  void** ptrs[8] = {(void**)&t->x[0], (void**)&t->P[0], (void**)&t->score[0], (void**)&t->meta[0],
+                    (void**)&t->x[1], (void**)&t->P[1], (void**)&t->score[1], (void**)&t->meta[1]};
+  const size_t eb[4] = {7 * sizeof(float), 49 * sizeof(float), sizeof(float), 5 * sizeof(int)};
+  void* nw[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ok = true;
+  for (int k = 0; k < 8 && ok; ++k) {
+    const size_t e = eb[k & 3];
+    ok = hipMalloc(&nw[k], S * Tn * e) == hipSuccess && hipMemset(nw[k], 0, S * Tn * e) == hipSuccess &&
+         hipMemcpy2D(nw[k], Tn * e, *ptrs[k], To * e, To * e, S, hipMemcpyDeviceToDevice) == hipSuccess;
   }
+  if (!ok) {
+    for (int k = 0; k < 8; ++k) hipFree(nw[k]);
+    (void)hipGetLastError();
+    return YL_ERR_NOMEM;       // nothing was swapped: the bank is exactly as before
+  }
+  for (int k = 0; k < 8; ++k) { hipFree(*ptrs[k]); *ptrs[k] = nw[k]; }
   t->T = new_max_tracks;
   return YL_OK;
 }
