@@ -222,7 +222,9 @@ void pack_stem(const float* w, int cout, int cin, int k, std::vector<float>& out
 }
 
 // stem of the fused entry block (3 input channels, 3x3): K order by input rows, see yl_stemblock.hip
-void pack_stem_rows(const float* w, int cout, std::vector<float>& out) {
+// bias (may be null): rides in the K = 27 -> 28 pad slot (s = 6, lane group 3) -- the kernel feeds 1.0 there, so the
+// shift is the LAST product of every output's fma chain (the rounding of conv + shift)
+void pack_stem_rows(const float* w, const float* bias, int cout, std::vector<float>& out) {
   const int KS = 7, NT = cdiv(cout, 16);
   out.assign((size_t)KS * NT * 64, 0.0f);
   for (int s = 0; s < KS; ++s)
@@ -233,7 +235,10 @@ void pack_stem_rows(const float* w, int cout, std::vector<float>& out) {
         if (s < 3) { row = 2 * kq; kx = s; }
         else if (s < 6) { row = 2 * kq + 1; kx = s - 3; }
         else if (kq < 3) { row = 8; kx = kq; }
-        else continue;                                               // pad slot: zero weight
+        else {                                                       // pad slot: the bias
+          if (n < cout && bias) out[((size_t)s * NT + nt) * 64 + lane] = bias[n];
+          continue;
+        }
         if (n < cout) out[((size_t)s * NT + nt) * 64 + lane] = w[(size_t)n * 27 + row * 3 + kx];
       }
 }
@@ -1049,7 +1054,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     std::vector<float> wp, bias;
     yl_status s;
     if (l.op == YL_OP_STEM || l.op == YL_OP_STEMBLOCK) {
-      if (l.op == YL_OP_STEMBLOCK) pack_stem_rows(l.w, l.cout, wp);
+      if (l.op == YL_OP_STEMBLOCK) pack_stem_rows(l.w, l.b, l.cout, wp);
       else pack_stem(l.w, l.cout, l.cin, l.k, wp);
       bias.assign(l.cout, 0.0f);
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));

@@ -40,6 +40,7 @@
 #define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
 #define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
+#define yl_launch_conv_pws yl_launch_conv_pws_bf16
 #define yl_launch_conv_wino yl_launch_conv_wino_bf16
 #define yl_launch_conv_dwk yl_launch_conv_dwk_bf16
 #define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
@@ -1250,6 +1251,11 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   // weight prologue, no barrier.  Measured against the persistent LDS kernel (edge_n, B = 64, eager, us): 48->96
   // @40x40 31 -> 26, 64->256 @20x20 28 -> 23, 64->480 @20x20 45 -> 35, 48->32 @80x80 40 -> 34, lateral3 32->96
   // @80x80 99 -> 81.  Same k order and epilogues: bit-identical results.  tile_hint 6 switches it off.
+  if (n == 1 && p.dw_k == 0 && p.k == 1 && p.stride == 1 && tile_hint != 6) {
+    // wide layers (K >= 80, >= 6 n-tiles): weight stream through LDS shared by the workgroup (yl_convc.hip, round 3)
+    const hipError_t es = yl_launch_conv_pws(p, st);
+    if (es != hipErrorNotSupported) return es;
+  }
   if (p.dw_k == 0 && p.k == 1 && p.stride == 1 && tile_hint != 6) {
     // (also the head-output layers of all levels in one launch when their decode runs in the epilogue)
     const hipError_t ep = yl_launch_conv_pwt_multi(ps, n, st);

@@ -39,6 +39,8 @@
 #define yl_launch_conv_wino yl_launch_conv_wino_bf16
 #define yl_conv_kxk_kernel yl_conv_kxk_kernel_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
+#define yl_conv_pws_kernel yl_conv_pws_kernel_bf16
+#define yl_launch_conv_pws yl_launch_conv_pws_bf16
 #endif
 #include <stdlib.h>
 #include <map>
@@ -1070,6 +1072,205 @@ hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Plain 1x1 convolution with MANY channels on both sides (round 3): yololite_m's EfficientNet-Lite blocks at 40x40 /
+// 20x20 -- conv_pw 120->720, 208->1248, conv_pwl 720->120, 1248->208, ... (model_v2.py:94-100: timm `ir` blocks) --
+// 3.5 of the model's 18.6 ms at 45-63 TFLOP/s through yl_conv_pwt_kernel.  That kernel gives every wave 16 pixels x
+// <= 4 n-tiles with BOTH operands straight from L1/L2: five 1-KiB fragment loads per 16 MFMAs, ~40 B/clk per CU at the
+// MFMA rate -- it is bound by the vector-memory path, not by the matrix pipe.  Here, as in yl_conv_kxk_kernel: NT
+// n-tiles (6..13, an exact divisor of the layer's n-tile count where one exists) per (m-tile, n-group) item, the
+// weight stream double-buffered through LDS in chunks of two k-steps shared by the workgroup's NW waves (asynchronous
+// copies of chunk c+1 under the MFMAs of chunk c, ONE barrier per chunk, the pipeline running on across items), the
+// activation fragment of the next k-step requested before the MFMAs of this one; a wave reads its A fragments from
+// LDS in groups of <= 7 (28 VGPRs).  Per 16 pixels and k-step: one L1/L2 load + NT LDS reads for 4 NT MFMAs.  Same k
+// order (channel blocks ascending, four sub-steps each) and epilogues as yl_conv_pwt_kernel: bit-identical results.
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(YlConvP p) {
+  constexpr int CH = 2;                                      // k-steps per weight chunk
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int KB = p.KB, NTtot = p.NTtot, Cin = p.Cin, M = p.M;
+  const float* const xin = p.x;
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][CH][NT][64] float4
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);   // [KB][NTtot][64] float4
+  const int NC = (KB + CH - 1) / CH;                         // chunks per item
+  const int G = (NTtot + NT - 1) / NT;                       // n-groups (the last one may be partial: clamped reads, no stores)
+  // work order as in yl_conv_kxk_kernel: XCD x (workgroup b -> XCD b % 8) owns a contiguous band of m-tiles and runs
+  // its (n-group, m-tile) items group-major, so that at any time an XCD streams 1/G of the weights out of its own L2
+  const int bx = blockIdx.x, gx = gridDim.x;                 // gx % 8 == 0
+  const int per = gx >> 3, slot = bx >> 3;
+  const int tpx = (p.ntiles + 7) >> 3;
+  const int band0 = (bx & 7) * tpx;
+  const int band1 = (band0 + tpx) < p.ntiles ? (band0 + tpx) : p.ntiles;
+  const int bt = band1 > band0 ? band1 - band0 : 0;
+  const int nitems = bt * G;
+  const int nmine = slot < nitems ? (nitems - 1 - slot) / per + 1 : 0;
+  const long total_chunks = (long)nmine * NC;
+  // asynchronous copy of chunk `c` (k-steps c*CH .. c*CH+CH-1, clamped) of n-group g into buffer `buf`
+  auto load_chunk = [&](int g, int c, int buf) {
+    for (int i = wave; i < CH * NT; i += NW) {
+      const int j = i / NT, nt = i - j * NT;
+      int kb = c * CH + j;
+      kb = kb < KB ? kb : KB - 1;
+      int ntg = g * NT + nt;
+      ntg = ntg < NTtot ? ntg : NTtot - 1;
+      yl_glds16(wg + ((size_t)kb * NTtot + ntg) * 64 + lane, wl + ((size_t)buf * CH * NT + i) * 64);
+    }
+  };
+  if (total_chunks > 0) load_chunk(slot / bt, 0, 0);
+  long gchunk = 0;                                            // chunks consumed so far (buffer = gchunk & 1)
+  __syncthreads();
+  const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE;
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const int ohw = p.OH * p.OW;
+
+  for (int wi = 0; wi < nmine; ++wi) {
+    const int item = slot + wi * per;
+    const int g = item / bt;
+    const int nt0 = g * NT;
+    const int tile = band0 + item - g * bt;
+    YlPix px[1];
+    {
+      size_t lin = ((size_t)tile * NW + wave) * 16 + pl;
+      px[0].valid = lin < (size_t)M;
+      if (!px[0].valid) lin = (size_t)M - 1;
+      px[0].lin = lin;
+      px[0].b = 0; px[0].oy = 0; px[0].ox = 0;
+      if (p.up) {                                            // only the upsample-add epilogue needs coordinates
+        const int b = (int)(lin / ohw);
+        const int rem = (int)(lin - (size_t)b * ohw);
+        px[0].b = b;
+        px[0].oy = rem / p.OW;
+        px[0].ox = rem - px[0].oy * p.OW;
+      }
+    }
+    const float* xrow = xin + px[0].lin * Cin + 4 * kq;
+    f32x4 acc[1][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pre_add) {
+      const size_t obase = px[0].lin * p.N;
+      size_t up_off = 0;
+      if (p.up) {
+        const int uy = (px[0].oy * p.UH) / p.OH, ux = (px[0].ox * p.UW) / p.OW;
+        up_off = (((size_t)px[0].b * p.UH + uy) * p.UW + ux) * p.N;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nt0 + nt) * 16 + 4 * kq;
+        if (n < p.N) {
+          if (p.res) acc[0][nt] = yl_ld4(p.res + obase + n);
+          if (p.up) acc[0][nt] += yl_ld4(p.up + up_off + n);
+        }
+      }
+    }
+    auto fetch = [&](int kb) {
+      const bool ok = kb * 16 + 4 * kq < Cin;                 // channel tail of the last block: zeros
+      return yl_ld4(ok ? xrow + kb * 16 : p.zeros);
+    };
+    f32x4 xq = fetch(0);
+    for (int c = 0; c < NC; ++c, ++gchunk) {
+      const int buf = (int)(gchunk & 1);
+      // next chunk of the stream (this item's, or the first one of the workgroup's next item) into the other buffer
+      if (gchunk + 1 < total_chunks) {
+        if (c + 1 < NC) load_chunk(g, c + 1, buf ^ 1);
+        else load_chunk((item + per) / bt, 0, buf ^ 1);
+      }
+      const f32x4* wb = wl + (size_t)buf * CH * NT * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int kb = c * CH + j;
+        if (kb < KB) {                                         // (workgroup-uniform) odd KB: the last chunk is half empty
+          const f32x4 xn = fetch(kb + 1 < KB ? kb + 1 : kb);
+          constexpr int H0 = NT > 7 ? (NT + 1) / 2 : NT;       // A fragments in two groups: <= 28 VGPRs of them live
+          constexpr int H1 = NT - H0;
+          f32x4 xs[1] = {xq};
+          {
+            f32x4 wq[H0], a0[1][H0];
+#pragma unroll
+            for (int nt = 0; nt < H0; ++nt) { wq[nt] = wb[(j * NT + nt) * 64]; a0[0][nt] = acc[0][nt]; }
+            yl_mma_step<H0, 1>(wq, xs, a0);
+#pragma unroll
+            for (int nt = 0; nt < H0; ++nt) acc[0][nt] = a0[0][nt];
+          }
+          if (H1 > 0) {
+            constexpr int H1s = H1 > 0 ? H1 : 1;
+            f32x4 wq[H1s], a1[1][H1s];
+#pragma unroll
+            for (int nt = 0; nt < H1; ++nt) { wq[nt] = wb[(j * NT + H0 + nt) * 64]; a1[0][nt] = acc[0][H0 + nt]; }
+            yl_mma_step<H1s, 1>(wq, xs, a1);
+#pragma unroll
+            for (int nt = 0; nt < H1; ++nt) acc[0][H0 + nt] = a1[0][nt];
+          }
+          xq = xn;
+        }
+      }
+      __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
+    }
+    if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, 1>(p, acc, px, nt0, kq);
+    else yl_epi_fast<NT, 1>(p, acc, px, nt0, kq, lo, hi, true);
+  }
+}
+
+template <int NT, int NW>
+static hipError_t pws_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  YlConvP p = p0;
+  p.ntiles = (int)(((long)p.M + 16 * NW - 1) / (16 * NW));
+  const size_t lds = (size_t)2 * 2 * NT * 1024;
+  int gx = yl_resident_blocks_n(yl_conv_pws_kernel<NT, NW>, NW * 64, lds) & ~7;
+  const int gy = (p.NTtot + NT - 1) / NT;
+  while (gx > 8 && gx - 8 >= p.ntiles * gy) gx -= 8;
+  hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int NT>
+static hipError_t pws_nw(const YlConvP& p, hipStream_t st, bool eight, bool attr_only) {
+  if (attr_only) {
+    const hipError_t e = pws_go<NT, 4>(p, st, true);
+    return e != hipSuccess ? e : pws_go<NT, 8>(p, st, true);
+  }
+  return eight ? pws_go<NT, 8>(p, st, false) : pws_go<NT, 4>(p, st, false);
+}
+
+// plain 1x1 stride-1 layers (N % 4 == 0, no decode epilogue) with enough channels on both sides that the weight
+// stream pays: K >= 80 and >= 6 n-tiles.  hipErrorNotSupported otherwise (yl_conv_pwt_kernel runs the layer).
+hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
+  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || (p.N & 3) || p.dec_boxes) return hipErrorNotSupported;
+  static const int sel = getenv("YL_PWS") ? atoi(getenv("YL_PWS")) : 1;       // 0: off (A/B runs)
+  if (!sel || p.KB < 5 || p.NTtot < 6) return hipErrorNotSupported;
+  // n-tiles per item, from {6..13}: the makespan of the launch in MFMA units -- (16-pixel x n-group) wave items dealt
+  // to 1024 SIMDs, each NT x KB x 4 MFMAs long -- with a penalty when fewer than 1.5 waves per SIMD exist (one wave
+  // alone cannot keep a matrix pipe busy); ties go to the larger NT (fewer passes over the activations).  E.g. 1248 ->
+  // 208 at 20x20 x 32 images (13 n-tiles, 800 pixel tiles): NT = 7 in two groups (116 -> 90 us), not 13 in one.
+  static const int cand[6] = {13, 11, 9, 8, 7, 6};
+  int NT = 0;
+  double best = 1e30;
+  long best_wi = 0;
+  const long mt16 = ((long)p.M + 15) / 16;
+  for (int i = 0; i < 6; ++i) {
+    const long wi = mt16 * ((p.NTtot + cand[i] - 1) / cand[i]);
+    const double sc = (double)((wi + 1023) / 1024) * cand[i] * (wi < 1536 ? 1.25 : 1.0);
+    if (sc < best) { best = sc; NT = cand[i]; best_wi = wi; }
+  }
+  if (best_wi < 1536) return hipErrorNotSupported;      // too few items for workgroup-shared weights: wave-autonomous kernel
+  const int gy = (p.NTtot + NT - 1) / NT;
+  const bool eight = ((long)p.M / 128) * gy >= 2 * 2 * YL_NUM_CU;          // enough 128-pixel items for 8-wave workgroups
+  switch (NT) {
+    case 6: return pws_nw<6>(p, st, eight, false);
+    case 7: return pws_nw<7>(p, st, eight, false);
+    case 8: return pws_nw<8>(p, st, eight, false);
+    case 9: return pws_nw<9>(p, st, eight, false);
+    case 11: return pws_nw<11>(p, st, eight, false);
+    default: return pws_nw<13>(p, st, eight, false);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Depthwise 3x3 -> 1x1 convolution whose 1x1 weights do not fit LDS (edge_m's 244-channel and yololite_m's
 // 328-channel neck / head blocks, model_v2.py:24-41: 240-430 KB packed).  yl_conv_dwh_kernel cannot hold the image and
 // the layer fell to yl_conv_mfma_kernel's streamed mode (48 TFLOP/s: fill / use barriers, 21 n-tiles as 8 + 8 + 5).
@@ -1526,6 +1727,12 @@ hipError_t yl_convc_init() {
   if (e == hipSuccess) e = kxk_go<7, 1, 8>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<4, 1, 8>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<4, 2, 4>(q, 1, nullptr, true);
+  if (e == hipSuccess) e = pws_nw<6>(q, nullptr, false, true);
+  if (e == hipSuccess) e = pws_nw<7>(q, nullptr, false, true);
+  if (e == hipSuccess) e = pws_nw<8>(q, nullptr, false, true);
+  if (e == hipSuccess) e = pws_nw<9>(q, nullptr, false, true);
+  if (e == hipSuccess) e = pws_nw<11>(q, nullptr, false, true);
+  if (e == hipSuccess) e = pws_nw<13>(q, nullptr, false, true);
   if (e == hipSuccess) e = dwt_any(m, 0, nullptr, false, false, true);
   if (e == hipSuccess) e = wino_go(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<7, 1, 4>(q, nullptr, true);

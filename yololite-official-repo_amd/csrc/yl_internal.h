@@ -87,6 +87,7 @@ struct YlConvP {
   int C1, C2, C3, act2, act3;
   int SH, SW;            // stem output grid
   int tiles_x, tiles_y;  // 8x8 output tiles per image
+  int sb_strip;          // yl_stemblock_kernel: tiles per strip (set by the launcher)
   // decode fused into the head-output conv (yl_predict): the epilogue turns the lane-distributed row of a
   // candidate (tx,ty,tw,th,obj,cls...) into box / score / class and writes the NMS inputs directly; the
   // raw level tensor is then only written when something else needs it (dec_raw: mask coefficients).
@@ -149,6 +150,9 @@ hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_pwt_bf16(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st);
 hipError_t yl_launch_conv_pwt_multi_bf16(const YlConvP* ps, int n, hipStream_t st);
+// plain 1x1 conv with a double-buffered weight stream for wide layers (yl_convc.hip); hipErrorNotSupported = pwt runs it
+hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv_pws_bf16(const YlConvP& p, hipStream_t st);
 // dense k x k conv with a double-buffered weight stream (yl_convc.hip); hipErrorNotSupported = other kernel runs it
 hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_kxk_bf16(const YlConvP& p, hipStream_t st);

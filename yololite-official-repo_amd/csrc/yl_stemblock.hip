@@ -6,9 +6,9 @@
 // layer-fused traffic together.  Here it lives only in LDS: one WAVE produces a 2x8 tile of the second
 // conv's output from a 5x17 patch of stem pixels kept in its private LDS region.
 //
-// Phase 1  stem on the 5x17 patch: transposed MFMA GEMM (A = stem weights in registers, 7 k-steps,
+// Phase 1  stem on the 5x16 new pixels of the patch: transposed MFMA GEMM (A = stem weights in registers, 7 k-steps,
 //          B = one input scalar per lane gathered from the NCHW planes), result (+bias, act; zero outside
-//          the image = the second conv's zero padding) -> LDS patch [96][C1+4].
+//          the image = the second conv's zero padding) -> LDS patch [5][17][C1+4].
 // Phase 2  3x3 s2 conv from LDS: one 16-pixel m-tile per wave, B operand = float4 of 4 channels read
 //          from the patch, A operand = packed weights in LDS (one ds_read_b128 per 16x16x16 step).
 // Phase 3  optional 1x1 conv chained in registers: the MFMA D layout (lane = pixel, 4 consecutive
@@ -28,27 +28,38 @@
 #include <type_traits>
 
 #ifndef SB_EXP
-#define SB_EXP 0                    // timing experiments (variant builds only): 1 no gathers, 2 no stem MFMAs,
-#endif                              // 3 no 3x3 MFMAs, 4 no stores -- results are WRONG when set
+#define SB_EXP 0                    // timing experiments (variant builds only): 2 no stem MFMAs, 3 no 3x3 MFMAs,
+#endif                              // 4 no stores, 5 no gathers, 6 no LDS patch traffic -- results are WRONG when set
 #define SB_TR 2                     // wave tile: 2 rows x 8 columns of the second conv's output grid
 #define SB_TC 8
 #define SB_PR (2 * SB_TR + 1)       // stem patch: 5 rows x 17 columns
 #define SB_PC (2 * SB_TC + 1)
 #define SB_NPATCH (SB_PR * SB_PC)   // 85 stem pixels
-#define SB_MT1 ((SB_NPATCH + 15) / 16)   // 6 m-tiles
+#define SB_NM SB_PR                 // stem m-tiles per tile: patch row m x columns 1..16 (column 0 rolls over, see below)
 struct __attribute__((packed, aligned(4))) SbF3 { float a, b, c; };   // 3 consecutive taps of one input row
 
 // Every WAVE owns its tiles end to end (private LDS patch, no workgroup barrier in the loop): waves
 // drift apart and cover each other's gather latency / MFMA dependency stalls.
+//
+// Round 3: a wave walks a horizontal STRIP of tiles left to right.  The 5 x 17 stem patch of a tile shares its
+// column 0 with column 16 of the tile before: that column stays in LDS (copied 16 -> 0, five pixels), and the stem
+// GEMM covers the 5 x 16 NEW pixels = exactly five 16-pixel m-tiles with no padding rows -- 70 stem MFMAs per tile
+// where the stand-alone 85-pixel patch (padded to 96) took 84, 146 instead of 160 per tile in total.  Only the first
+// tile of a strip computes its own column 0 (one more m-tile with five live rows).  Further VALU work removed from
+// the MFMA-issue-bound loop (fp32 MFMA and fp32 VALU share the FMA lanes, see yl_dev.h): the stem bias rides in the
+// K = 27 -> 28 pad slot of the stem GEMM (weight slot = bias, input slot = 1.0: added last in the fma chain, the same
+// rounding as the separate add), and all tile bookkeeping is scalar (wave id through readfirstlane), so the gathers are
+// `global_load saddr + per-lane constant offset` with no per-tile vector address arithmetic.
 template <int NT1 /*C1/16*/, int NT2 /*ceil(C2/16)*/, int NT3 /*ceil(C3/16), 0 = no 1x1*/>
 __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   constexpr int C1 = NT1 * 16, P1 = C1 + 4, KS = 7, KB1 = NT1;
-  constexpr int PATCH_F = SB_MT1 * 16 * P1;                          // floats per wave patch (96 rows)
+  constexpr int PATCH_F = 96 * P1;                                   // floats per wave patch (85 rows used)
   extern __shared__ __attribute__((aligned(16))) float sb_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
-  float* patch = sb_lds + (SB_EXP == 7 ? 0 : wave) * PATCH_F;       // [96][P1], wave private
-  f32x4* w2l = reinterpret_cast<f32x4*>(sb_lds + (SB_EXP == 7 ? 1 : 4) * PATCH_F);
+  float* patch = sb_lds + wave * PATCH_F;                            // [5][17][P1], wave private
+  f32x4* w2l = reinterpret_cast<f32x4*>(sb_lds + 4 * PATCH_F);
   f32x4* w3l = w2l + 9 * KB1 * NT2 * 64;
 
   // ---- once per block: stem A fragments -> registers, conv2 / conv3 weights -> LDS
@@ -58,12 +69,18 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) wa[s][nt] = p.wp[(s * NT1 + nt) * 64 + lane];
 #if YL_BF16
+  // bf16 operands would round the bias: this build keeps the separate fp32 add and a zero weight in the pad slot
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) if (kq == 3) wa[6][nt] = 0.0f;
   yl_s16x4 wab[2][NT1];
 #pragma unroll
   for (int nt = 0; nt < NT1; ++nt) {
     wab[0][nt] = yl_pk_bf16((f32x4){wa[0][nt], wa[1][nt], wa[2][nt], wa[3][nt]});
     wab[1][nt] = yl_pk_bf16((f32x4){wa[4][nt], wa[5][nt], wa[6][nt], 0.0f});
   }
+  f32x4 bias1[NT1];
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) bias1[nt] = yl_ld4(p.bias + nt * 16 + 4 * kq);
 #endif
   {
     const f32x4* g2 = reinterpret_cast<const f32x4*>(p.w2p);
@@ -75,12 +92,11 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   }
   __syncthreads();
 
-  const size_t plane = (size_t)p.H * p.W;
-  // per-lane constants: tap decode of the lane's k slots and patch-pixel coordinates of its m-tile rows.
-  // K order (shared with pack_stem_rows in yl_api.hip): the 27 taps are 9 rows (c,ky) of 3 consecutive kx.
-  // Lane group kq owns rows 2kq and 2kq+1 whole (slots 0-2, 3-5) and one element of row 8 (slot 6, kx = kq;
-  // group 3: the zero-weight pad slot), so a lane's 7 operands per patch pixel are two 12-byte loads and one
-  // 4-byte load instead of seven scattered dwords.
+  const int plane = p.H * p.W;
+  // per-lane constants: tap decode of the lane's k slots.  K order (shared with pack_stem_rows in yl_api.hip): the 27
+  // taps are 9 rows (c,ky) of 3 consecutive kx.  Lane group kq owns rows 2kq and 2kq+1 whole (slots 0-2, 3-5) and one
+  // element of row 8 (slot 6, kx = kq; group 3: the bias slot), so a lane's 7 operands per patch pixel are two 12-byte
+  // loads and one 4-byte load instead of seven scattered dwords.
   int tky[KS], tkx[KS], tc[KS], gs[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -88,24 +104,25 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     if (s < 3) { row = 2 * kq; kx = s; }
     else if (s < 6) { row = 2 * kq + 1; kx = s - 3; }
     else if (kq < 3) { row = 8; kx = kq; }
-    else { row = 7; kx = 2; }                                        // pad slot: any valid address, weight 0
+    else { row = 7; kx = 2; }                                        // bias slot: any valid address, value replaced by 1.0
     tc[s] = row / 3;
     tky[s] = row - 3 * tc[s];
     tkx[s] = kx;
-    gs[s] = tc[s] * (int)plane + tky[s] * p.W + tkx[s];
+    gs[s] = tc[s] * plane + tky[s] * p.W + tkx[s];
   }
-  int ppi[SB_MT1], ppj[SB_MT1], gm[SB_MT1];
-#pragma unroll
-  for (int m = 0; m < SB_MT1; ++m) {
-    const int q = m * 16 + pl;
-    const int qq = q < SB_NPATCH ? q : SB_NPATCH - 1;
-    ppi[m] = qq / SB_PC;
-    ppj[m] = qq - ppi[m] * SB_PC;
-    gm[m] = (ppi[m] * p.stride) * p.W + ppj[m] * p.stride;
-  }
-  f32x4 bias1[NT1], bias2[NT2];
-#pragma unroll
-  for (int nt = 0; nt < NT1; ++nt) bias1[nt] = yl_ld4(p.bias + nt * 16 + 4 * kq);
+  // gather offsets (floats) relative to the uniform base of (tile, patch row): regular m-tile m = patch row m, lane pl =
+  // patch column 1 + pl; first-tile m-tile = patch column 0, lane pl = patch row min(pl, 4)
+  const int pcol = (1 + pl) * p.stride;
+  const unsigned vr0 = (unsigned)(gs[0] + pcol), vr1 = (unsigned)(gs[3] + pcol), vr2 = (unsigned)(gs[6] + pcol);
+  const int prow = (pl < SB_PR ? pl : SB_PR - 1);
+  const unsigned vf0 = (unsigned)(gs[0] + prow * p.stride * p.W), vf1 = (unsigned)(gs[3] + prow * p.stride * p.W),
+                 vf2 = (unsigned)(gs[6] + prow * p.stride * p.W);
+#if YL_BF16
+  const bool slot6_lane = true;                                      // bf16 build: separate bias add, zero weight in the slot
+#else
+  const bool slot6_lane = kq != 3;                                   // lane group 3: the bias slot (input 1.0)
+#endif
+  f32x4 bias2[NT2];
 #pragma unroll
   for (int nt = 0; nt < NT2; ++nt) bias2[nt] = yl_ld4(p.b2 + nt * 16 + 4 * kq);
   // ReLU-family activations as branch-free clamps (SiLU is rejected for this op at yl_create)
@@ -116,106 +133,145 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   f32x4 bias3[NT3 > 0 ? NT3 : 1];
 #pragma unroll
   for (int nt = 0; nt < NT3; ++nt) bias3[nt] = yl_ld4(p.b3 + nt * 16 + 4 * kq);
-  const int lq = pl * P1 + 4 * kq;                                   // lane part of the patch write offset
+  const int lqr = (1 + pl) * P1 + 4 * kq;                            // patch write offset: regular m-tile (+ m * 17 * P1)
+  const int lqf = prow * SB_PC * P1 + 4 * kq;                        // patch write offset: column-0 m-tile
   const int ty = pl >> 3, tx = pl & 7;                               // lane's pixel inside the 2x8 tile
   const int lr = ((2 * ty) * SB_PC + 2 * tx) * P1 + 4 * kq;          // lane part of the patch read offset
   const int Nout = (NT3 > 0) ? p.C3 : p.C2;
   const int tpr = (p.OW + SB_TC - 1) / SB_TC, tpc = (p.OH + SB_TR - 1) / SB_TR;
-  const int tiles_img = tpr * tpc;
-  const int ntiles = p.B * tiles_img;
-  const int wstride = gridDim.x * 4;
+  const int SL = p.sb_strip;                                         // tiles per strip
+  const int spr = (tpr + SL - 1) / SL;                               // strips per tile row
+  const int strips_img = spr * tpc;
+  const int nstrips = p.B * strips_img;
 
-  // gather of the 42 input scalars this lane feeds to the stem MFMAs of `tile` (7 k-slots x 6 patch
-  // m-tiles).  Issued for tile t+1 right after tile t's stem phase has consumed the registers, so the
-  // global-load latency hides behind tile t's 3x3 / 1x1 MFMAs.
-  float xv[SB_MT1][KS];
-  int nb = 0, ntyi = 0, ntxi = 0;                    // decode of the tile whose gather is in flight
-  int gb = 0, gty = 0, gtx = 0, sdb = 0, sdy = 0, sdx = 0;   // next gather tile and the decomposition of the tile stride
-  auto gather = [&](int tile) {
-    if (SB_EXP == 1) {
-#pragma unroll
-      for (int m = 0; m < SB_MT1; ++m)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) xv[m][s] = (float)(tile + m + s);
-      return;
-    }
-    (void)tile;                                       // (image, tile row, tile column) of `tile` are carried in gb/gty/gtx
-    const int b = gb, tyi = gty, txi = gtx;
-    nb = b; ntyi = tyi; ntxi = txi;
-    gtx += sdx;                                       // advance to the tile of the NEXT call (tile + wstride2): two
-    if (gtx >= tpr) { gtx -= tpr; ++gty; }            // carries instead of two integer divisions (~50 VALU ops, and
-    gty += sdy;                                       // fp32 VALU time is MFMA time in this kernel)
-    if (gty >= tpc) { gty -= tpc; ++gb; }
-    gb += sdb;
-    const int sy0 = 2 * tyi * SB_TR - 1, sx0 = 2 * txi * SB_TC - 1;
-    const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;
-    const float* xb = p.x + (size_t)b * 3 * plane;
-    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW && iy0 >= 0 && ix0 >= 0 &&
-                          iy0 + (SB_PR - 1) * p.stride + 3 <= p.H && ix0 + (SB_PC - 1) * p.stride + 3 <= p.W;
-    if (interior) {                                   // the common case: no bounds logic (wave-uniform branch)
-      const float* xo = xb + (size_t)iy0 * p.W + ix0;
-#pragma unroll
-      for (int m = 0; m < SB_MT1; ++m) {
-        const float* q = xo + gm[m];
-        const SbF3 r0 = *reinterpret_cast<const SbF3*>(q + gs[0]);
-        const SbF3 r1 = *reinterpret_cast<const SbF3*>(q + gs[3]);
-        xv[m][0] = r0.a; xv[m][1] = r0.b; xv[m][2] = r0.c;
-        xv[m][3] = r1.a; xv[m][4] = r1.b; xv[m][5] = r1.c;
-        xv[m][6] = q[gs[6]];
-      }
-    } else {
-#pragma unroll
-      for (int m = 0; m < SB_MT1; ++m)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int iy = iy0 + ppi[m] * p.stride + tky[s], ix = ix0 + ppj[m] * p.stride + tkx[s];
-          const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-          xv[m][s] = *(in ? xb + tc[s] * plane + (size_t)iy * p.W + ix : p.zeros);
-        }
-    }
-  };
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; placement changes speed only), and
-  // XCD x owns the contiguous tile range [x*ntiles/8, (x+1)*ntiles/8) -- whole images for B % 8 == 0 -- so the input
-  // rows / columns shared by neighbouring 5x17 patches are re-read from this XCD's L2 instead of from HBM a second
-  // time (rocprofv3: 630 MB fetched per launch for a 315 MB input with the round-robin order).
-  int tile0 = blockIdx.x * 4 + wave, wstride2 = wstride, tend = ntiles;
+  // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order; placement changes speed only), and XCD x
+  // owns the contiguous strip range [x*nstrips/8, (x+1)*nstrips/8) -- whole images for B % 8 == 0 -- so the input rows
+  // shared by vertically neighbouring patches are re-read from this XCD's L2 instead of from HBM a second time.
+  int strip = blockIdx.x * 4 + wave, sstride = gridDim.x * 4, send = nstrips;
   if ((gridDim.x & 7) == 0) {
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
-    const int r0 = (int)(((long)ntiles * x) >> 3), r1 = (int)(((long)ntiles * (x + 1)) >> 3);
-    tile0 = r0 + j * 4 + wave; wstride2 = nj * 4; tend = r1;
+    const int r0 = (int)(((long)nstrips * x) >> 3), r1 = (int)(((long)nstrips * (x + 1)) >> 3);
+    strip = r0 + j * 4 + wave; sstride = nj * 4; send = r1;
   }
+  // the tile whose inputs are being gathered (one ahead of the tile being computed); everything here is wave-uniform
+  int g_b = 0, g_ty = 0, g_tx = 0, g_txend = 0, g_first = 0, g_valid = 0, g_strip = strip;
+  auto decode_strip = [&]() {
+    g_valid = g_strip < send;
+    if (!g_valid) return;
+    g_b = g_strip / strips_img;
+    const int rem = g_strip - g_b * strips_img;
+    g_ty = rem / spr;
+    g_tx = (rem - g_ty * spr) * SL;
+    g_txend = (g_tx + SL) < tpr ? (g_tx + SL) : tpr;
+    g_first = 1;
+  };
+  auto advance = [&]() {
+    if (g_tx + 1 < g_txend) { ++g_tx; g_first = 0; }
+    else { g_strip += sstride; decode_strip(); }
+  };
+
+  // gather of the input scalars this lane feeds to the stem MFMAs of the tile (g_b, g_ty, g_tx): 7 k-slots x 5 m-tiles
+  // (+ 1 for the first tile of a strip).  Issued for tile t+1 right after tile t's stem phase has consumed the
+  // registers, so the global-load latency hides behind tile t's 3x3 / 1x1 MFMAs.
+  float xv[SB_NM][KS], xf[KS];
+  const float* g_xo = p.x;                            // interior gather in flight: uniform base of its patch
+  bool g_int = false;
+  auto gather_piece = [&](int i) {                    // i = 2 m + (0: input rows 2kq, 1: rows 2kq+1) of m-tile m
+    const int m = i >> 1;
+    const float* q = g_xo + m * p.stride * p.W;
+    const SbF3 r = *reinterpret_cast<const SbF3*>(q + ((i & 1) ? vr1 : vr0));
+    xv[m][3 * (i & 1)] = r.a; xv[m][3 * (i & 1) + 1] = r.b; xv[m][3 * (i & 1) + 2] = r.c;
+  };
+  auto gather = [&]() {
+    if (SB_EXP == 5) {                                // timing experiment: no loads
+#pragma unroll
+      for (int m = 0; m < SB_NM; ++m)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) xv[m][s] = (float)(g_tx + m + s);
+      return;
+    }
+    const int sy0 = 2 * g_ty * SB_TR - 1, sx0 = 2 * g_tx * SB_TC - 1;
+    const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;
+    const float* xb = p.x + (size_t)g_b * 3 * plane;
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW && iy0 >= 0 && ix0 >= 0 &&
+                          iy0 + (SB_PR - 1) * p.stride + 3 <= p.H && ix0 + (SB_PC - 1) * p.stride + 3 <= p.W;
+    g_int = interior;
+    if (interior) {                                   // the common case: no bounds logic (wave-uniform branch)
+      const float* xo = xb + (long)iy0 * p.W + ix0;   // uniform: scalar base, per-lane constant offsets
+      g_xo = xo;
+      // The ten 12-byte gathers of the regular m-tiles are NOT issued here: they go out one per MFMA step inside phase
+      // 2 (gather_piece), so that the wave never sits in front of its own 3x3 MFMAs with a full address queue.
+      // (Measured, B = 64: kernel without any gather 0.261 ms, with 0.323 ms; an L2 prefetch of the lines one or two
+      // tiles ahead made it SLOWER (0.334 / 0.338 ms) -- the cost is the vector-memory path itself (17 instructions of
+      // scattered 12-/4-byte lanes per tile), not the miss latency.)
+      if (g_first) {
+        const SbF3 r0 = *reinterpret_cast<const SbF3*>(xo + vf0);
+        const SbF3 r1 = *reinterpret_cast<const SbF3*>(xo + vf1);
+        xf[0] = r0.a; xf[1] = r0.b; xf[2] = r0.c; xf[3] = r1.a; xf[4] = r1.b; xf[5] = r1.c;
+      }
+      // slot 6 (4 bytes per lane, cheap): now.  The bias lanes read some valid address; their value is replaced by 1.0
+      // where it is CONSUMED (stem_mtile) -- a select here would wait for the load on the spot
+#pragma unroll
+      for (int m = 0; m < SB_NM; ++m) xv[m][6] = (xo + m * p.stride * p.W)[vr2];
+      if (g_first) xf[6] = xo[vf2];
+    } else {
+#pragma unroll
+      for (int m = 0; m < SB_NM; ++m)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int iy = iy0 + m * p.stride + tky[s], ix = ix0 + (1 + pl) * p.stride + tkx[s];
+          const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          xv[m][s] = *(in ? xb + tc[s] * plane + (long)iy * p.W + ix : p.zeros);
+        }
+      if (g_first) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int iy = iy0 + prow * p.stride + tky[s], ix = ix0 + tkx[s];
+          const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          xf[s] = *(in ? xb + tc[s] * plane + (long)iy * p.W + ix : p.zeros);
+        }
+      }
+    }
+  };
 #ifdef SB_STAGGER
   if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(SB_STAGGER);   // de-phase the two co-resident blocks of a CU
 #endif
-  if (tile0 < tend) {
-    gb = tile0 / tiles_img;
-    const int trem = tile0 - gb * tiles_img;
-    gty = trem / tpr; gtx = trem - gty * tpr;
-    sdb = wstride2 / tiles_img;
-    const int srem = wstride2 - sdb * tiles_img;
-    sdy = srem / tpr; sdx = srem - sdy * tpr;
-    gather(tile0);
+  decode_strip();
+  if (g_valid) {
+    gather();
+    if (g_int) {
+#pragma unroll
+      for (int i = 0; i < 2 * SB_NM; ++i) gather_piece(i);
+    }
   }
 
-  for (int tile = tile0; tile < tend; tile += wstride2) {
-    const int b = nb, tyi = ntyi, txi = ntxi;
+  while (g_valid) {
+    const int b = g_b, tyi = g_ty, txi = g_tx, first = g_first;       // the tile computed now (its inputs are in xv / xf)
     const int oy0 = tyi * SB_TR, ox0 = txi * SB_TC;                  // tile origin on the conv2 output grid
     const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;                  // patch origin on the stem grid
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW;
-    // ---- phase 1: stem on the patch -> wave-private LDS.  Two copies of the code, selected by a wave-uniform
+    // ---- phase 0: column 16 of the previous tile's patch is column 0 of this one (five pixels x C1 channels)
+    if (!first) {
+      constexpr int Q = C1 / 4;                                      // float4 per pixel
+      if (lane < SB_PR * Q) {
+        const int i = lane / Q, c4 = lane - i * Q;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(patch + (i * SB_PC + (SB_PC - 1)) * P1 + 4 * c4);
+        *reinterpret_cast<f32x4*>(patch + (i * SB_PC) * P1 + 4 * c4) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // ---- phase 1: stem on the new patch pixels -> wave-private LDS.  Two copies of the code, selected by a wave-uniform
     // branch: interior tiles (all but the image border) carry no padding logic at all -- left as a runtime flag
     // the compiler predicates it per lane (compares, exec masking and 8 v_cndmask per m-tile on every tile)
-    auto phase1 = [&](auto interior_tag) {
+    auto stem_mtile = [&](auto interior_tag, const float (&xs)[KS], int sy, int sx, float* dst, bool live) {
       constexpr bool INTERIOR = decltype(interior_tag)::value;
-#pragma unroll
-    for (int m = 0; m < SB_MT1; ++m) {
       f32x4 a1[NT1];
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) a1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #if YL_BF16
       {   // the lane's 7 k slots as two 4-wide bf16 operands (slot 7 = zero); same slot <-> lane pairing in A and B
-        const yl_s16x4 x0 = yl_pk_bf16((f32x4){xv[m][0], xv[m][1], xv[m][2], xv[m][3]});
-        const yl_s16x4 x1 = yl_pk_bf16((f32x4){xv[m][4], xv[m][5], xv[m][6], 0.0f});
+        const yl_s16x4 x0 = yl_pk_bf16((f32x4){xs[0], xs[1], xs[2], xs[3]});
+        const yl_s16x4 x1 = yl_pk_bf16((f32x4){xs[4], xs[5], xs[6], 0.0f});
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) {
           a1[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wab[0][nt], x0, a1[nt], 0, 0, 0);
@@ -223,31 +279,39 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
         }
       }
 #else
+      // the bias slot of the stem GEMM: weight = bias (pack_stem_rows), input = 1.0 on lane group 3
+      const float x6 = slot6_lane ? xs[6] : 1.0f;
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
-          if (SB_EXP != 2) a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], xv[m][s], a1[nt], 0, 0, 0);
-          else a1[nt][0] += wa[s][nt] * xv[m][s];
+          if (SB_EXP != 2) a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], s == 6 ? x6 : xs[s], a1[nt], 0, 0, 0);
+          else a1[nt][0] += wa[s][nt] * xs[s];
 #endif
       bool inside = true;
-      if (!INTERIOR) {
-        const int sy = sy0 + ppi[m], sx = sx0 + ppj[m];
-        inside = sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;       // else: zero padding of the second conv
-      }
+      if (!INTERIOR) inside = sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;   // else: zero padding of the second conv
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
+#if YL_BF16
         f32x4 v = clamp4(a1[nt] + bias1[nt], lo1, hi1);     // conv + shift, the reference's order
+#else
+        f32x4 v = clamp4(a1[nt], lo1, hi1);                 // the shift was the last product of the fma chain
+#endif
         if (!INTERIOR && !inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(patch + m * 16 * P1 + lq + nt * 16) = v;
+        if (live) *reinterpret_cast<f32x4*>(dst + nt * 16) = v;
       }
-    }
+    };
+    auto phase1 = [&](auto interior_tag) {
+      if (first) stem_mtile(interior_tag, xf, sy0 + prow, sx0, patch + lqf, pl < SB_PR);
+#pragma unroll
+      for (int m = 0; m < SB_NM; ++m) stem_mtile(interior_tag, xv[m], sy0 + m, sx0 + 1 + pl, patch + m * SB_PC * P1 + lqr, true);
     };
     if (interior) phase1(std::true_type{});
     else phase1(std::false_type{});
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // LDS writes of other lanes -> reads below
     __builtin_amdgcn_wave_barrier();
-    if (tile + wstride2 < tend) gather(tile + wstride2);             // next tile's inputs: in flight during phases 2-3
+    advance();
+    if (g_valid) gather();                                           // next tile's inputs: in flight during phases 2-3
 
     // ---- phase 2: 3x3 stride-2 conv on the wave's 2x8 tile.  LDS operands of step i+1 are requested
     //      before the MFMAs of step i (explicit double buffer, order pinned with sched_group_barrier), and
@@ -257,6 +321,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) { a2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; a2b[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     constexpr int NSTEP = 9 * KB1;
+    constexpr int PPS = (2 * SB_NM + NSTEP - 1) / NSTEP;             // gather pieces per MFMA step
     f32x4 xq[2], wq[2][NT2];
     auto lds_step = [&](int i, int buf) {              // i = tap * KB1 + kb  (all compile-time after unrolling)
       const int tap = i / KB1, kb = i - tap * KB1;
@@ -265,29 +330,41 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
       for (int nt = 0; nt < NT2; ++nt) wq[buf][nt] = w2l[(i * NT2 + nt) * 64 + lane];
     };
-    lds_step(0, 0);
+    auto phase2 = [&](auto gather_tag) {
+      constexpr bool GATHER = decltype(gather_tag)::value;           // the next tile's 12-byte gathers ride along
+      lds_step(0, 0);
 #pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-      if (i + 1 < NSTEP) lds_step(i + 1, (i + 1) & 1);
+      for (int i = 0; i < NSTEP; ++i) {
+        if (i + 1 < NSTEP) lds_step(i + 1, (i + 1) & 1);
+        int npiece = 0;
+        if (GATHER) {
 #pragma unroll
-      for (int nt = 0; nt < NT2; ++nt) {
-        const f32x4 w = wq[i & 1][nt], x = xq[i & 1];
-        if (SB_EXP == 3) { a2[nt][0] += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3]; continue; }
+          for (int k = 0; k < PPS; ++k)
+            if (i * PPS + k < 2 * SB_NM) { gather_piece(i * PPS + k); ++npiece; }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+          const f32x4 w = wq[i & 1][nt], x = xq[i & 1];
+          if (SB_EXP == 3) { a2[nt][0] += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3]; continue; }
 #if YL_BF16
-        if (i & 1) a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2b[nt], 0, 0, 0);
-        else a2[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2[nt], 0, 0, 0);
+          if (i & 1) a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2b[nt], 0, 0, 0);
+          else a2[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2[nt], 0, 0, 0);
 #else
-        a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], a2[nt], 0, 0, 0);
-        a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], a2b[nt], 0, 0, 0);
-        a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], a2[nt], 0, 0, 0);
-        a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[3], a2b[nt], 0, 0, 0);
+          a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], a2[nt], 0, 0, 0);
+          a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], a2b[nt], 0, 0, 0);
+          a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], a2[nt], 0, 0, 0);
+          a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[3], a2b[nt], 0, 0, 0);
+#endif
+        }
+#if !YL_BF16
+        __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT2, 0);     // DS reads of step i+1
+        if (npiece) __builtin_amdgcn_sched_group_barrier(0x020, PPS, 0);   // this step's gather pieces (VMEM reads)
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT2, 0);     // MFMAs of step i
 #endif
       }
-#if !YL_BF16
-      __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT2, 0);       // DS reads of step i+1
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT2, 0);       // MFMAs of step i
-#endif
-    }
+    };
+    if (g_valid && g_int && SB_EXP != 5) phase2(std::true_type{});
+    else phase2(std::false_type{});
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) a2[nt] = clamp4((a2[nt] + a2b[nt]) + bias2[nt], lo2, hi2);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // patch reads done before the next tile's writes
@@ -305,13 +382,13 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
       for (int kb = 0; kb < NT2; ++kb)
 #pragma unroll
         for (int nt = 0; nt < NT3; ++nt) {
-          const f32x4 wq = w3l[(kb * NT3 + nt) * 64 + lane];
+          const f32x4 wq3 = w3l[(kb * NT3 + nt) * 64 + lane];
 #if YL_BF16
-          a3[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(wq), yl_pk_bf16(a2[kb]), a3[nt], 0, 0, 0);
+          a3[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(wq3), yl_pk_bf16(a2[kb]), a3[nt], 0, 0, 0);
 #else
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            a3[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s], a2[kb][s], a3[nt], 0, 0, 0);
+            a3[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq3[s], a2[kb][s], a3[nt], 0, 0, 0);
 #endif
         }
 #pragma unroll
@@ -331,16 +408,23 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 }
 
 template <int NT1, int NT2, int NT3>
-static hipError_t sb_go(const YlConvP& p, hipStream_t st, bool attr_only) {
+static hipError_t sb_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
   constexpr int P1 = NT1 * 16 + 4;
-  const size_t lds = (size_t)((SB_EXP == 7 ? 1 : 4) * SB_MT1 * 16 * P1) * 4 + (size_t)(9 * NT1 * NT2 + NT2 * NT3) * 1024;
+  const size_t lds = (size_t)(4 * 96 * P1) * 4 + (size_t)(9 * NT1 * NT2 + NT2 * NT3) * 1024;
   if (attr_only)
     return hipFuncSetAttribute((const void*)yl_stemblock_kernel<NT1, NT2, NT3>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  const int wtiles = p.B * ((p.OW + SB_TC - 1) / SB_TC) * ((p.OH + SB_TR - 1) / SB_TR);
-  int gx = (SB_EXP == 7 ? 3 : 2) * YL_NUM_CU;
-  if (gx > (wtiles + 3) / 4) gx = (wtiles + 3) / 4;
-  if (gx >= 8) gx &= ~7;                                  // multiple of 8: XCD-aware tile ranges (see the kernel)
+  YlConvP p = p0;
+  // strips of ~10 tiles: long enough that the one extra m-tile of a strip's first tile is noise (1.4 of 147 MFMAs per
+  // tile), short enough that every wave of the 2-workgroups-per-CU grid gets several (640 x 640, B = 64: 5 each)
+  const int tpr = (p.OW + SB_TC - 1) / SB_TC, tpc = (p.OH + SB_TR - 1) / SB_TR;
+  int nsp = (tpr + 5) / 10;
+  if (nsp < 1) nsp = 1;
+  p.sb_strip = (tpr + nsp - 1) / nsp;
+  const long nstrips = (long)p.B * tpc * ((tpr + p.sb_strip - 1) / p.sb_strip);
+  int gx = 2 * YL_NUM_CU;
+  if (gx > (nstrips + 3) / 4) gx = (int)((nstrips + 3) / 4);
+  if (gx >= 8) gx &= ~7;                                  // multiple of 8: XCD-aware strip ranges (see the kernel)
   hipLaunchKernelGGL((yl_stemblock_kernel<NT1, NT2, NT3>), dim3(gx), dim3(256), lds, st, p);
   return hipGetLastError();
 }
