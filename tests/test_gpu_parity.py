@@ -834,3 +834,30 @@ def test_pip_api_predict_on_a_seg_checkpoint(tmp_path):
         assert union == 0 or inter / union >= 0.999, (inter, union)
         tot += int(union)
     assert tot > 100, tot
+
+
+@pytest.mark.parametrize("S,B", [(640, 2), (320, 3), (384, 2)])
+def test_ir_fusion_is_bitwise_the_two_launch_form(S, B):
+    """yl_ir_kernel (round 3): yololite_m's early EfficientNet-Lite inverted-residual blocks (stride 1 and 2, TF-SAME
+    pads, 3x3 and 5x5, with and without residual) as ONE launch each -- same k orders, tap order and epilogues as
+    conv_pw followed by depthwise + conv_pwl, so the raw levels must be bit-identical to the unfused program.  640: all
+    seven blocks fuse; 320 / 384: a subset (tile divisibility), the rest runs the two-launch form inside the same model."""
+    meta = zoo_meta("yololite_m", 80, S)
+    sd = synth_state_dict(meta, seed=6)
+    x = _x(B, S, seed=31).to(DEV)
+    mf = ya.build_model_from_meta(meta, fuse_ir=True); mf.load_state_dict(sd); mf.to(DEV)
+    mu = ya.build_model_from_meta(meta, fuse_ir=False); mu.load_state_dict(sd); mu.to(DEV)
+    nf = sum(1 for l in mf.program.layers if l.name.endswith(".ir"))
+    assert nf >= (7 if S == 640 else 2) and not any(l.name.endswith(".ir") for l in mu.program.layers)
+    assert len(mf.program.layers) == len(mu.program.layers) - nf
+    for a, b in zip(mf(x), mu(x)):
+        assert torch.equal(a, b)
+    # and in the bf16-MFMA mode the fused program stays within that mode's bound of the fp32 result
+    ctx = mf._ctx_for(S)
+    ref = [t.clone() for t in mf(x)]
+    ctx.set_option("mfma_bf16", 1)
+    for a, r in zip(mf(x), ref):
+        assert float((a - r).abs().max()) <= 3e-2 * max(float(r.abs().max()), 1.0)
+    ctx.set_option("mfma_bf16", 0)
+    for a, r in zip(mf(x), ref):
+        assert torch.equal(a, r)

@@ -994,12 +994,18 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       const bool uib = (l.op == YL_OP_CONV && l.c2 > 0);
       if (c->slots[l.in_slot].c != (uib ? l.c2 : l.cin)) return bad("cin does not match the input slot");
       if (uib) {
-        if (!l.w2 || l.dw_k == 0 || l.dw_stride != 1 || l.k != 1 || l.head_level >= 0 || l.up_slot >= 0)
-          return bad("fused expand->depthwise->project block: needs w2, a stride-1 depthwise prologue, 1x1 projection");
-        if (!yl_uib_supported(l.c2, l.cin, l.cout, l.dw_k))
-          return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block: shape not instantiated / LDS budget exceeded");
-        if ((c->slots[l.in_slot].h & 3) || (c->slots[l.in_slot].w & 3))
-          return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block needs H,W multiples of 4");
+        if (!l.w2 || l.dw_k == 0 || l.dw_stride < 1 || l.k != 1 || l.head_level >= 0 || l.up_slot >= 0)
+          return bad("fused expand->depthwise->project block: needs w2, a depthwise prologue, 1x1 projection");
+        // workgroup-level halo kernel (yl_ir_kernel: stride 1 / 2, TF-SAME pads) or the per-wave one (yl_uib_kernel)
+        const bool ir = l.out_slot >= 0 && l.out_slot < d->num_slots &&
+                        yl_ir_supported(l.c2, l.cin, l.cout, l.dw_k, l.dw_stride, c->slots[l.out_slot].h, c->slots[l.out_slot].w);
+        if (!ir) {
+          if (l.dw_stride != 1) return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block: stride-2 shape not instantiated");
+          if (!yl_uib_supported(l.c2, l.cin, l.cout, l.dw_k))
+            return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block: shape not instantiated / LDS budget exceeded");
+          if ((c->slots[l.in_slot].h & 3) || (c->slots[l.in_slot].w & 3))
+            return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block needs H,W multiples of 4");
+        }
       }
     }
     // output geometry.  Sizes are declared by the host (slot / level dims); pad_t/pad_l are explicit

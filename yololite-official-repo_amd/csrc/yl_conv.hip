@@ -41,6 +41,7 @@
 #define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #define yl_launch_conv_pws yl_launch_conv_pws_bf16
+#define yl_launch_conv_ir yl_launch_conv_ir_bf16
 #define yl_launch_conv_wino yl_launch_conv_wino_bf16
 #define yl_launch_conv_dwk yl_launch_conv_dwk_bf16
 #define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
@@ -1243,6 +1244,10 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   const int gy = (p.NTtot + NT - 1) / NT;
   if (n > 1 && gy != 1) return hipErrorInvalidValue;
   if (p.C1 > 0) {          // fused inverted-residual block (expand -> depthwise -> project)
+    if (n == 1) {          // workgroup-level halo kernel for the shapes it is instantiated for (yl_convc.hip)
+      const hipError_t ei = yl_launch_conv_ir(p, st);
+      if (ei != hipErrorNotSupported) return ei;
+    }
     if (n != 1 || gy != 1 || (p.OH & 3) || (p.OW & 3) || p.dw_stride != 1) return hipErrorInvalidValue;
     return yl_uib_dispatch(p, yl_uib_lds_bytes(p.Cin, NT, p.dw_k), st, false, NT, p.dw_k, (p.C1 + 15) / 16);
   }

@@ -41,6 +41,9 @@
 #define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
 #define yl_conv_pws_kernel yl_conv_pws_kernel_bf16
 #define yl_launch_conv_pws yl_launch_conv_pws_bf16
+#define yl_ir_kernel yl_ir_kernel_bf16
+#define yl_launch_conv_ir yl_launch_conv_ir_bf16
+#define yl_ir_supported yl_ir_supported_bf16
 #endif
 #include <stdlib.h>
 #include <map>
@@ -1271,6 +1274,257 @@ hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole EfficientNet-style inverted-residual block in ONE launch (round 3):  1x1 expand (+BN+act) -> depthwise DK x DK,
+// stride 1 or 2, TF-SAME or symmetric padding (+BN+act) -> 1x1 project (+BN) (+residual) -- timm's `ir` blocks behind
+// model_v2.py:94-100.  Built for the EARLY blocks of yololite_m (tf_efficientnet_lite2: 16->96->24 at 320x320, 24->144->24 at
+// 160x160, 48->288->48 at 80x80, ...), where the 6x expanded tensor is the largest tensor of the network (1.26 GB at B = 32)
+// and the two-launch form (conv_pw, then depthwise + conv_pwl) spends its time writing and re-reading it at 3-4 TB/s:
+// 2.7 of the model's 17.6 ms.  Here the expanded tensor exists only as one 16-channel SLAB of the workgroup's halo region
+// in LDS.
+//   workgroup tile  8 x 8*MT output pixels, four waves, wave w owns the 4 x 4*MT block (w >> 1, w & 1)
+//   per slab kb     E: the halo region ((8-1)*DS+DK rows x (8 MT-1)*DS+DK columns of expanded pixels, 16-pixel m-tiles
+//                      dealt to the waves) = act(bias + Wexp[kb] . x) by MFMA from the block input held in registers
+//                      for the whole tile, zero outside the image (the depthwise conv pads the EXPANDED tensor) -> LDS;
+//                   barrier (ONE per slab: slabs and projection weights are double-buffered, the counters run on
+//                      across tiles);
+//                   D: B fragment of the lane's pixel = act(bias + sum of taps), taps and weights from LDS, in the tap
+//                      order of yl_conv_dwt_kernel;  P: NT x 4 MFMAs per m-tile against the projection weights of
+//                      the slab (asynchronous global -> LDS copy issued one slab ahead).
+// The old yl_uib_kernel (yl_conv.hip, MobileNetV4 blocks) recomputes the expansion on a (3+DK)^2 halo per 4x4 tile and
+// WAVE: 2.25-4x the expansion MFMAs; the workgroup-level halo here costs 1.2x (stride 2) to 1.9x (5x5 stride 1).  Same
+// k orders (input channel blocks ascending; slabs = the projection's k blocks ascending; taps (dy,dx)) and epilogues as
+// the two-launch form: bit-identical results.
+template <int KBI /*ceil(C1/16)*/, int NT, int DK, int DS, int MT>
+__global__ __launch_bounds__(256, 2) void yl_ir_kernel(YlConvP p) {
+  constexpr int TH = 8, TW = 8 * MT;
+  constexpr int HH = (TH - 1) * DS + DK, HW = (TW - 1) * DS + DK, HN = HH * HW;
+  constexpr int HMT = (HN + 15) / 16, HMW = (HMT + 3) / 4;         // halo m-tiles: all, per wave
+  constexpr int PITCHF = ((HW * 16 + 7) / 64) * 64 + 56;           // slab row pitch in floats (see yl_conv_dwh_kernel)
+  constexpr int SLAB = HH * PITCHF;
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int Cmid = p.Cin, KB = p.KB, NTtot = p.NTtot, C1 = p.C1, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N;
+  float* slab = yl_clds;                                           // [2][SLAB]
+  f32x4* wpl = reinterpret_cast<f32x4*>(yl_clds + 2 * SLAB);       // [2][NT][64] float4: projection weights of a slab
+  float* dwl = yl_clds + 2 * SLAB + 2 * NT * 256;                  // [DK*DK][Cmid] taps, [Cmid] dw bias
+  float* b2l = dwl + (((size_t)(DK * DK + 1) * Cmid + 3) & ~(size_t)3);   // [KB*16] expansion bias
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);          // projection [KB][NTtot][64]
+  const f32x4* w2g = reinterpret_cast<const f32x4*>(p.w2p);        // expansion [KBI][KB][64]
+  const float* const xin = p.x;
+  {
+    const int nw = DK * DK * Cmid;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cmid, tid, 256);
+    else for (int i = tid; i < Cmid; i += 256) dwl[nw + i] = 0.0f;
+    for (int i = tid; i < KB * 16; i += 256) b2l[i] = p.b2[i];
+  }
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float elo = (p.act2 == YL_ACT_RELU || p.act2 == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float ehi = (p.act2 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const int dw_act = p.dw_act, act2 = p.act2;
+  // lane constants: the lane's halo pixel in each of the wave's halo m-tiles (m = wave + 4 j)
+  int h_r[HMW], h_c[HMW], h_lo[HMW];
+  bool h_ok[HMW];
+#pragma unroll
+  for (int j = 0; j < HMW; ++j) {
+    const int q = (wave + 4 * j) * 16 + pl;
+    h_ok[j] = q < HN;
+    const int qq = h_ok[j] ? q : 0;
+    h_r[j] = qq / HW;
+    h_c[j] = qq - h_r[j] * HW;
+    h_lo[j] = h_r[j] * PITCHF + h_c[j] * 16 + 4 * kq;
+  }
+  const int rb = wave >> 1, cb = wave & 1;                         // the wave's 4 x 4 MT block of the tile
+  const int rbase = ((4 * rb + (pl >> 2)) * DS) * PITCHF + ((cb * 4 * MT + (pl & 3)) * DS) * 16 + 4 * kq;
+  const bool pre_add = p.res != nullptr && p.act == YL_ACT_NONE;
+  const int twn = OW / TW, thn = OH / TH;
+  const int tiles_img = twn * thn;
+  const int ntiles = p.B * tiles_img;
+  int tile, tend, tstride;
+  if ((gridDim.x & 7) == 0) {                                      // XCD bands, see yl_conv_dwt_kernel
+    const int tpx = (ntiles + 7) >> 3;
+    const int band0 = (blockIdx.x & 7) * tpx;
+    tend = (band0 + tpx) < ntiles ? (band0 + tpx) : ntiles;
+    tile = band0 + (blockIdx.x >> 3);
+    tstride = gridDim.x >> 3;
+  } else {
+    tile = blockIdx.x; tend = ntiles; tstride = gridDim.x;
+  }
+  auto load_proj = [&](int kb, int buf) {                           // projection weights of slab kb -> LDS (asynchronous)
+    for (int nt = wave; nt < NT; nt += 4)
+      yl_glds16(wg + ((size_t)kb * NTtot + (nt < NTtot ? nt : NTtot - 1)) * 64 + lane, wpl + ((size_t)buf * NT + nt) * 64);
+  };
+  unsigned gs = 0;                                                  // slabs started by this workgroup (buffer = gs & 1)
+  if (tile < tend) load_proj(0, 0);
+  __syncthreads();
+
+  for (; tile < tend; tile += tstride) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / twn, txi = trem - tyi * twn;
+    const int iy0 = tyi * TH * DS - p.dw_pad_t, ix0 = txi * TW * DS - p.dw_pad_l;
+    YlPix px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      px[mt].b = b;
+      px[mt].oy = tyi * TH + 4 * rb + (pl >> 2);
+      px[mt].ox = txi * TW + cb * 4 * MT + 4 * mt + (pl & 3);
+      px[mt].valid = true;
+      px[mt].lin = ((size_t)b * OH + px[mt].oy) * OW + px[mt].ox;
+    }
+    // block input at the lane's halo pixels: B fragments of the expansion GEMM, resident for the tile
+    f32x4 xh[HMW][KBI];
+    bool h_in[HMW];
+#pragma unroll
+    for (int j = 0; j < HMW; ++j) {
+      const int iy = iy0 + h_r[j], ix = ix0 + h_c[j];
+      h_in[j] = h_ok[j] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float* src = xin + (((size_t)b * H + iy) * W + ix) * C1 + 4 * kq;
+#pragma unroll
+      for (int kbi = 0; kbi < KBI; ++kbi) {
+        const bool ok = h_in[j] && (kbi * 16 + 4 * kq) < C1;
+        xh[j][kbi] = yl_ld4(ok ? src + kbi * 16 : p.zeros);
+      }
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int n = nt * 16 + 4 * kq;
+        if (pre_add && n < N) acc[mt][nt] = yl_ld4(p.res + px[mt].lin * N + n);
+      }
+    f32x4 we[KBI], wn[KBI];
+#pragma unroll
+    for (int kbi = 0; kbi < KBI; ++kbi) wn[kbi] = w2g[((size_t)kbi * KB + 0) * 64 + lane];
+    for (int kb = 0; kb < KB; ++kb, ++gs) {
+      const int buf = (int)(gs & 1u);
+#pragma unroll
+      for (int kbi = 0; kbi < KBI; ++kbi) we[kbi] = wn[kbi];
+      if (kb + 1 < KB) {
+#pragma unroll
+        for (int kbi = 0; kbi < KBI; ++kbi) wn[kbi] = w2g[((size_t)kbi * KB + kb + 1) * 64 + lane];
+      }
+      // ---- E: expansion slab on the wave's halo m-tiles -> LDS
+      const f32x4 eb = yl_ld4(b2l + kb * 16 + 4 * kq);
+      float* sb = slab + buf * SLAB;
+#pragma unroll
+      for (int j = 0; j < HMW; ++j) {
+        f32x4 e[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+        for (int kbi = 0; kbi < KBI; ++kbi) {
+          const f32x4 wq1[1] = {we[kbi]};
+          const f32x4 xq1[1] = {xh[j][kbi]};
+          yl_mma_step<1, 1>(wq1, xq1, e);
+        }
+        const f32x4 v = yl_sel4(h_in[j], yl_actc(e[0][0] + eb, act2, elo, ehi));   // zero padding of the EXPANDED tensor
+        if (h_ok[j]) *reinterpret_cast<f32x4*>(sb + h_lo[j]) = v;
+      }
+      __syncthreads();                 // slab `buf` complete; the projection weights of this slab have landed
+      if (kb + 1 < KB) load_proj(kb + 1, buf ^ 1);
+      else if (tile + tstride < tend) load_proj(0, buf ^ 1);        // first slab of the workgroup's next tile
+      // ---- D: depthwise on the slab -> B fragments
+      const int c = kb * 16 + 4 * kq;
+      const int cs = c < Cmid ? c : Cmid - 4;
+      const float* tapw = dwl + cs;
+      f32x4 xq[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_ld4(tapw + DK * DK * Cmid);
+      auto tap_row = [&](int dy) {
+#pragma unroll
+        for (int dx = 0; dx < DK; ++dx) {
+          const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * Cmid);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sb + rbase + dy * PITCHF + (dx + 4 * mt * DS) * 16);
+            xq[mt].x = fmaf(v.x, w.x, xq[mt].x); xq[mt].y = fmaf(v.y, w.y, xq[mt].y);
+            xq[mt].z = fmaf(v.z, w.z, xq[mt].z); xq[mt].w = fmaf(v.w, w.w, xq[mt].w);
+          }
+        }
+      };
+      if (DK == 3) {
+#pragma unroll
+        for (int dy = 0; dy < DK; ++dy) tap_row(dy);
+      } else {
+#pragma unroll 1
+        for (int dy = 0; dy < DK; ++dy) tap_row(dy);                 // one tap row at a time bounds the register footprint
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_actc(xq[mt], dw_act, dlo, dhi);
+      // channel tail (c >= Cmid): the packed projection weights of those k slots are zero, no select needed
+      // ---- P: projection
+      f32x4 wq[NT];
+      const f32x4* wrow = wpl + (size_t)buf * NT * 64 + lane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
+      yl_mma_step<NT, MT>(wq, xq, acc);
+    }
+    if (!pre_add && (p.res || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
+    else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
+  }
+}
+
+static size_t yl_ir_lds(int dk, int ds, int mt, int nt, int cmid) {
+  const int hh = 7 * ds + dk, hw = (8 * mt - 1) * ds + dk;
+  const int pitch = ((hw * 16 + 7) / 64) * 64 + 56;
+  return ((size_t)2 * hh * pitch + (size_t)2 * nt * 256 + ((((size_t)(dk * dk + 1) * cmid) + 3) & ~(size_t)3) + (size_t)((cmid + 15) / 16) * 16) * 4;
+}
+
+template <int KBI, int NT, int DK, int DS, int MT>
+static hipError_t ir_go(const YlConvP& p, hipStream_t st, bool attr_only) {
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_ir_kernel<KBI, NT, DK, DS, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  const size_t lds = yl_ir_lds(DK, DS, MT, NT, p.Cin);
+  const long ntiles = (long)p.B * (p.OH / 8) * (p.OW / (8 * MT));
+  int gx = yl_resident_blocks_n(yl_ir_kernel<KBI, NT, DK, DS, MT>, 256, lds);
+  if (gx > ntiles) gx = (int)ntiles;
+  if (gx >= 8) gx &= ~7;
+  hipLaunchKernelGGL((yl_ir_kernel<KBI, NT, DK, DS, MT>), dim3(gx), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+// instantiated shapes: (input k-blocks, projection n-tiles, dw k, dw stride, m-tiles per wave)
+#define YL_IR_SHAPES(X) X(1, 2, 3, 2, 1) X(2, 2, 3, 1, 2) X(2, 3, 5, 2, 1) X(3, 3, 5, 1, 2) X(3, 6, 3, 2, 1)
+
+// fused inverted-residual block (p.C1 > 0).  hipErrorNotSupported: shape not instantiated (yl_uib_kernel or the
+// two-launch form handles it -- yl_ir_supported tells the host compiler beforehand)
+bool yl_ir_supported(int c1, int cmid, int n, int dk, int ds, int oh, int ow) {
+  const int kbi = (c1 + 15) / 16, nt = (n + 15) / 16;
+#define YL_IR_CHECK(A, B, C, D, E) \
+  if (kbi == A && nt <= B && nt > (B == 2 ? 0 : B == 3 ? 2 : 3) && dk == C && ds == D && (oh % 8) == 0 && (ow % (8 * E)) == 0 && \
+      yl_ir_lds(C, D, E, B, cmid) <= 150 * 1024) return true;
+  YL_IR_SHAPES(YL_IR_CHECK)
+#undef YL_IR_CHECK
+  return false;
+}
+
+hipError_t yl_launch_conv_ir(const YlConvP& p, hipStream_t st) {
+  if (p.C1 <= 0 || p.k != 1 || p.dw_k == 0 || (p.N & 3)) return hipErrorNotSupported;
+  const int kbi = (p.C1 + 15) / 16, nt = p.NTtot;
+#define YL_IR_RUN(A, B, C, D, E) \
+  if (kbi == A && nt <= B && nt > (B == 2 ? 0 : B == 3 ? 2 : 3) && p.dw_k == C && p.dw_stride == D && (p.OH % 8) == 0 && \
+      (p.OW % (8 * E)) == 0 && yl_ir_lds(C, D, E, B, p.Cin) <= 150 * 1024) return ir_go<A, B, C, D, E>(p, st, false);
+  YL_IR_SHAPES(YL_IR_RUN)
+#undef YL_IR_RUN
+  return hipErrorNotSupported;
+}
+
+static hipError_t yl_ir_init() {
+  YlConvP q = {};
+  hipError_t e = hipSuccess;
+#define YL_IR_ATTR(A, B, C, D, E) if (e == hipSuccess) e = ir_go<A, B, C, D, E>(q, nullptr, true);
+  YL_IR_SHAPES(YL_IR_ATTR)
+#undef YL_IR_ATTR
+  return e;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Depthwise 3x3 -> 1x1 convolution whose 1x1 weights do not fit LDS (edge_m's 244-channel and yololite_m's
 // 328-channel neck / head blocks, model_v2.py:24-41: 240-430 KB packed).  yl_conv_dwh_kernel cannot hold the image and
 // the layer fell to yl_conv_mfma_kernel's streamed mode (48 TFLOP/s: fill / use barriers, 21 n-tiles as 8 + 8 + 5).
@@ -1727,6 +1981,7 @@ hipError_t yl_convc_init() {
   if (e == hipSuccess) e = kxk_go<7, 1, 8>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<4, 1, 8>(q, 1, nullptr, true);
   if (e == hipSuccess) e = kxk_go<4, 2, 4>(q, 1, nullptr, true);
+  if (e == hipSuccess) e = yl_ir_init();
   if (e == hipSuccess) e = pws_nw<6>(q, nullptr, false, true);
   if (e == hipSuccess) e = pws_nw<7>(q, nullptr, false, true);
   if (e == hipSuccess) e = pws_nw<8>(q, nullptr, false, true);

@@ -150,6 +150,10 @@ hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_pwt_bf16(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st);
 hipError_t yl_launch_conv_pwt_multi_bf16(const YlConvP* ps, int n, hipStream_t st);
+// fused inverted-residual block with a workgroup-level halo (yl_convc.hip, round 3); hipErrorNotSupported = yl_uib_kernel
+hipError_t yl_launch_conv_ir(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv_ir_bf16(const YlConvP& p, hipStream_t st);
+bool yl_ir_supported(int c1, int cmid, int n, int dk, int ds, int oh, int ow);
 // plain 1x1 conv with a double-buffered weight stream for wide layers (yl_convc.hip); hipErrorNotSupported = pwt runs it
 hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_pws_bf16(const YlConvP& p, hipStream_t st);

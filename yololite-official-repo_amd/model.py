@@ -341,9 +341,9 @@ class YOLOLiteHIP:
     checkpoint's meta, weights attached with load_state_dict(), moved with .to(device), called with
     a [B,3,S,S] float tensor, returns the list of level tensors."""
 
-    def __init__(self, meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False):
+    def __init__(self, meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False, fuse_ir=None):
         self.meta = meta
-        self.fuse_dw, self.fuse_stem, self.fuse_uib = fuse_dw, fuse_stem, fuse_uib
+        self.fuse_dw, self.fuse_stem, self.fuse_uib, self.fuse_ir = fuse_dw, fuse_stem, fuse_uib, fuse_ir
         self.export_concat = False
         self.program: Optional[Program] = None
         self.ctx: Optional[HipContext] = None
@@ -362,7 +362,7 @@ class YOLOLiteHIP:
         missing weights raise."""
         try:
             self.program = build_program(self.meta, state_dict, fuse_dw=self.fuse_dw, fuse_stem=self.fuse_stem,
-                                         fuse_uib=self.fuse_uib)
+                                         fuse_uib=self.fuse_uib, fuse_ir=self.fuse_ir)
         except KeyError as e:
             raise RuntimeError(f"checkpoint lacks a weight the forward pass needs: {e.args[0]}") from None
         self._sd = state_dict
@@ -389,7 +389,7 @@ class YOLOLiteHIP:
         if img_size not in self._ctxs:
             p = self.program if img_size == self.program.img_size else \
                 build_program(self.meta, self._sd, fuse_dw=self.fuse_dw, img_size=img_size, fuse_stem=self.fuse_stem,
-                              fuse_uib=self.fuse_uib)
+                              fuse_uib=self.fuse_uib, fuse_ir=self.fuse_ir)
             self._ctxs[img_size] = (p, HipContext(p.img_size, p.num_classes, p.level_size, p.level_anchors, p,
                                                   self._device_index))
         return self._ctxs[img_size][1]
@@ -422,9 +422,10 @@ class YOLOLiteHIP:
     forward = __call__
 
 
-def build_model_from_meta(meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False) -> YOLOLiteHIP:
+def build_model_from_meta(meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False,
+                          fuse_ir=None) -> YOLOLiteHIP:
     """tools/infer.py:34-77."""
-    return YOLOLiteHIP(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib)
+    return YOLOLiteHIP(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib, fuse_ir=fuse_ir)
 
 
 def load_model_names_imgsize_from_ckpt(weights: str, device):

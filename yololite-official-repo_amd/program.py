@@ -17,6 +17,7 @@ nearest-upsample-add / activation epilogues, one GEMM for the three head output 
 from __future__ import annotations
 
 import math
+import os
 import zlib
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -255,8 +256,9 @@ DW_PROLOGUE_LDS_MAX = 32 * 1024      # bytes; mirrors YL_DW_LDS_MAX in csrc/yl_a
 
 
 class _Builder:
-    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw, fuse_stem=True, fuse_uib=True):
+    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw, fuse_stem=True, fuse_uib=True, fuse_ir=True):
         self.sd, self.p, self.fuse_dw, self.fuse_stem, self.fuse_uib = sd, prog, fuse_dw, fuse_stem, fuse_uib
+        self.fuse_ir = fuse_ir
 
     # ---- state-dict access
     def get(self, key: str, shape: Tuple[int, ...]) -> np.ndarray:
@@ -349,20 +351,41 @@ class _Builder:
         lds = kb * nt * 1024 + (dk * dk + 1) * cmid * 4 + kb * 64 + 4 * hp * pitch * 64
         return lds <= 144 * 1024
 
+    # shapes instantiated by yl_launch_conv_ir (csrc/yl_convc.hip: YL_IR_SHAPES): (input k-blocks, projection n-tile
+    # bucket, dw k, dw stride, m-tiles per wave) -- the workgroup-level-halo kernel for EfficientNet-style blocks
+    _IR_SHAPES = ((1, 2, 3, 2, 1), (2, 2, 3, 1, 2), (2, 3, 5, 2, 1), (3, 3, 5, 1, 2), (3, 6, 3, 2, 1))
+
+    def ir_fusable(self, x, cmid, cout, dk, ds, oh, ow):
+        """mirror of yl_ir_supported (csrc/yl_convc.hip)"""
+        if not self.fuse_ir:
+            return False
+        c1 = self.dims(x)[2]
+        kbi, nt = -(-c1 // 16), -(-cout // 16)
+        for (a, bk, c, d, e) in self._IR_SHAPES:
+            lo = 0 if bk == 2 else (2 if bk == 3 else 3)
+            if kbi == a and lo < nt <= bk and dk == c and ds == d and oh % 8 == 0 and ow % (8 * e) == 0:
+                hh, hw = 7 * d + c, (8 * e - 1) * d + c
+                pitch = ((hw * 16 + 7) // 64) * 64 + 56
+                lds = (2 * hh * pitch + 2 * bk * 256 + (((c * c + 1) * cmid + 3) & ~3) + -(-cmid // 16) * 16) * 4
+                return lds <= 150 * 1024
+        return False
+
     def uib(self, x, pre, eps, act, cmid, cout, dk, res,
-            keys=("pw_exp.conv", "pw_exp.bn", "dw_mid.conv", "dw_mid.bn", "pw_proj.conv", "pw_proj.bn")):
-        """pw_exp(+BN+act) -> dw_mid dk x dk s1 (+BN+act) -> pw_proj(+BN)(+res) as ONE launch.  `keys`: parameter names
-        of the three conv / BN pairs (MobileNetV4 UIB by default; EfficientNet-style InvertedResidual passes its own)."""
+            keys=("pw_exp.conv", "pw_exp.bn", "dw_mid.conv", "dw_mid.bn", "pw_proj.conv", "pw_proj.bn"), ds=1, same=False):
+        """pw_exp(+BN+act) -> dw_mid dk x dk (stride ds) (+BN+act) -> pw_proj(+BN)(+res) as ONE launch.  `keys`: parameter
+        names of the three conv / BN pairs (MobileNetV4 UIB by default; EfficientNet-style InvertedResidual passes its own)."""
         h, w, c1 = self.dims(x)
+        oh, pad = self.geom(h, dk, ds, same)
+        ow, _ = self.geom(w, dk, ds, same)
         w2, b2 = self.fold(pre + keys[0], pre + keys[1], eps, False, (cmid, c1, 1, 1))
         dww, dwb = self.fold(pre + keys[2], pre + keys[3], eps, False, (cmid, 1, dk, dk))
         wp, bp = self.fold(pre + keys[4], pre + keys[5], eps, False, (cout, cmid, 1, 1))
-        o = self.slot(h, w, cout)
+        o = self.slot(oh, ow, cout)
         L = Layer(_OP_CONV, x, o, cmid, cout, 1, 1, 0, 0, _ACT["none"], wp, bp, res_slot=res,
-                  dw_k=dk, dw_stride=1, dw_pad_t=dk // 2, dw_pad_l=dk // 2, dw_act=_ACT[act], dw_w=dww, dw_b=dwb,
-                  c2=c1, act2=_ACT[act], w2=w2, b2=b2, name=pre + "uib",
-                  macs=h * w * (c1 * cmid + cmid * dk * dk + cmid * cout),
-                  bytes_in=4 * h * w * c1 * (2 if res >= 0 else 1), bytes_out=4 * h * w * cout)
+                  dw_k=dk, dw_stride=ds, dw_pad_t=pad, dw_pad_l=pad, dw_act=_ACT[act], dw_w=dww, dw_b=dwb,
+                  c2=c1, act2=_ACT[act], w2=w2, b2=b2, name=pre + ("ir" if keys[0] == "conv_pw" else "uib"),
+                  macs=h * w * c1 * cmid + oh * ow * (cmid * dk * dk + cmid * cout),
+                  bytes_in=4 * (h * w * c1 + (oh * ow * cout if res >= 0 else 0)), bytes_out=4 * oh * ow * cout)
         self.p.layers.append(L)
         return o
 
@@ -478,6 +501,12 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
                     dw = dict(conv=pre + "conv_dw", bn=pre + "bn1", eps=eps, act=act, k=d["k"], s=s)
                     x = b.conv(x, pre + "conv_pw", pre + "bn2", eps, "none", cout, same=same, dw=dw,
                                res=(x if skip else -1))
+                elif d["type"] == "ir" and b.ir_fusable(x, _make_divisible(cin * d["e"], 8), cout, d["k"], s,
+                                                        b.geom(b.dims(x)[0], d["k"], s, same)[0], b.geom(b.dims(x)[1], d["k"], s, same)[0]):
+                    # the early EfficientNet blocks (6x expanded tensor at 320x320 ... 80x80): one launch, the expanded
+                    # tensor only as 16-channel slabs of a workgroup's halo region in LDS (yl_ir_kernel, round 3)
+                    x = b.uib(x, pre, eps, act, _make_divisible(cin * d["e"], 8), cout, d["k"], x if skip else -1,
+                              keys=("conv_pw", "bn1", "conv_dw", "bn2", "conv_pwl", "bn3"), ds=s, same=same)
                 elif d["type"] == "ir" and s == 1 and b.uib_fusable(x, _make_divisible(cin * d["e"], 8), cout, d["k"]):
                     # (fuse_uib only; stride 1: TF-SAME padding is the symmetric k // 2 the fused kernel applies.  Measured
                     # on yololite_m B=32: 144-channel dw3 blocks @160x160 0.39 -> 0.35 ms, 288-channel dw5 blocks @80x80
@@ -502,11 +531,16 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
 
 
 def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto",
-                  img_size: Optional[int] = None, fuse_stem: bool = True, fuse_uib: bool = False) -> Program:
+                  img_size: Optional[int] = None, fuse_stem: bool = True, fuse_uib: bool = False,
+                  fuse_ir: Optional[bool] = None) -> Program:
     """meta: the checkpoint's `meta` dict (tools/train.py:62-75); reads the keys
     build_model_from_meta reads (tools/infer.py:35-50).
     fuse_dw: True = every depthwise conv becomes the prologue of the following 1x1 conv, False = none,
-    "dw3" = only 3x3; "auto" = measured best policy (currently: all, LDS-halo kernel)."""
+    "dw3" = only 3x3; "auto" = measured best policy (currently: all, LDS-halo kernel).
+    fuse_ir: EfficientNet-style inverted-residual blocks of the shapes yl_ir_kernel is instantiated for as ONE launch
+    (default on; None reads YL_FUSE_IR, "0" = off for A/B runs)."""
+    if fuse_ir is None:
+        fuse_ir = os.environ.get("YL_FUSE_IR", "1") != "0"
     cfg = meta.get("config", {}) or {}
     mcfg = cfg.get("model", {}) or {}
     tcfg = cfg.get("training", {}) or {}
@@ -534,7 +568,8 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     else:
         sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
     prog = Program(img_size=S, num_classes=C, level_size=[], level_anchors=[], strides=[])
-    b = _Builder(sd, prog, fuse_dw, fuse_stem, bool(fuse_uib) and fuse_dw is not False)
+    b = _Builder(sd, prog, fuse_dw, fuse_stem, bool(fuse_uib) and fuse_dw is not False,
+                 bool(fuse_ir) and fuse_dw is not False)
 
     feats = _backbone(b, backbone)
     take = 4 if use_p2 else 3
