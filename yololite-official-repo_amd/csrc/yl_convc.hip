@@ -1490,7 +1490,7 @@ static hipError_t ir_go(const YlConvP& p, hipStream_t st, bool attr_only) {
 }
 
 // instantiated shapes: (input k-blocks, projection n-tiles, dw k, dw stride, m-tiles per wave)
-#define YL_IR_SHAPES(X) X(1, 2, 3, 2, 1) X(2, 2, 3, 1, 2) X(2, 3, 5, 2, 1) X(3, 3, 5, 1, 2) X(3, 6, 3, 2, 1)
+#define YL_IR_SHAPES(X) X(1, 2, 3, 2, 1) X(2, 2, 3, 1, 2) X(2, 3, 5, 2, 1) X(3, 3, 5, 1, 2) X(3, 6, 3, 2, 1) X(3, 3, 3, 1, 1) X(6, 6, 3, 1, 1)
 
 // fused inverted-residual block (p.C1 > 0).  hipErrorNotSupported: shape not instantiated (yl_uib_kernel or the
 // two-launch form handles it -- yl_ir_supported tells the host compiler beforehand)

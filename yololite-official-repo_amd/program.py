@@ -353,7 +353,8 @@ class _Builder:
 
     # shapes instantiated by yl_launch_conv_ir (csrc/yl_convc.hip: YL_IR_SHAPES): (input k-blocks, projection n-tile
     # bucket, dw k, dw stride, m-tiles per wave) -- the workgroup-level-halo kernel for EfficientNet-style blocks
-    _IR_SHAPES = ((1, 2, 3, 2, 1), (2, 2, 3, 1, 2), (2, 3, 5, 2, 1), (3, 3, 5, 1, 2), (3, 6, 3, 2, 1))
+    _IR_SHAPES = ((1, 2, 3, 2, 1), (2, 2, 3, 1, 2), (2, 3, 5, 2, 1), (3, 3, 5, 1, 2), (3, 6, 3, 2, 1), (3, 3, 3, 1, 1),
+                  (6, 6, 3, 1, 1))
 
     def ir_fusable(self, x, cmid, cout, dk, ds, oh, ow):
         """mirror of yl_ir_supported (csrc/yl_convc.hip)"""
@@ -482,6 +483,12 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
                 skip = (cin == cout and s == 1)
                 if d["type"] == "cn":
                     x = b.conv(x, pre + "conv", pre + "bn1", eps, act, cout, d["k"], s, same)
+                elif d["type"] == "uir" and not d["a"] and d["k"] and not same and os.environ.get("YL_FUSE_UIR", "1") != "0" and \
+                        b.ir_fusable(x, _make_divisible(cin * d["e"], 8), cout, d["k"], s,
+                                     b.geom(b.dims(x)[0], d["k"], s, same)[0], b.geom(b.dims(x)[1], d["k"], s, same)[0]):
+                    # MobileNetV4 UIB blocks without a start depthwise, at the shapes yl_ir_kernel is instantiated for
+                    # (the 40x40 stage of edge_n / edge_m): expand -> dw -> project in one launch
+                    x = b.uib(x, pre, eps, act, _make_divisible(cin * d["e"], 8), cout, d["k"], x if skip else -1, ds=s, same=same)
                 elif d["type"] == "uir" and not d["a"] and d["k"] and s == 1 and not same and \
                         b.uib_fusable(x, _make_divisible(cin * d["e"], 8), cout, d["k"]):
                     x = b.uib(x, pre, eps, act, _make_divisible(cin * d["e"], 8), cout, d["k"], x if skip else -1)
