@@ -65,14 +65,19 @@ def test_program_edge_n_macs_and_layout():
     assert abs(p.macs - 796.39e6) < 0.05e6
     assert p.level_size == [80, 40, 20] and p.level_anchors == [1, 1, 1] and p.strides == [8, 16, 32]
     assert [p.slots[p.feature_slots[k]] for k in ("c3", "c4", "c5")] == [(80, 80, 32), (40, 40, 48), (20, 20, 480)]
-    nconv = sum(1 + (l.dw_k > 0) for l in p.layers)     # SURVEY App. A counts the head box/obj/cls convs as one row
+    # SURVEY App. A counts the head box/obj/cls convs as one row; a fused inverted-residual launch (yl_ir_kernel: c2 > 0)
+    # holds three convs (expand, depthwise, project)
+    nconv = sum(1 + (l.dw_k > 0) + (l.op == 1 and l.c2 > 0) for l in p.layers)
     assert nconv == 63
     p2 = build_program(meta, synth_state_dict(meta), fuse_dw=False, fuse_stem=False, fuse_uib=False)
     assert len(p2.layers) > len(p.layers) and p2.macs == p.macs
     p3 = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=True, fuse_uib=False)   # 3 entry convs -> 1 launch
     assert len(p3.layers) == len(p.layers) - 2 and p3.macs == p.macs and p3.layers[0].op == 3
-    p4 = build_program(meta, synth_state_dict(meta), fuse_uib=True)     # + 8 inverted-residual blocks as one launch each
-    assert len(p4.layers) == len(p3.layers) - 8 and p4.macs == p.macs
+    # the four 40x40 blocks are one launch each by default (yl_ir_kernel, round 3); fuse_uib adds the four 20x20 ones
+    p0 = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=True, fuse_uib=False, fuse_ir=False)
+    assert len(p3.layers) == len(p0.layers) - 4 and p0.macs == p.macs
+    p4 = build_program(meta, synth_state_dict(meta), fuse_uib=True)     # 8 inverted-residual blocks as one launch each
+    assert len(p4.layers) == len(p0.layers) - 8 and p4.macs == p.macs
 
 
 @pytest.mark.parametrize("name,feat", [("edge_m", [(80, 80, 64), (40, 40, 96), (20, 20, 960)]),
