@@ -1295,7 +1295,7 @@ hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
 // k orders (input channel blocks ascending; slabs = the projection's k blocks ascending; taps (dy,dx)) and epilogues as
 // the two-launch form: bit-identical results.
 template <int KBI /*ceil(C1/16)*/, int NT, int DK, int DS, int MT>
-__global__ __launch_bounds__(256, 2) void yl_ir_kernel(YlConvP p) {
+__global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 3) ? 3 : 2) void yl_ir_kernel(YlConvP p) {
   constexpr int TH = 8, TW = 8 * MT;
   constexpr int HH = (TH - 1) * DS + DK, HW = (TW - 1) * DS + DK, HN = HH * HW;
   constexpr int HMT = (HN + 15) / 16, HMW = (HMT + 3) / 4;         // halo m-tiles: all, per wave
@@ -1448,13 +1448,8 @@ __global__ __launch_bounds__(256, 2) void yl_ir_kernel(YlConvP p) {
           }
         }
       };
-      if (DK == 3) {
-#pragma unroll
-        for (int dy = 0; dy < DK; ++dy) tap_row(dy);
-      } else {
 #pragma unroll 1
-        for (int dy = 0; dy < DK; ++dy) tap_row(dy);                 // one tap row at a time bounds the register footprint
-      }
+      for (int dy = 0; dy < DK; ++dy) tap_row(dy);                   // one tap row at a time bounds the register footprint
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_actc(xq[mt], dw_act, dlo, dhi);
       // channel tail (c >= Cmid): the packed projection weights of those k slots are zero, no select needed
@@ -1490,7 +1485,7 @@ static hipError_t ir_go(const YlConvP& p, hipStream_t st, bool attr_only) {
 }
 
 // instantiated shapes: (input k-blocks, projection n-tiles, dw k, dw stride, m-tiles per wave)
-#define YL_IR_SHAPES(X) X(1, 2, 3, 2, 1) X(2, 2, 3, 1, 2) X(2, 3, 5, 2, 1) X(3, 3, 5, 1, 2) X(3, 6, 3, 2, 1) X(3, 3, 3, 1, 1) X(6, 6, 3, 1, 1)
+#define YL_IR_SHAPES(X) X(1, 2, 3, 2, 1) X(2, 2, 3, 1, 2) X(2, 3, 5, 2, 1) X(3, 3, 5, 1, 2) X(3, 6, 3, 2, 1) X(3, 3, 3, 1, 1)
 
 // fused inverted-residual block (p.C1 > 0).  hipErrorNotSupported: shape not instantiated (yl_uib_kernel or the
 // two-launch form handles it -- yl_ir_supported tells the host compiler beforehand)

@@ -353,8 +353,7 @@ class _Builder:
 
     # shapes instantiated by yl_launch_conv_ir (csrc/yl_convc.hip: YL_IR_SHAPES): (input k-blocks, projection n-tile
     # bucket, dw k, dw stride, m-tiles per wave) -- the workgroup-level-halo kernel for EfficientNet-style blocks
-    _IR_SHAPES = ((1, 2, 3, 2, 1), (2, 2, 3, 1, 2), (2, 3, 5, 2, 1), (3, 3, 5, 1, 2), (3, 6, 3, 2, 1), (3, 3, 3, 1, 1),
-                  (6, 6, 3, 1, 1))
+    _IR_SHAPES = ((1, 2, 3, 2, 1), (2, 2, 3, 1, 2), (2, 3, 5, 2, 1), (3, 3, 5, 1, 2), (3, 6, 3, 2, 1), (3, 3, 3, 1, 1))
 
     def ir_fusable(self, x, cmid, cout, dk, ds, oh, ow):
         """mirror of yl_ir_supported (csrc/yl_convc.hip)"""
