@@ -84,8 +84,10 @@ typedef struct {
   const float* dw_b;          /* [cin] or NULL                                                    */
   /* YL_OP_STEMBLOCK: second and optional third conv of the fused entry block.
    * YL_OP_CONV with c2 > 0: fused inverted-residual block -- in_slot has c2 channels, w2/b2/act2 is the 1x1
-   * EXPANSION [cin][c2][1][1] applied first, then the depthwise prologue (dw_*, stride 1) on the cin expanded
-   * channels, then the 1x1 projection (w,b,act,res_slot); the expanded tensor never reaches HBM.
+   * EXPANSION [cin][c2][1][1] applied first, then the depthwise prologue (dw_*, stride 1 or 2) on the cin expanded
+   * channels, then the 1x1 projection (w,b,act,res_slot); the expanded tensor never reaches HBM.  With up_slot >= 0
+   * (cin channels) the nearest-upsampled tensor is added to the EXPANSION's output before act2 -- the FPN pair
+   * "lateral 1x1 (+bias) + upsample-add, then depthwise smooth block" (model_v2.py:359-361) as one launch.
    * 0 / NULL otherwise. */
   int32_t c2, act2;           /* STEMBLOCK: 3x3 stride-2 pad-1 conv [c2][cout][3][3]              */
   int32_t c3, act3;           /* 1x1 conv: [c3][c2][1][1]; c3 = 0 -> absent                       */

@@ -994,12 +994,13 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       const bool uib = (l.op == YL_OP_CONV && l.c2 > 0);
       if (c->slots[l.in_slot].c != (uib ? l.c2 : l.cin)) return bad("cin does not match the input slot");
       if (uib) {
-        if (!l.w2 || l.dw_k == 0 || l.dw_stride < 1 || l.k != 1 || l.head_level >= 0 || l.up_slot >= 0)
+        if (!l.w2 || l.dw_k == 0 || l.dw_stride < 1 || l.k != 1 || l.head_level >= 0)
           return bad("fused expand->depthwise->project block: needs w2, a depthwise prologue, 1x1 projection");
         // workgroup-level halo kernel (yl_ir_kernel: stride 1 / 2, TF-SAME pads) or the per-wave one (yl_uib_kernel)
         const bool ir = l.out_slot >= 0 && l.out_slot < d->num_slots &&
                         yl_ir_supported(l.c2, l.cin, l.cout, l.dw_k, l.dw_stride, c->slots[l.out_slot].h, c->slots[l.out_slot].w);
         if (!ir) {
+          if (l.up_slot >= 0) return fail(c, YL_ERR_UNSUPPORTED, "fused block with an upsample-add: shape not instantiated");
           if (l.dw_stride != 1) return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block: stride-2 shape not instantiated");
           if (!yl_uib_supported(l.c2, l.cin, l.cout, l.dw_k))
             return fail(c, YL_ERR_UNSUPPORTED, "fused inverted-residual block: shape not instantiated / LDS budget exceeded");
@@ -1049,7 +1050,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     }
     if (l.up_slot >= 0) {
       if (l.up_slot >= d->num_slots || l.op != YL_OP_CONV) return bad("bad up_slot");
-      if (c->slots[l.up_slot].c != l.cout) return bad("upsample source channel mismatch");
+      // (fused block: the addend joins the EXPANDED tensor, cin channels)
+      if (c->slots[l.up_slot].c != ((l.op == YL_OP_CONV && l.c2 > 0) ? l.cin : l.cout)) return bad("upsample source channel mismatch");
     }
     if (l.op == YL_OP_DW && l.cin != l.cout) return bad("depthwise needs cin == cout");
     if (l.op != YL_OP_STEM && l.op != YL_OP_STEMBLOCK && (l.cin & 3)) return fail(c, YL_ERR_UNSUPPORTED, "cin must be a multiple of 4");

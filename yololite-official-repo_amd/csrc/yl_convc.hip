@@ -1313,6 +1313,7 @@ __global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);          // projection [KB][NTtot][64]
   const f32x4* w2g = reinterpret_cast<const f32x4*>(p.w2p);        // expansion [KBI][KB][64]
   const float* const xin = p.x;
+  const float* const up = p.up;                                     // FPN lateral + smooth pair: addend of the expansion
   {
     const int nw = DK * DK * Cmid;
     yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
@@ -1380,10 +1381,13 @@ __global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 
     // block input at the lane's halo pixels: B fragments of the expansion GEMM, resident for the tile
     f32x4 xh[HMW][KBI];
     bool h_in[HMW];
+    long uoff[HMW];
 #pragma unroll
     for (int j = 0; j < HMW; ++j) {
       const int iy = iy0 + h_r[j], ix = ix0 + h_c[j];
       h_in[j] = h_ok[j] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      uoff[j] = 0;
+      if (up && h_in[j]) uoff[j] = ((((long)b * p.UH + (iy * p.UH) / H) * p.UW + (ix * p.UW) / W) * Cmid) + 4 * kq;
       const float* src = xin + (((size_t)b * H + iy) * W + ix) * C1 + 4 * kq;
 #pragma unroll
       for (int kbi = 0; kbi < KBI; ++kbi) {
@@ -1417,6 +1421,11 @@ __global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 
 #pragma unroll
       for (int j = 0; j < HMW; ++j) {
         f32x4 e[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
+        if (up) {       // FPN lateral: the nearest-upsampled coarser level initialises the accumulator (the order of
+                        // the stand-alone lateral conv: (addend + products) + bias)
+          const float* us = up + uoff[j] + kb * 16;
+          e[0][0] = yl_ld4((h_in[j] && kb * 16 + 4 * kq < Cmid) ? us : p.zeros);
+        }
 #pragma unroll
         for (int kbi = 0; kbi < KBI; ++kbi) {
           const f32x4 wq1[1] = {we[kbi]};
@@ -1485,7 +1494,7 @@ static hipError_t ir_go(const YlConvP& p, hipStream_t st, bool attr_only) {
 }
 
 // instantiated shapes: (input k-blocks, projection n-tiles, dw k, dw stride, m-tiles per wave)
-#define YL_IR_SHAPES(X) X(1, 2, 3, 2, 1) X(2, 2, 3, 1, 2) X(2, 3, 5, 2, 1) X(3, 3, 5, 1, 2) X(3, 6, 3, 2, 1) X(3, 3, 3, 1, 1)
+#define YL_IR_SHAPES(X) X(1, 2, 3, 2, 1) X(2, 2, 3, 1, 2) X(2, 3, 5, 2, 1) X(3, 3, 5, 1, 2) X(3, 6, 3, 2, 1) X(3, 3, 3, 1, 1) X(2, 6, 3, 1, 2) X(3, 6, 3, 1, 1)
 
 // fused inverted-residual block (p.C1 > 0).  hipErrorNotSupported: shape not instantiated (yl_uib_kernel or the
 // two-launch form handles it -- yl_ir_supported tells the host compiler beforehand)

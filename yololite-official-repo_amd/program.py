@@ -353,7 +353,8 @@ class _Builder:
 
     # shapes instantiated by yl_launch_conv_ir (csrc/yl_convc.hip: YL_IR_SHAPES): (input k-blocks, projection n-tile
     # bucket, dw k, dw stride, m-tiles per wave) -- the workgroup-level-halo kernel for EfficientNet-style blocks
-    _IR_SHAPES = ((1, 2, 3, 2, 1), (2, 2, 3, 1, 2), (2, 3, 5, 2, 1), (3, 3, 5, 1, 2), (3, 6, 3, 2, 1), (3, 3, 3, 1, 1))
+    _IR_SHAPES = ((1, 2, 3, 2, 1), (2, 2, 3, 1, 2), (2, 3, 5, 2, 1), (3, 3, 5, 1, 2), (3, 6, 3, 2, 1), (3, 3, 3, 1, 1), (2, 6, 3, 1, 2),
+                  (3, 6, 3, 1, 1))
 
     def ir_fusable(self, x, cmid, cout, dk, ds, oh, ow):
         """mirror of yl_ir_supported (csrc/yl_convc.hip)"""
@@ -386,6 +387,23 @@ class _Builder:
                   c2=c1, act2=_ACT[act], w2=w2, b2=b2, name=pre + ("ir" if keys[0] == "conv_pw" else "uib"),
                   macs=h * w * c1 * cmid + oh * ow * (cmid * dk * dk + cmid * cout),
                   bytes_in=4 * (h * w * c1 + (oh * ow * cout if res >= 0 else 0)), bytes_out=4 * oh * ow * cout)
+        self.p.layers.append(L)
+        return o
+
+    def lateral_smooth(self, x, lat, sm, F_, up):
+        """lateral{k} (1x1, bias, no BN / act, + nearest-upsampled `up`) -> smooth{k}.block.0 (dw3, no bias) ->
+        block.1 (1x1) + block.2 (BN) + ReLU as ONE fused launch (model_v2.py:23-39,359-361)."""
+        h, w, c1 = self.dims(x)
+        w2, b2 = self.fold(lat, None, 0.0, True, (F_, c1, 1, 1))
+        dww, _ = self.fold(sm + "0", None, 1e-5, False, (F_, 1, 3, 3))
+        wp, bp = self.fold(sm + "1", sm + "2", 1e-5, False, (F_, F_, 1, 1))
+        o = self.slot(h, w, F_)
+        L = Layer(_OP_CONV, x, o, F_, F_, 1, 1, 0, 0, _ACT["relu"], wp, bp, up_slot=up,
+                  dw_k=3, dw_stride=1, dw_pad_t=1, dw_pad_l=1, dw_act=_ACT["none"], dw_w=dww, dw_b=None,
+                  c2=c1, act2=_ACT["none"], w2=w2, b2=b2, name=lat + "+" + sm + "1",
+                  macs=h * w * (c1 * F_ + F_ * 9 + F_ * F_),
+                  bytes_in=4 * (h * w * c1 + (self.dims(up)[0] * self.dims(up)[1] * F_ if up >= 0 else 0)),
+                  bytes_out=4 * h * w * F_)
         self.p.layers.append(L)
         return o
 
@@ -617,8 +635,18 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     for n_ in reversed(pyr):
         k = n_[1]
         cslot = prog.feature_slots["c" + k]
-        lat = b.conv(cslot, f"lateral{k}", None, 0.0, "none", F_, bias=True, up=(P[prev] if prev else -1))
-        P[n_] = smooth(lat, f"smooth{k}")
+        ch, cw = b.dims(cslot)[0], b.dims(cslot)[1]
+        if cpu_arch and os.environ.get("YL_FUSE_LAT", "1") != "0" and b.ir_fusable(cslot, F_, F_, 3, 1, ch, cw):
+            # lateral 1x1 (+bias, + upsample-add of the smoothed coarser level) and the first depthwise smooth block as
+            # ONE launch (yl_ir_kernel: the lateral is the "expansion", its output -- which has no other consumer --
+            # lives only as 16-channel slabs of a workgroup's halo region in LDS)
+            x = b.lateral_smooth(cslot, f"lateral{k}", f"smooth{k}.block.", F_, P[prev] if prev else -1)
+            for i in range(1, d):
+                x = smooth_step(x, f"smooth{k}", i)
+            P[n_] = x
+        else:
+            lat = b.conv(cslot, f"lateral{k}", None, 0.0, "none", F_, bias=True, up=(P[prev] if prev else -1))
+            P[n_] = smooth(lat, f"smooth{k}")
         prev = n_
     if use_p6:                                             # model_v2.py:373-375
         x6 = b.conv(P["p5"], "p6_down", "p6_bn", 1e-5, "relu" if cpu_arch else "silu", F_, k=3, s=2)
