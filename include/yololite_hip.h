@@ -88,6 +88,9 @@ typedef struct {
    * channels, then the 1x1 projection (w,b,act,res_slot); the expanded tensor never reaches HBM.  With up_slot >= 0
    * (cin channels) the nearest-upsampled tensor is added to the EXPANSION's output before act2 -- the FPN pair
    * "lateral 1x1 (+bias) + upsample-add, then depthwise smooth block" (model_v2.py:359-361) as one launch.
+   * YL_OP_CONV with c3 > 0 (k > 1, no depthwise prologue, cout <= 96, c3 <= 32): a 1x1 conv w3/b3/act3 [c3][cout][1][1]
+   * chained behind this conv in the same launch; out_slot then has c3 channels and the cout-channel tensor never
+   * reaches HBM.
    * 0 / NULL otherwise. */
   int32_t c2, act2;           /* STEMBLOCK: 3x3 stride-2 pad-1 conv [c2][cout][3][3]              */
   int32_t c3, act3;           /* 1x1 conv: [c3][c2][1][1]; c3 = 0 -> absent                       */

@@ -866,17 +866,19 @@ def test_ir_fusion_is_bitwise_the_two_launch_form(S, B):
 @pytest.mark.parametrize("name,S,B", [("edge_n", 640, 2), ("edge_n", 320, 3)])
 def test_uib_and_lateral_fusion_through_the_ir_kernel_is_bitwise(name, S, B, monkeypatch):
     """Round 3: MobileNetV4 UIB blocks without a start depthwise and the FPN pairs lateral{k} (1x1 + bias + upsample-add)
-    -> smooth{k} (depthwise block) run through yl_ir_kernel where it is instantiated.  Same arithmetic order as the
+    -> smooth{k} (depthwise block) run through yl_ir_kernel where it is instantiated; blocks.1.1 (1x1) is chained in the
+    epilogue of blocks.1.0 (3x3 s2).  Same arithmetic order as the
     stand-alone launches: the raw levels are bit-identical to the program built with both fusions off."""
     meta = zoo_meta(name, 80, S)
     sd = synth_state_dict(meta, seed=8)
     x = _x(B, S, seed=41).to(DEV)
     mf = _hip_for(meta, sd)
-    monkeypatch.setenv("YL_FUSE_UIR", "0"); monkeypatch.setenv("YL_FUSE_LAT", "0")
+    monkeypatch.setenv("YL_FUSE_UIR", "0"); monkeypatch.setenv("YL_FUSE_LAT", "0"); monkeypatch.setenv("YL_FUSE_CHAIN", "0")
     mu = _hip_for(meta, sd)
     names_f = [l.name for l in mf.program.layers]
     assert any("+smooth" in n for n in names_f) and any(n.endswith(".uib") for n in names_f)
-    assert not any("+smooth" in l.name or l.name.endswith(".uib") for l in mu.program.layers)
+    assert any(l.c3 > 0 and l.op == 1 for l in mf.program.layers)           # blocks.1.0 with blocks.1.1 chained in its epilogue
+    assert not any("+smooth" in l.name or l.name.endswith(".uib") or (l.c3 > 0 and l.op == 1) for l in mu.program.layers)
     assert len(mu.program.layers) > len(mf.program.layers)
     for a, b in zip(mf(x), mu(x)):
         assert torch.equal(a, b)

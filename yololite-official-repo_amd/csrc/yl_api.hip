@@ -468,6 +468,9 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   if (d.op == YL_OP_CONV && d.c2 > 0) {      // fused expand -> depthwise -> project
     p.w2p = L.w2p; p.b2 = L.b2; p.C1 = d.c2; p.act2 = d.act2;
   }
+  if (d.op == YL_OP_CONV && d.c3 > 0) {      // dense k x k conv with a chained 1x1 conv (yl_conv_mfma_kernel epilogue)
+    p.w3p = L.w3p; p.b3 = L.b3; p.C3 = d.c3; p.act3 = d.act3;
+  }
   if (d.op == YL_OP_STEMBLOCK) {
     p.w2p = L.w2p; p.b2 = L.b2; p.w3p = L.w3p; p.b3 = L.b3;
     p.C1 = d.cout; p.C2 = d.c2; p.C3 = d.c3; p.act2 = d.act2; p.act3 = d.act3;
@@ -488,7 +491,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
     p.out = level_out[l] + (size_t)b0 * p.out_bstride + (size_t)L.head_anchor * ss * c->E;
   } else {
     p.out = slot_ptr(d.out_slot);
-    p.out_bstride = (long)L.out_h * L.out_w * d.cout;
+    p.out_bstride = (long)L.out_h * L.out_w * ((d.op == YL_OP_CONV && d.c3 > 0) ? d.c3 : d.cout);
   }
 }
 
@@ -1028,7 +1031,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     } else {
       if (l.out_slot < 0 || l.out_slot >= d->num_slots) return bad("bad out_slot");
       L.out_h = c->slots[l.out_slot].h; L.out_w = c->slots[l.out_slot].w;
-      const int oc = (l.op == YL_OP_STEMBLOCK) ? (l.c3 > 0 ? l.c3 : l.c2) : l.cout;
+      const int oc = (l.op == YL_OP_STEMBLOCK) ? (l.c3 > 0 ? l.c3 : l.c2) : ((l.op == YL_OP_CONV && l.c3 > 0) ? l.c3 : l.cout);
       if (c->slots[l.out_slot].c != oc) return bad("cout does not match the output slot");
     }
     if (l.op == YL_OP_STEMBLOCK) {
@@ -1085,11 +1088,21 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       pack_conv(l.w, l.cout, l.cin, l.k, wp);
       bias.assign((size_t)cdiv(l.cout, 16) * 16 + 128, 0.0f);
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
-      if (l.k == 3 && l.stride == 1 && l.dw_k == 0 && l.c2 == 0 && l.pad_t == 1 && l.pad_l == 1 && l.in_shift == 0 &&
+      if (l.k == 3 && l.stride == 1 && l.dw_k == 0 && l.c2 == 0 && l.c3 == 0 && l.pad_t == 1 && l.pad_l == 1 && l.in_shift == 0 &&
           l.cin >= 64 && l.cout >= 64 && (l.cout & 3) == 0 && l.head_level < 0 && l.res_slot < 0 && l.up_slot < 0) {
         std::vector<float> wn;
         pack_wino(l.w, l.cout, l.cin, wn);
         if ((s = upload(c, wn, &L.wino)) != YL_OK) return s;
+      }
+      if (l.c3 > 0) {       // chained 1x1 conv [c3][cout][1][1]: its k-blocks are this conv's 16-wide n-tiles
+        if (!l.w3 || l.k < 2 || l.dw_k > 0 || l.c2 > 0 || l.head_level >= 0 || l.res_slot >= 0 || l.up_slot >= 0 || l.in_shift ||
+            (l.cout & 3) || (l.c3 & 3) || l.c3 > 32 || l.cout > 96 || l.act == YL_ACT_SILU || l.act3 == YL_ACT_SILU)
+          return fail(c, YL_ERR_UNSUPPORTED, "chained 1x1 conv: needs a plain dense k x k conv (<= 96 channels out), c3 <= 32, ReLU-family activations");
+        std::vector<float> w3, b3v((size_t)cdiv(l.c3, 16) * 16, 0.0f);
+        pack_conv(l.w3, l.c3, l.cout, 1, w3);
+        if (l.b3) memcpy(b3v.data(), l.b3, l.c3 * sizeof(float));
+        if ((s = upload(c, w3, &L.w3p)) != YL_OK) return s;
+        if ((s = upload(c, b3v, &L.b3)) != YL_OK) return s;
       }
       if (l.c2 > 0) {       // expansion conv of a fused inverted-residual block: [cin][c2][1][1]
         std::vector<float> w2, b2v((size_t)cdiv(l.cin, 16) * 16, 0.0f);

@@ -380,6 +380,42 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 && MODE <= 1) ? YL_PW_WAVES : 3)
       }
     }
 
+    if (MODE == YL_CM_KXK && p.w3p) {
+      // Chained 1x1 conv (round 3: blocks.1.0 3x3 s2 16->48 -> blocks.1.1 1x1 48->32 of mobilenetv4_conv_small_050):
+      // the epilogue of this conv leaves act(acc + bias) as 4 consecutive channels of the lane's pixel -- exactly the
+      // B fragment of k-block `nt` of the next GEMM -- so the 48-channel tensor is never stored (79 MB written and
+      // re-read at B = 64, one launch).  <= 2 n-tiles out; k-blocks beyond this conv's n-tiles meet zero weights.
+      const f32x4* w3g = reinterpret_cast<const f32x4*>(p.w3p);      // [NTtot of this conv][NT3][64] float4
+      const int NT3 = (p.C3 + 15) >> 4;
+      const float lo3 = (p.act3 == YL_ACT_RELU || p.act3 == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+      const float hi3 = (p.act3 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+      f32x4 a3[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { a3[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; a3[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt < ntc) {
+          f32x4 v[MT], w3[2];
+          const f32x4 bq = yl_ld4(p.bias + (nt0 + nt) * 16 + 4 * kq);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) v[mt] = yl_clamp4(acc[mt][nt] + bq, lo, hi);
+          w3[0] = w3g[((size_t)nt * NT3 + 0) * 64 + lane];
+          w3[1] = w3g[((size_t)nt * NT3 + (NT3 > 1 ? 1 : 0)) * 64 + lane];
+          yl_mma_step<2, MT>(w3, v, a3);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (!px[mt].valid) continue;
+        float* orow = p.out + px[mt].lin * p.C3;
+#pragma unroll
+        for (int nt3 = 0; nt3 < 2; ++nt3) {
+          const int n = nt3 * 16 + 4 * kq;
+          if (nt3 < NT3 && n < p.C3) *reinterpret_cast<f32x4*>(orow + n) = yl_clamp4(a3[mt][nt3] + yl_ld4(p.b3 + n), lo3, hi3);
+        }
+      }
+      continue;
+    }
     if (p.dec_boxes) yl_epi_decode<NT, MT>(p, acc, px, nt0, kq, lane);
     if (p.dec_boxes && !p.dec_raw) continue;
     if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi, stg, ((size_t)tile * 4 + wave) * (MT * 16), lane);

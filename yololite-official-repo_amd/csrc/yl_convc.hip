@@ -1057,7 +1057,7 @@ static hipError_t kxk_go(const YlConvP& p0, int gy, hipStream_t st, bool attr_on
 // (yololite_m's 328-channel FPN) or exactly 4 (the 64-channel prototype branch of the seg head: two m-tiles per wave
 // so that a weight fragment read feeds 8 MFMAs).  hipErrorNotSupported otherwise (yl_conv_mfma_kernel runs the layer).
 hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
-  if (p.k != 3 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0) return hipErrorNotSupported;
+  if (p.k != 3 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.w3p) return hipErrorNotSupported;
   static const int NWsel = getenv("YL_KXK_NW") ? atoi(getenv("YL_KXK_NW")) : 0;
   static const int MTsel = getenv("YL_KXK_MT") ? atoi(getenv("YL_KXK_MT")) : 1;
   if (p.NTtot == 4) {

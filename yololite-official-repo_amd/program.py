@@ -408,7 +408,7 @@ class _Builder:
         return o
 
     def conv(self, x, conv, bn, eps, act, cout, k=1, s=1, same=False, bias=False, res=-1, up=-1, head_level=-1,
-             dw=None, out_hw=None, wb=None, name=None, in_shift=0):
+             dw=None, out_hw=None, wb=None, name=None, in_shift=0, chain=None):
         """dense conv; dw = dict(conv=..., bn=..., eps=..., act=..., k=..., s=..., bias=False) is a depthwise
         conv applied to x first (fused as a prologue when enabled, otherwise emitted as its own layer)."""
         h, wd, cin = self.dims(x)
@@ -445,10 +445,16 @@ class _Builder:
         if head_level >= 0:
             o = -1
         else:
-            o = self.slot(oh, ow, cout)
+            o = self.slot(oh, ow, chain["cout"] if chain else cout)
         L = Layer(_OP_CONV, x, o, cin, cout, k, s, pad, pad, _ACT[act], w, b, in_shift=in_shift, res_slot=res, up_slot=up,
                   head_level=head_level, name=name or conv, macs=oh * ow * cout * cin * k * k,
                   bytes_in=4 * h * wd * cin, bytes_out=4 * oh * ow * cout)
+        if chain:           # a 1x1 conv (+BN+act) chained in the same launch: chain = dict(conv, bn, eps, act, cout)
+            w3, b3 = self.fold(chain["conv"], chain["bn"], chain["eps"], False, (chain["cout"], cout, 1, 1))
+            L.c3, L.act3, L.w3, L.b3 = chain["cout"], _ACT[chain["act"]], w3, b3
+            L.name = (name or conv) + "+" + chain["conv"].split(".")[-2] + ".conv"
+            L.macs += oh * ow * cout * chain["cout"]
+            L.bytes_out = 4 * oh * ow * chain["cout"]
         if res >= 0 or up >= 0:
             L.bytes_in += 4 * oh * ow * cout if res >= 0 else 4 * self.dims(up)[0] * self.dims(up)[1] * cout
         if pro is not None:
@@ -488,7 +494,12 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
         if fused_entry and si == 0:
             continue
         bi = 0
-        for bstr in stage:
+        skip_next = False
+        for sidx, bstr in enumerate(stage):
+            if skip_next:                      # this entry went out as the chained 1x1 of the conv before it
+                skip_next = False
+                bi += 1
+                continue
             d = _parse(bstr)
             rep = d["r"]
             if spec["dmult"] != 1.0 and not (spec["fix_first_last"] and si in (0, ns - 1)):
@@ -499,7 +510,21 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
                 pre = f"{prefix}blocks.{si}.{bi}."
                 skip = (cin == cout and s == 1)
                 if d["type"] == "cn":
-                    x = b.conv(x, pre + "conv", pre + "bn1", eps, act, cout, d["k"], s, same)
+                    chain = None
+                    if (d["k"] > 1 and rep == 1 and sidx + 1 < len(stage) and b.fuse_dw is not False and act in ("relu", "relu6")
+                            and os.environ.get("YL_FUSE_CHAIN", "1") != "0"):
+                        d2 = _parse(stage[sidx + 1])
+                        c2o = _make_divisible(d2["c"] * spec["cmult"], 8)
+                        if (d2["type"] == "cn" and d2["k"] == 1 and d2["s"] == 1 and d2["r"] == 1 and cout <= 96 and cout % 4 == 0
+                                and c2o <= 32 and c2o % 4 == 0):
+                            # dense k x k conv followed by a 1x1 conv (blocks.1.0 / blocks.1.1 of mobilenetv4_conv_small):
+                            # the 1x1 is chained in the epilogue of the k x k launch (yl_conv_mfma_kernel)
+                            chain = dict(conv=f"{prefix}blocks.{si}.{bi + 1}.conv", bn=f"{prefix}blocks.{si}.{bi + 1}.bn1",
+                                         eps=eps, act=act, cout=c2o)
+                    x = b.conv(x, pre + "conv", pre + "bn1", eps, act, cout, d["k"], s, same, chain=chain)
+                    if chain:
+                        skip_next = True
+                        cout = chain["cout"]
                 elif d["type"] == "uir" and not d["a"] and d["k"] and not same and os.environ.get("YL_FUSE_UIR", "1") != "0" and \
                         b.ir_fusable(x, _make_divisible(cin * d["e"], 8), cout, d["k"], s,
                                      b.geom(b.dims(x)[0], d["k"], s, same)[0], b.geom(b.dims(x)[1], d["k"], s, same)[0]):
