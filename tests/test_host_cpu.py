@@ -66,18 +66,20 @@ def test_program_edge_n_macs_and_layout():
     assert p.level_size == [80, 40, 20] and p.level_anchors == [1, 1, 1] and p.strides == [8, 16, 32]
     assert [p.slots[p.feature_slots[k]] for k in ("c3", "c4", "c5")] == [(80, 80, 32), (40, 40, 48), (20, 20, 480)]
     # SURVEY App. A counts the head box/obj/cls convs as one row; a fused inverted-residual launch (yl_ir_kernel: c2 > 0)
-    # holds three convs (expand, depthwise, project)
-    nconv = sum(1 + (l.dw_k > 0) + (l.op == 1 and l.c2 > 0) for l in p.layers)
+    # holds three convs (expand, depthwise, project), a dense conv with a chained 1x1 (c3 > 0) two
+    nconv = sum(1 + (l.dw_k > 0) + (l.op == 1 and l.c2 > 0) + (l.op == 1 and l.c3 > 0) for l in p.layers)
     assert nconv == 63
     p2 = build_program(meta, synth_state_dict(meta), fuse_dw=False, fuse_stem=False, fuse_uib=False)
     assert len(p2.layers) > len(p.layers) and p2.macs == p.macs
-    p3 = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=True, fuse_uib=False)   # 3 entry convs -> 1 launch
-    assert len(p3.layers) == len(p.layers) - 2 and p3.macs == p.macs and p3.layers[0].op == 3
-    # the four 40x40 blocks are one launch each by default (yl_ir_kernel, round 3); fuse_uib adds the four 20x20 ones
+    p3 = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=True, fuse_uib=False)
+    # 3 entry convs -> 1 launch (without the fused entry: the stem + [blocks.0.0 with blocks.0.1 chained] = 2 launches)
+    assert len(p3.layers) == len(p.layers) - 1 and p3.macs == p.macs and p3.layers[0].op == 3
+    # by default (yl_ir_kernel, round 3) the four 40x40 blocks and the two lateral + smooth pairs at 80x80 / 40x40 are
+    # one launch each; fuse_uib adds the four 20x20 blocks through the per-wave kernel
     p0 = build_program(meta, synth_state_dict(meta), fuse_dw=True, fuse_stem=True, fuse_uib=False, fuse_ir=False)
-    assert len(p3.layers) == len(p0.layers) - 4 and p0.macs == p.macs
-    p4 = build_program(meta, synth_state_dict(meta), fuse_uib=True)     # 8 inverted-residual blocks as one launch each
-    assert len(p4.layers) == len(p0.layers) - 8 and p4.macs == p.macs
+    assert len(p3.layers) == len(p0.layers) - 6 and p0.macs == p.macs
+    p4 = build_program(meta, synth_state_dict(meta), fuse_uib=True)
+    assert len(p4.layers) == len(p0.layers) - 10 and p4.macs == p.macs
 
 
 @pytest.mark.parametrize("name,feat", [("edge_m", [(80, 80, 64), (40, 40, 96), (20, 20, 960)]),
