@@ -1281,8 +1281,9 @@ hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
 // and the two-launch form (conv_pw, then depthwise + conv_pwl) spends its time writing and re-reading it at 3-4 TB/s:
 // 2.7 of the model's 17.6 ms.  Here the expanded tensor exists only as one 16-channel SLAB of the workgroup's halo region
 // in LDS.
-//   workgroup tile  8 x 8*MT output pixels, four waves, wave w owns the 4 x 4*MT block (w >> 1, w & 1)
-//   per slab kb     E: the halo region ((8-1)*DS+DK rows x (8 MT-1)*DS+DK columns of expanded pixels, 16-pixel m-tiles
+//   workgroup tile  4*RBN x 4*MT*CBN output pixels, RBN x CBN waves (2 x 2, or 1 x 5 for 20 x 20 grids), wave w owns the
+//                   4 x 4*MT block (w / CBN, w % CBN)
+//   per slab kb     E: the halo region ((TH-1)*DS+DK rows x (TW-1)*DS+DK columns of expanded pixels, 16-pixel m-tiles
 //                      dealt to the waves) = act(bias + Wexp[kb] . x) by MFMA from the block input held in registers
 //                      for the whole tile, zero outside the image (the depthwise conv pads the EXPANDED tensor) -> LDS;
 //                   barrier (ONE per slab: slabs and projection weights are double-buffered, the counters run on
@@ -1294,11 +1295,12 @@ hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
 // WAVE: 2.25-4x the expansion MFMAs; the workgroup-level halo here costs 1.2x (stride 2) to 1.9x (5x5 stride 1).  Same
 // k orders (input channel blocks ascending; slabs = the projection's k blocks ascending; taps (dy,dx)) and epilogues as
 // the two-launch form: bit-identical results.
-template <int KBI /*ceil(C1/16)*/, int NT, int DK, int DS, int MT>
-__global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 3) ? 3 : 2) void yl_ir_kernel(YlConvP p) {
-  constexpr int TH = 8, TW = 8 * MT;
+template <int KBI /*ceil(C1/16)*/, int NT, int DK, int DS, int MT, int RBN /*wave rows*/, int CBN /*wave columns*/>
+__global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 3) ? 3 : 2) void yl_ir_kernel(YlConvP p) {
+  constexpr int NWV = RBN * CBN, NTH = NWV * 64;                   // waves / threads per workgroup
+  constexpr int TH = 4 * RBN, TW = 4 * MT * CBN;                   // workgroup tile: every wave a 4 x 4 MT block
   constexpr int HH = (TH - 1) * DS + DK, HW = (TW - 1) * DS + DK, HN = HH * HW;
-  constexpr int HMT = (HN + 15) / 16, HMW = (HMT + 3) / 4;         // halo m-tiles: all, per wave
+  constexpr int HMT = (HN + 15) / 16, HMW = (HMT + NWV - 1) / NWV; // halo m-tiles: all, per wave
   constexpr int PITCHF = ((HW * 16 + 7) / 64) * 64 + 56;           // slab row pitch in floats (see yl_conv_dwh_kernel)
   constexpr int SLAB = HH * PITCHF;
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
@@ -1316,10 +1318,10 @@ __global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 
   const float* const up = p.up;                                     // FPN lateral + smooth pair: addend of the expansion
   {
     const int nw = DK * DK * Cmid;
-    yl_glds_floats(p.dw_w, dwl, nw, tid, 256);
-    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cmid, tid, 256);
-    else for (int i = tid; i < Cmid; i += 256) dwl[nw + i] = 0.0f;
-    for (int i = tid; i < KB * 16; i += 256) b2l[i] = p.b2[i];
+    yl_glds_floats(p.dw_w, dwl, nw, tid, NTH);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cmid, tid, NTH);
+    else for (int i = tid; i < Cmid; i += NTH) dwl[nw + i] = 0.0f;
+    for (int i = tid; i < KB * 16; i += NTH) b2l[i] = p.b2[i];
   }
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
@@ -1333,14 +1335,14 @@ __global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 
   bool h_ok[HMW];
 #pragma unroll
   for (int j = 0; j < HMW; ++j) {
-    const int q = (wave + 4 * j) * 16 + pl;
+    const int q = (wave + NWV * j) * 16 + pl;
     h_ok[j] = q < HN;
     const int qq = h_ok[j] ? q : 0;
     h_r[j] = qq / HW;
     h_c[j] = qq - h_r[j] * HW;
     h_lo[j] = h_r[j] * PITCHF + h_c[j] * 16 + 4 * kq;
   }
-  const int rb = wave >> 1, cb = wave & 1;                         // the wave's 4 x 4 MT block of the tile
+  const int rb = wave / CBN, cb = wave - rb * CBN;                  // the wave's 4 x 4 MT block of the tile
   const int rbase = ((4 * rb + (pl >> 2)) * DS) * PITCHF + ((cb * 4 * MT + (pl & 3)) * DS) * 16 + 4 * kq;
   const bool pre_add = p.res != nullptr && p.act == YL_ACT_NONE;
   const int twn = OW / TW, thn = OH / TH;
@@ -1357,7 +1359,7 @@ __global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 
     tile = blockIdx.x; tend = ntiles; tstride = gridDim.x;
   }
   auto load_proj = [&](int kb, int buf) {                           // projection weights of slab kb -> LDS (asynchronous)
-    for (int nt = wave; nt < NT; nt += 4)
+    for (int nt = wave; nt < NT; nt += NWV)
       yl_glds16(wg + ((size_t)kb * NTtot + (nt < NTtot ? nt : NTtot - 1)) * 64 + lane, wpl + ((size_t)buf * NT + nt) * 64);
   };
   unsigned gs = 0;                                                  // slabs started by this workgroup (buffer = gs & 1)
@@ -1474,35 +1476,42 @@ __global__ __launch_bounds__(256, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 
   }
 }
 
-static size_t yl_ir_lds(int dk, int ds, int mt, int nt, int cmid) {
-  const int hh = 7 * ds + dk, hw = (8 * mt - 1) * ds + dk;
+static size_t yl_ir_lds(int dk, int ds, int mt, int rbn, int cbn, int nt, int cmid) {
+  const int hh = (4 * rbn - 1) * ds + dk, hw = (4 * mt * cbn - 1) * ds + dk;
   const int pitch = ((hw * 16 + 7) / 64) * 64 + 56;
   return ((size_t)2 * hh * pitch + (size_t)2 * nt * 256 + ((((size_t)(dk * dk + 1) * cmid) + 3) & ~(size_t)3) + (size_t)((cmid + 15) / 16) * 16) * 4;
 }
 
-template <int KBI, int NT, int DK, int DS, int MT>
+template <int KBI, int NT, int DK, int DS, int MT, int RBN, int CBN>
 static hipError_t ir_go(const YlConvP& p, hipStream_t st, bool attr_only) {
   if (attr_only)
-    return hipFuncSetAttribute((const void*)yl_ir_kernel<KBI, NT, DK, DS, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  const size_t lds = yl_ir_lds(DK, DS, MT, NT, p.Cin);
-  const long ntiles = (long)p.B * (p.OH / 8) * (p.OW / (8 * MT));
-  int gx = yl_resident_blocks_n(yl_ir_kernel<KBI, NT, DK, DS, MT>, 256, lds);
+    return hipFuncSetAttribute((const void*)yl_ir_kernel<KBI, NT, DK, DS, MT, RBN, CBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  const size_t lds = yl_ir_lds(DK, DS, MT, RBN, CBN, NT, p.Cin);
+  const long ntiles = (long)p.B * (p.OH / (4 * RBN)) * (p.OW / (4 * MT * CBN));
+  int gx = yl_resident_blocks_n(yl_ir_kernel<KBI, NT, DK, DS, MT, RBN, CBN>, RBN * CBN * 64, lds);
   if (gx > ntiles) gx = (int)ntiles;
   if (gx >= 8) gx &= ~7;
-  hipLaunchKernelGGL((yl_ir_kernel<KBI, NT, DK, DS, MT>), dim3(gx), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((yl_ir_kernel<KBI, NT, DK, DS, MT, RBN, CBN>), dim3(gx), dim3(RBN * CBN * 64), lds, st, p);
   return hipGetLastError();
 }
 
-// instantiated shapes: (input k-blocks, projection n-tiles, dw k, dw stride, m-tiles per wave)
-#define YL_IR_SHAPES(X) X(1, 2, 3, 2, 1) X(2, 2, 3, 1, 2) X(2, 3, 5, 2, 1) X(3, 3, 5, 1, 2) X(3, 6, 3, 2, 1) X(3, 3, 3, 1, 1) X(2, 6, 3, 1, 2) X(3, 6, 3, 1, 1)
+// instantiated shapes: (input k-blocks, projection n-tile bucket, dw k, dw stride, m-tiles per wave, wave rows, wave columns).
+// Buckets: 2 = 1-2 n-tiles, 3 = 3, 4 = 4, 6 = 5-6.  Workgroup tile = 4*rows x 4*MT*columns output pixels: 2 x 2 waves for
+// the grids that are multiples of 8 / 16.  (1 x 5 waves = 4 x 20 pixel tiles for the 20 x 20 stage of edge_n were built
+// and measured: 320 workgroup tiles per B = 64 launch, 0.083-0.114 ms per block against 0.055-0.067 ms for the
+// two-launch form -- not instantiated.)
+#define YL_IR_SHAPES(X)                                                                                              \
+  X(1, 2, 3, 2, 1, 2, 2) X(2, 2, 3, 1, 2, 2, 2) X(2, 3, 5, 2, 1, 2, 2) X(3, 3, 5, 1, 2, 2, 2) X(3, 6, 3, 2, 1, 2, 2)    \
+  X(3, 3, 3, 1, 1, 2, 2) X(2, 6, 3, 1, 2, 2, 2) X(3, 6, 3, 1, 1, 2, 2)
+#define YL_IR_BUCKET_LO(B) ((B) == 2 ? 0 : (B) == 3 ? 2 : (B) == 4 ? 3 : 4)
 
 // fused inverted-residual block (p.C1 > 0).  hipErrorNotSupported: shape not instantiated (yl_uib_kernel or the
 // two-launch form handles it -- yl_ir_supported tells the host compiler beforehand)
 bool yl_ir_supported(int c1, int cmid, int n, int dk, int ds, int oh, int ow) {
   const int kbi = (c1 + 15) / 16, nt = (n + 15) / 16;
-#define YL_IR_CHECK(A, B, C, D, E) \
-  if (kbi == A && nt <= B && nt > (B == 2 ? 0 : B == 3 ? 2 : 3) && dk == C && ds == D && (oh % 8) == 0 && (ow % (8 * E)) == 0 && \
-      yl_ir_lds(C, D, E, B, cmid) <= 150 * 1024) return true;
+#define YL_IR_CHECK(A, B, C, D, E, R, S)                                                                             \
+  if (kbi == A && nt <= B && nt > YL_IR_BUCKET_LO(B) && dk == C && ds == D && (oh % (4 * R)) == 0 &&                    \
+      (ow % (4 * E * S)) == 0 && yl_ir_lds(C, D, E, R, S, B, cmid) <= 150 * 1024) return true;
   YL_IR_SHAPES(YL_IR_CHECK)
 #undef YL_IR_CHECK
   return false;
@@ -1511,9 +1520,10 @@ bool yl_ir_supported(int c1, int cmid, int n, int dk, int ds, int oh, int ow) {
 hipError_t yl_launch_conv_ir(const YlConvP& p, hipStream_t st) {
   if (p.C1 <= 0 || p.k != 1 || p.dw_k == 0 || (p.N & 3)) return hipErrorNotSupported;
   const int kbi = (p.C1 + 15) / 16, nt = p.NTtot;
-#define YL_IR_RUN(A, B, C, D, E) \
-  if (kbi == A && nt <= B && nt > (B == 2 ? 0 : B == 3 ? 2 : 3) && p.dw_k == C && p.dw_stride == D && (p.OH % 8) == 0 && \
-      (p.OW % (8 * E)) == 0 && yl_ir_lds(C, D, E, B, p.Cin) <= 150 * 1024) return ir_go<A, B, C, D, E>(p, st, false);
+#define YL_IR_RUN(A, B, C, D, E, R, S)                                                                               \
+  if (kbi == A && nt <= B && nt > YL_IR_BUCKET_LO(B) && p.dw_k == C && p.dw_stride == D && (p.OH % (4 * R)) == 0 &&     \
+      (p.OW % (4 * E * S)) == 0 && yl_ir_lds(C, D, E, R, S, B, p.Cin) <= 150 * 1024)                                    \
+    return ir_go<A, B, C, D, E, R, S>(p, st, false);
   YL_IR_SHAPES(YL_IR_RUN)
 #undef YL_IR_RUN
   return hipErrorNotSupported;
@@ -1522,7 +1532,7 @@ hipError_t yl_launch_conv_ir(const YlConvP& p, hipStream_t st) {
 static hipError_t yl_ir_init() {
   YlConvP q = {};
   hipError_t e = hipSuccess;
-#define YL_IR_ATTR(A, B, C, D, E) if (e == hipSuccess) e = ir_go<A, B, C, D, E>(q, nullptr, true);
+#define YL_IR_ATTR(A, B, C, D, E, R, S) if (e == hipSuccess) e = ir_go<A, B, C, D, E, R, S>(q, nullptr, true);
   YL_IR_SHAPES(YL_IR_ATTR)
 #undef YL_IR_ATTR
   return e;

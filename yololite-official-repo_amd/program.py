@@ -353,8 +353,8 @@ class _Builder:
 
     # shapes instantiated by yl_launch_conv_ir (csrc/yl_convc.hip: YL_IR_SHAPES): (input k-blocks, projection n-tile
     # bucket, dw k, dw stride, m-tiles per wave) -- the workgroup-level-halo kernel for EfficientNet-style blocks
-    _IR_SHAPES = ((1, 2, 3, 2, 1), (2, 2, 3, 1, 2), (2, 3, 5, 2, 1), (3, 3, 5, 1, 2), (3, 6, 3, 2, 1), (3, 3, 3, 1, 1), (2, 6, 3, 1, 2),
-                  (3, 6, 3, 1, 1))
+    _IR_SHAPES = ((1, 2, 3, 2, 1, 2, 2), (2, 2, 3, 1, 2, 2, 2), (2, 3, 5, 2, 1, 2, 2), (3, 3, 5, 1, 2, 2, 2), (3, 6, 3, 2, 1, 2, 2),
+                  (3, 3, 3, 1, 1, 2, 2), (2, 6, 3, 1, 2, 2, 2), (3, 6, 3, 1, 1, 2, 2))
 
     def ir_fusable(self, x, cmid, cout, dk, ds, oh, ow):
         """mirror of yl_ir_supported (csrc/yl_convc.hip)"""
@@ -362,10 +362,10 @@ class _Builder:
             return False
         c1 = self.dims(x)[2]
         kbi, nt = -(-c1 // 16), -(-cout // 16)
-        for (a, bk, c, d, e) in self._IR_SHAPES:
-            lo = 0 if bk == 2 else (2 if bk == 3 else 3)
-            if kbi == a and lo < nt <= bk and dk == c and ds == d and oh % 8 == 0 and ow % (8 * e) == 0:
-                hh, hw = 7 * d + c, (8 * e - 1) * d + c
+        for (a, bk, c, d, e, r, cb) in self._IR_SHAPES:
+            lo = {2: 0, 3: 2, 4: 3}.get(bk, 4)
+            if kbi == a and lo < nt <= bk and dk == c and ds == d and oh % (4 * r) == 0 and ow % (4 * e * cb) == 0:
+                hh, hw = (4 * r - 1) * d + c, (4 * e * cb - 1) * d + c
                 pitch = ((hw * 16 + 7) // 64) * 64 + 56
                 lds = (2 * hh * pitch + 2 * bk * 256 + (((c * c + 1) * cmid + 3) & ~3) + -(-cmid // 16) * 16) * 4
                 return lds <= 150 * 1024
