@@ -1552,7 +1552,9 @@ static hipError_t yl_ir_init() {
 // and the depthwise part is recomputed per group; GW = all groups = no recomputation, 2 waves per SIMD.
 template <int NT, int GW, int NW>
 __global__ __launch_bounds__(NW * 64, GW == 1 ? 3 : 2) void yl_conv_dwk_kernel(YlConvP p) {
-  constexpr int S = GW == 1 ? 3 : 1;                         // k-steps per weight chunk
+  // k-steps per weight chunk (= per barrier): 3 when a wave holds one n-group; with all groups in one wave 2 where two
+  // buffers of 2 x GW x NT KiB still leave two workgroups per CU (edge_m's 244 channels: 0.359 -> 0.341 ms), else 1
+  constexpr int S = GW == 1 ? 3 : (GW * NT <= 16 ? 2 : 1);
   constexpr int PCS = S * GW * NT;                           // 1 KiB pieces per chunk
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1710,7 +1712,7 @@ static hipError_t dwk_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
     return hipFuncSetAttribute((const void*)yl_conv_dwk_kernel<NT, GW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   YlConvP p = p0;
   p.ntiles = (int)(((long)p.M + 16 * NW - 1) / (16 * NW));
-  const size_t lds = (size_t)2 * (GW == 1 ? 3 : 1) * GW * NT * 1024 + (((size_t)10 * p.Cin + 3) & ~(size_t)3) * 4;
+  const size_t lds = (size_t)2 * (GW == 1 ? 3 : (GW * NT <= 16 ? 2 : 1)) * GW * NT * 1024 + (((size_t)10 * p.Cin + 3) & ~(size_t)3) * 4;
   if (lds > 96 * 1024) return hipErrorNotSupported;
   const int res = yl_resident_blocks_n(yl_conv_dwk_kernel<NT, GW, NW>, NW * 64, lds);
   const int G = p.NTtot / (NT * GW);
