@@ -36,7 +36,6 @@
 #define SB_PC (2 * SB_TC + 1)
 #define SB_NPATCH (SB_PR * SB_PC)   // 85 stem pixels
 #define SB_NM SB_PR                 // stem m-tiles per tile: patch row m x columns 1..16 (column 0 rolls over, see below)
-struct __attribute__((packed, aligned(4))) SbF3 { float a, b, c; };   // 3 consecutive taps of one input row
 
 // Every WAVE owns its tiles end to end (private LDS patch, no workgroup barrier in the loop): waves
 // drift apart and cover each other's gather latency / MFMA dependency stalls.
@@ -50,16 +49,25 @@ struct __attribute__((packed, aligned(4))) SbF3 { float a, b, c; };   // 3 conse
 // K = 27 -> 28 pad slot of the stem GEMM (weight slot = bias, input slot = 1.0: added last in the fma chain, the same
 // rounding as the separate add), and all tile bookkeeping is scalar (wave id through readfirstlane), so the gathers are
 // `global_load saddr + per-lane constant offset` with no per-tile vector address arithmetic.
-template <int NT1 /*C1/16*/, int NT2 /*ceil(C2/16)*/, int NT3 /*ceil(C3/16), 0 = no 1x1*/>
-__global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
+#define SB_SROWS (2 * (SB_PR - 1) + 3)     // input rows under a patch (stem stride 2, 3x3): 11
+#define SB_SCOLS (2 * (SB_PC - 1) + 3)     // input columns: 35
+#define SB_NSEG (3 * SB_SROWS)             // (channel, row) segments: 33
+#define SB_SP 36                           // column pitch of the staged block: 9 chunks of 4 floats per segment
+#define SB_NCH (SB_NSEG * SB_SP / 4)       // 16-byte chunks: 297
+#define SB_NSTG ((SB_NCH + 63) / 64)       // LDS-DMA instructions (64 lanes x 16 bytes) per tile: 5
+#define SB_NSTG1 ((SB_NSEG * SB_SP + 63) / 64)   // dword-granular rows (image-border tiles): 19
+template <int NT1 /*C1/16*/, int NT2 /*ceil(C2/16)*/, int NT3 /*ceil(C3/16), 0 = no 1x1*/, int NWV /*waves per workgroup*/>
+__global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
   constexpr int C1 = NT1 * 16, P1 = C1 + 4, KS = 7, KB1 = NT1;
-  constexpr int PATCH_F = 96 * P1;                                   // floats per wave patch (85 rows used)
+  constexpr int PATCH_F = SB_NPATCH * P1;                            // floats per wave patch
+  constexpr int WAVE_F = PATCH_F + SB_NSTG * 256;                     // + the staged input of the tile's new pixels
   extern __shared__ __attribute__((aligned(16))) float sb_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
-  float* patch = sb_lds + wave * PATCH_F;                            // [5][17][P1], wave private
-  f32x4* w2l = reinterpret_cast<f32x4*>(sb_lds + 4 * PATCH_F);
+  float* patch = sb_lds + wave * WAVE_F;                             // [5][17][P1], wave private
+  float* stage = patch + PATCH_F;                                    // [33 segments][36 columns] (+ tail of the 5th KB)
+  f32x4* w2l = reinterpret_cast<f32x4*>(sb_lds + NWV * WAVE_F);
   f32x4* w3l = w2l + 9 * KB1 * NT2 * 64;
 
   // ---- once per block: stem A fragments -> registers, conv2 / conv3 weights -> LDS
@@ -84,10 +92,10 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #endif
   {
     const f32x4* g2 = reinterpret_cast<const f32x4*>(p.w2p);
-    for (int r = wave; r < 9 * KB1 * NT2; r += 4) yl_glds16(g2 + r * 64 + lane, w2l + r * 64);   // async, see yl_dev.h
+    for (int r = wave; r < 9 * KB1 * NT2; r += NWV) yl_glds16(g2 + r * 64 + lane, w2l + r * 64);   // async, see yl_dev.h
     if (NT3 > 0) {
       const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
-      for (int r = wave; r < NT2 * NT3; r += 4) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
+      for (int r = wave; r < NT2 * NT3; r += NWV) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
     }
   }
   __syncthreads();
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   // taps are 9 rows (c,ky) of 3 consecutive kx.  Lane group kq owns rows 2kq and 2kq+1 whole (slots 0-2, 3-5) and one
   // element of row 8 (slot 6, kx = kq; group 3: the bias slot), so a lane's 7 operands per patch pixel are two 12-byte
   // loads and one 4-byte load instead of seven scattered dwords.
-  int tky[KS], tkx[KS], tc[KS], gs[KS];
+  int tky[KS], tkx[KS], tc[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     int row, kx;
@@ -108,15 +116,31 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     tc[s] = row / 3;
     tky[s] = row - 3 * tc[s];
     tkx[s] = kx;
-    gs[s] = tc[s] * plane + tky[s] * p.W + tkx[s];
   }
-  // gather offsets (floats) relative to the uniform base of (tile, patch row): regular m-tile m = patch row m, lane pl =
-  // patch column 1 + pl; first-tile m-tile = patch column 0, lane pl = patch row min(pl, 4)
-  const int pcol = (1 + pl) * p.stride;
-  const unsigned vr0 = (unsigned)(gs[0] + pcol), vr1 = (unsigned)(gs[3] + pcol), vr2 = (unsigned)(gs[6] + pcol);
+  // Round 3 (second half): the input of a tile's new stem pixels is STAGED in the wave's LDS region by asynchronous
+  // global -> LDS copies -- five 16-byte-per-lane loads cover the [33 (channel,row) segments][36 columns] block (lane =
+  // one 4-float chunk of one segment; no VGPRs, no ds_write) -- instead of ten 12-byte + seven 4-byte scattered gathers
+  // into registers: the ablations put 19 % of the kernel on the vector-memory path of those gathers.  Phase 1 reads its
+  // B operands from the stage (7 ds_read_b32 per m-tile).  Column 35 of a segment is not used; interior tiles may read
+  // it one float past a row's end (never past the tensor: see `interior` in gather()).
+  int goff[SB_NSTG];                                                 // global offset (floats) of chunk k*64 + lane
+#pragma unroll
+  for (int k = 0; k < SB_NSTG; ++k) {
+    int e = k * 64 + lane;
+    e = e < SB_NCH ? e : SB_NCH - 1;
+    const int seg = e / (SB_SP / 4), ch = e - seg * (SB_SP / 4);
+    const int c = seg / SB_SROWS, r = seg - c * SB_SROWS;
+    goff[k] = c * plane + r * p.W + 4 * ch;
+  }
   const int prow = (pl < SB_PR ? pl : SB_PR - 1);
-  const unsigned vf0 = (unsigned)(gs[0] + prow * p.stride * p.W), vf1 = (unsigned)(gs[3] + prow * p.stride * p.W),
-                 vf2 = (unsigned)(gs[6] + prow * p.stride * p.W);
+  // stage index of the lane's k slot s: regular m-tile m (patch row m, column 1 + pl) = rs[s] + 72 m; first-tile m-tile
+  // (patch column 0, row prow) = rf[s]
+  int rs[KS], rf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    rs[s] = (tc[s] * SB_SROWS + tky[s]) * SB_SP + tkx[s] + 2 * (1 + pl);
+    rf[s] = (tc[s] * SB_SROWS + 2 * prow + tky[s]) * SB_SP + tkx[s];
+  }
 #if YL_BF16
   const bool slot6_lane = true;                                      // bf16 build: separate bias add, zero weight in the slot
 #else
@@ -147,11 +171,11 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
   // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order; placement changes speed only), and XCD x
   // owns the contiguous strip range [x*nstrips/8, (x+1)*nstrips/8) -- whole images for B % 8 == 0 -- so the input rows
   // shared by vertically neighbouring patches are re-read from this XCD's L2 instead of from HBM a second time.
-  int strip = blockIdx.x * 4 + wave, sstride = gridDim.x * 4, send = nstrips;
+  int strip = blockIdx.x * NWV + wave, sstride = gridDim.x * NWV, send = nstrips;
   if ((gridDim.x & 7) == 0) {
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, nj = gridDim.x >> 3;
     const int r0 = (int)(((long)nstrips * x) >> 3), r1 = (int)(((long)nstrips * (x + 1)) >> 3);
-    strip = r0 + j * 4 + wave; sstride = nj * 4; send = r1;
+    strip = r0 + j * NWV + wave; sstride = nj * NWV; send = r1;
   }
   // the tile whose inputs are being gathered (one ahead of the tile being computed); everything here is wave-uniform
   int g_b = 0, g_ty = 0, g_tx = 0, g_txend = 0, g_first = 0, g_valid = 0, g_strip = strip;
@@ -170,66 +194,31 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     else { g_strip += sstride; decode_strip(); }
   };
 
-  // gather of the input scalars this lane feeds to the stem MFMAs of the tile (g_b, g_ty, g_tx): 7 k-slots x 5 m-tiles
-  // (+ 1 for the first tile of a strip).  Issued for tile t+1 right after tile t's stem phase has consumed the
-  // registers, so the global-load latency hides behind tile t's 3x3 / 1x1 MFMAs.
-  float xv[SB_NM][KS], xf[KS];
-  const float* g_xo = p.x;                            // interior gather in flight: uniform base of its patch
+  // staging of the input block under the patch of tile (g_b, g_ty, g_tx): issued for tile t+1 during tile t's 3x3 phase
+  // (one or two LDS-DMA rows per MFMA step), consumed by tile t+1's stem phase after an s_waitcnt vmcnt(0).
+  const float* g_xo = p.x;                            // interior staging in flight: uniform base of its input block
   bool g_int = false;
-  auto gather_piece = [&](int i) {                    // i = 2 m + (0: input rows 2kq, 1: rows 2kq+1) of m-tile m
-    const int m = i >> 1;
-    const float* q = g_xo + m * p.stride * p.W;
-    const SbF3 r = *reinterpret_cast<const SbF3*>(q + ((i & 1) ? vr1 : vr0));
-    xv[m][3 * (i & 1)] = r.a; xv[m][3 * (i & 1) + 1] = r.b; xv[m][3 * (i & 1) + 2] = r.c;
-  };
+  auto gather_piece = [&](int k) { yl_glds16(g_xo + goff[k], stage + k * 256); };
   auto gather = [&]() {
-    if (SB_EXP == 5) {                                // timing experiment: no loads
-#pragma unroll
-      for (int m = 0; m < SB_NM; ++m)
-#pragma unroll
-        for (int s = 0; s < 6; ++s) xv[m][s] = (float)(g_tx + m + s);
-      return;
-    }
     const int sy0 = 2 * g_ty * SB_TR - 1, sx0 = 2 * g_tx * SB_TC - 1;
     const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;
     const float* xb = p.x + (size_t)g_b * 3 * plane;
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW && iy0 >= 0 && ix0 >= 0 &&
-                          iy0 + (SB_PR - 1) * p.stride + 3 <= p.H && ix0 + (SB_PC - 1) * p.stride + 3 <= p.W;
+                          iy0 + SB_SROWS <= p.H && ix0 + SB_SCOLS <= p.W &&
+                          (ix0 + SB_SP <= p.W || iy0 + SB_SROWS < p.H || g_b + 1 < p.B);   // column 35: inside the tensor
     g_int = interior;
-    if (interior) {                                   // the common case: no bounds logic (wave-uniform branch)
-      const float* xo = xb + (long)iy0 * p.W + ix0;   // uniform: scalar base, per-lane constant offsets
-      g_xo = xo;
-      // The ten 12-byte gathers of the regular m-tiles are NOT issued here: they go out one per MFMA step inside phase
-      // 2 (gather_piece), so that the wave never sits in front of its own 3x3 MFMAs with a full address queue.
-      // (Measured, B = 64: kernel without any gather 0.261 ms, with 0.323 ms; an L2 prefetch of the lines one or two
-      // tiles ahead made it SLOWER (0.334 / 0.338 ms) -- the cost is the vector-memory path itself (17 instructions of
-      // scattered 12-/4-byte lanes per tile), not the miss latency.)
-      if (g_first) {
-        const SbF3 r0 = *reinterpret_cast<const SbF3*>(xo + vf0);
-        const SbF3 r1 = *reinterpret_cast<const SbF3*>(xo + vf1);
-        xf[0] = r0.a; xf[1] = r0.b; xf[2] = r0.c; xf[3] = r1.a; xf[4] = r1.b; xf[5] = r1.c;
-      }
-      // slot 6 (4 bytes per lane, cheap): now.  The bias lanes read some valid address; their value is replaced by 1.0
-      // where it is CONSUMED (stem_mtile) -- a select here would wait for the load on the spot
+    if (interior) {                                   // the common case: uniform base + per-lane constant offsets; the
+      g_xo = xb + (long)iy0 * p.W + ix0;              // loads themselves go out inside phase 2 (gather_piece)
+    } else {                                          // image border: per-lane bounds, out-of-image elements read zeros
 #pragma unroll
-      for (int m = 0; m < SB_NM; ++m) xv[m][6] = (xo + m * p.stride * p.W)[vr2];
-      if (g_first) xf[6] = xo[vf2];
-    } else {
-#pragma unroll
-      for (int m = 0; m < SB_NM; ++m)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int iy = iy0 + m * p.stride + tky[s], ix = ix0 + (1 + pl) * p.stride + tkx[s];
-          const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-          xv[m][s] = *(in ? xb + tc[s] * plane + (long)iy * p.W + ix : p.zeros);
-        }
-      if (g_first) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int iy = iy0 + prow * p.stride + tky[s], ix = ix0 + tkx[s];
-          const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-          xf[s] = *(in ? xb + tc[s] * plane + (long)iy * p.W + ix : p.zeros);
-        }
+      for (int k = 0; k < SB_NSTG1; ++k) {
+        int e = k * 64 + lane;
+        e = e < SB_NSEG * SB_SP ? e : SB_NSEG * SB_SP - 1;
+        const int seg = e / SB_SP, col = e - seg * SB_SP;
+        const int c = seg / SB_SROWS, r = seg - c * SB_SROWS;
+        const int iy = iy0 + r, ix = ix0 + col;
+        const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        yl_glds4(in ? xb + c * plane + (long)iy * p.W + ix : p.zeros, stage + k * 64);
       }
     }
   };
@@ -241,12 +230,26 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     gather();
     if (g_int) {
 #pragma unroll
-      for (int i = 0; i < 2 * SB_NM; ++i) gather_piece(i);
+      for (int k = 0; k < SB_NSTG; ++k) gather_piece(k);
     }
   }
+  // the output stores of tile t are issued at the start of tile t+1's 3x3 phase, IN FRONT of that phase's staging loads:
+  // vmcnt counts loads and stores in one in-order counter, and the vmcnt(0) in front of a stem phase must not sit
+  // behind stores issued a moment earlier
+  constexpr int NTO = NT3 > 0 ? NT3 : NT2;
+  f32x4 ov[NTO];
+  float* o_row = p.out;
+  bool o_valid = false;
+  auto flush_out = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < NTO; ++nt) {
+      const int n = nt * 16 + 4 * kq;
+      if (o_valid && n < Nout) *reinterpret_cast<f32x4*>(o_row + n) = ov[nt];
+    }
+  };
 
   while (g_valid) {
-    const int b = g_b, tyi = g_ty, txi = g_tx, first = g_first;       // the tile computed now (its inputs are in xv / xf)
+    const int b = g_b, tyi = g_ty, txi = g_tx, first = g_first;       // the tile computed now (its inputs are staged)
     const int oy0 = tyi * SB_TR, ox0 = txi * SB_TC;                  // tile origin on the conv2 output grid
     const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;                  // patch origin on the stem grid
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW;
@@ -263,8 +266,11 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
     // ---- phase 1: stem on the new patch pixels -> wave-private LDS.  Two copies of the code, selected by a wave-uniform
     // branch: interior tiles (all but the image border) carry no padding logic at all -- left as a runtime flag
     // the compiler predicates it per lane (compares, exec masking and 8 v_cndmask per m-tile on every tile)
-    auto stem_mtile = [&](auto interior_tag, const float (&xs)[KS], int sy, int sx, float* dst, bool live) {
+    auto stem_mtile = [&](auto interior_tag, const int (&ri)[KS], int roff, int sy, int sx, float* dst, bool live) {
       constexpr bool INTERIOR = decltype(interior_tag)::value;
+      float xs[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xs[s] = stage[ri[s] + roff];
       f32x4 a1[NT1];
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) a1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -302,10 +308,12 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
       }
     };
     auto phase1 = [&](auto interior_tag) {
-      if (first) stem_mtile(interior_tag, xf, sy0 + prow, sx0, patch + lqf, pl < SB_PR);
+      if (first) stem_mtile(interior_tag, rf, 0, sy0 + prow, sx0, patch + lqf, pl < SB_PR);
 #pragma unroll
-      for (int m = 0; m < SB_NM; ++m) stem_mtile(interior_tag, xv[m], sy0 + m, sx0 + 1 + pl, patch + m * SB_PC * P1 + lqr, true);
+      for (int m = 0; m < SB_NM; ++m)
+        stem_mtile(interior_tag, rs, m * 2 * SB_SP, sy0 + m, sx0 + 1 + pl, patch + m * SB_PC * P1 + lqr, true);
     };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the staged input has landed (LDS-DMA completion)
     if (interior) phase1(std::true_type{});
     else phase1(std::false_type{});
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // LDS writes of other lanes -> reads below
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) { a2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; a2b[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     constexpr int NSTEP = 9 * KB1;
-    constexpr int PPS = (2 * SB_NM + NSTEP - 1) / NSTEP;             // gather pieces per MFMA step
+    constexpr int PPS = (SB_NSTG + NSTEP - 1) / NSTEP;               // staging rows per MFMA step
     f32x4 xq[2], wq[2][NT2];
     auto lds_step = [&](int i, int buf) {              // i = tap * KB1 + kb  (all compile-time after unrolling)
       const int tap = i / KB1, kb = i - tap * KB1;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
         if (GATHER) {
 #pragma unroll
           for (int k = 0; k < PPS; ++k)
-            if (i * PPS + k < 2 * SB_NM) { gather_piece(i * PPS + k); ++npiece; }
+            if (i * PPS + k < SB_NSTG) { gather_piece(i * PPS + k); ++npiece; }
         }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
@@ -363,19 +371,20 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #endif
       }
     };
-    if (g_valid && g_int && SB_EXP != 5) phase2(std::true_type{});
+    flush_out();                                                     // the previous tile's outputs
+    if (g_valid && g_int) phase2(std::true_type{});
     else phase2(std::false_type{});
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) a2[nt] = clamp4((a2[nt] + a2b[nt]) + bias2[nt], lo2, hi2);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // patch reads done before the next tile's writes
     __builtin_amdgcn_wave_barrier();
 
-    // ---- phase 3: optional 1x1 conv chained in registers, then store
+    // ---- phase 3: optional 1x1 conv chained in registers; the store is deferred (flush_out)
     const int oy = oy0 + ty, ox = ox0 + tx;
-    const bool valid = oy < p.OH && ox < p.OW;
-    float* orow = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * Nout;
-    if (NT3 > 0) {
-      f32x4 a3[NT3 > 0 ? NT3 : 1];
+    o_valid = oy < p.OH && ox < p.OW;
+    o_row = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * Nout;
+    if constexpr (NT3 > 0) {
+      f32x4 a3[NT3];
 #pragma unroll
       for (int nt = 0; nt < NT3; ++nt) a3[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -392,41 +401,45 @@ __global__ __launch_bounds__(256) void yl_stemblock_kernel(YlConvP p) {
 #endif
         }
 #pragma unroll
-      for (int nt = 0; nt < NT3; ++nt) {
-        const int n = nt * 16 + 4 * kq;
-        const f32x4 v = clamp4(a3[nt] + bias3[nt], lo3, hi3);
-        if (valid && n < Nout && (SB_EXP != 4 || v[0] == 1234.5f)) *reinterpret_cast<f32x4*>(orow + n) = v;
-      }
+      for (int nt = 0; nt < NT3; ++nt) ov[nt] = clamp4(a3[nt] + bias3[nt], lo3, hi3);
     } else {
 #pragma unroll
-      for (int nt = 0; nt < NT2; ++nt) {
-        const int n = nt * 16 + 4 * kq;
-        if (valid && n < Nout) *reinterpret_cast<f32x4*>(orow + n) = a2[nt];
-      }
+      for (int nt = 0; nt < NT2; ++nt) ov[nt] = a2[nt];
     }
   }
+  flush_out();
 }
 
-template <int NT1, int NT2, int NT3>
-static hipError_t sb_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
-  constexpr int P1 = NT1 * 16 + 4;
-  const size_t lds = (size_t)(4 * 96 * P1) * 4 + (size_t)(9 * NT1 * NT2 + NT2 * NT3) * 1024;
+template <int NT1, int NT2, int NT3, int NWV>
+static hipError_t sb_launch(const YlConvP& p0, hipStream_t st, bool attr_only, size_t lds) {
   if (attr_only)
-    return hipFuncSetAttribute((const void*)yl_stemblock_kernel<NT1, NT2, NT3>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return hipFuncSetAttribute((const void*)yl_stemblock_kernel<NT1, NT2, NT3, NWV>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   YlConvP p = p0;
+  if (p.stride != 2 || p.k != 3) return hipErrorInvalidValue;   // the staged input block is 11 x 35 per channel
   // strips of ~10 tiles: long enough that the one extra m-tile of a strip's first tile is noise (1.4 of 147 MFMAs per
-  // tile), short enough that every wave of the 2-workgroups-per-CU grid gets several (640 x 640, B = 64: 5 each)
+  // tile), short enough that every wave of the 8-waves-per-CU grid gets several (640 x 640, B = 64: 5 each)
   const int tpr = (p.OW + SB_TC - 1) / SB_TC, tpc = (p.OH + SB_TR - 1) / SB_TR;
   int nsp = (tpr + 5) / 10;
   if (nsp < 1) nsp = 1;
   p.sb_strip = (tpr + nsp - 1) / nsp;
   const long nstrips = (long)p.B * tpc * ((tpr + p.sb_strip - 1) / p.sb_strip);
-  int gx = 2 * YL_NUM_CU;
-  if (gx > (nstrips + 3) / 4) gx = (int)((nstrips + 3) / 4);
+  int gx = (8 / NWV) * YL_NUM_CU;
+  if (gx > (nstrips + NWV - 1) / NWV) gx = (int)((nstrips + NWV - 1) / NWV);
   if (gx >= 8) gx &= ~7;                                  // multiple of 8: XCD-aware strip ranges (see the kernel)
-  hipLaunchKernelGGL((yl_stemblock_kernel<NT1, NT2, NT3>), dim3(gx), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((yl_stemblock_kernel<NT1, NT2, NT3, NWV>), dim3(gx), dim3(NWV * 64), lds, st, p);
   return hipGetLastError();
+}
+
+// One 8-wave workgroup per CU shares ONE copy of the conv2 / conv3 weights where that fits the 160 KB of LDS next to
+// the eight wave-private patches and stages; otherwise 4 waves.
+template <int NT1, int NT2, int NT3>
+static hipError_t sb_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
+  constexpr int P1 = NT1 * 16 + 4;
+  constexpr size_t wave_b = (size_t)(SB_NPATCH * P1 + SB_NSTG * 256) * 4;
+  constexpr size_t w_b = (size_t)(9 * NT1 * NT2 + NT2 * NT3) * 1024;
+  if constexpr (8 * wave_b + w_b <= 160 * 1024) return sb_launch<NT1, NT2, NT3, 8>(p0, st, attr_only, 8 * wave_b + w_b);
+  else return sb_launch<NT1, NT2, NT3, 4>(p0, st, attr_only, 4 * wave_b + w_b);
 }
 
 template <int NT1>
