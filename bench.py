@@ -548,6 +548,8 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     }
     out.update(extra)
     if args.layers:
+        print(f"# layer table: {model_name}{'+seg' if seg else ''} B={B} {S}x{S}, eager launches, median of "
+              f"the timed forwards; {len(prog.layers)} launches, sum {fwd_ms:.4f} ms", file=sys.stderr)
         for i, (l, ms) in enumerate(zip(prog.layers, lay)):
             print(f"{i:3d} {l.name:42s} cin{l.cin:4d} cout{l.cout:4d} k{l.k} dw{l.dw_k} {ms:8.4f} ms "
                   f"{2.0 * l.macs * B / (ms * 1e-3) / 1e12:7.2f} TF {(l.bytes_in + l.bytes_out) * B / (ms * 1e-3) / 1e9:8.1f} GB/s",

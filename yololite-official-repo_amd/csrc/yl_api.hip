@@ -49,7 +49,7 @@ struct yl_ctx {
   int level_S[YL_MAX_LEVELS] = {0}, level_A[YL_MAX_LEVELS] = {0}, level_off[YL_MAX_LEVELS + 1] = {0};
   std::vector<Slot> slots;
   std::vector<DevLayer> layers;
-  float* zeros = nullptr;                  // 256 zero bytes (padding source for the conv kernels)
+  float* zeros = nullptr;                  // 1 KiB of zeros (padding source for the conv kernels)
   int cap_batch = 0;                       // images the pinned slots / level buffers are allocated for (capacity)
   int act_batch = 0;                       // batch of the last forward: what yl_masks* / yl_read_slot may address
   // Activation memory: ONE arena per batch chunk (chunks run concurrently on their own streams), slots placed by
@@ -96,6 +96,7 @@ struct yl_ctx {
   int opt_winograd = 0;      // dense 3x3 stride-1 layers with >= 64 channels through Winograd F(2x2,3x3) (2.25x fewer MACs;
                              // NOT bit-identical to the direct convolution: fp32 rounding of the transforms)
   int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
+  int opt_fuse_head = 1;     // ... and the head trunk (depthwise 3x3 -> 1x1) in the same launch (yl_conv_dpp_kernel)
   int opt_bf16 = 0;   // 1: conv / stem-block launches use the bf16-MFMA builds (fp32 storage, fp32 accumulate)
   // batch chunks run on `opt_streams` internal streams (fork/join around every call): the
   // latency-bound low-resolution layers of one chunk overlap the bandwidth-bound layers of another
@@ -510,6 +511,33 @@ bool can_fuse_decode(const yl_ctx* c) {
   return any;
 }
 
+// Head branches as ONE launch (yl_conv_dpp_kernel): the level-batched run [i, gend) of head trunks (depthwise 3x3 -> 1x1)
+// is followed by the run of their head-output convs in the same order, nothing else reads the trunk tensors, decode is
+// fused (yl_predict, no mask coefficients) and the shape is instantiated
+bool head_run_fusable(const yl_ctx* c, size_t i, size_t gend, size_t lend) {
+  const size_t n = gend - i;
+  if (!c->opt_fuse_head || c->opt_bf16 || c->NM > 0 || gend + n > lend) return false;
+  for (size_t q = 0; q < n; ++q) {
+    const DevLayer& T = c->layers[i + q];
+    const DevLayer& O = c->layers[gend + q];
+    const yl_layer& t = T.d; const yl_layer& o = O.d;
+    if (t.op != YL_OP_CONV || t.k != 1 || t.dw_k != 3 || t.dw_stride != 1 || t.c2 > 0 || t.c3 > 0 || t.head_level >= 0 ||
+        t.res_slot >= 0 || t.up_slot >= 0 || t.in_shift || t.act == YL_ACT_SILU || t.dw_act == YL_ACT_SILU || t.out_slot < 0)
+      return false;
+    if (o.op != YL_OP_CONV || o.head_level < 0 || o.k != 1 || o.dw_k > 0 || o.c2 > 0 || o.c3 > 0 || o.in_slot != t.out_slot ||
+        o.cin != t.cout || o.act != YL_ACT_NONE || o.res_slot >= 0 || o.up_slot >= 0 || o.in_shift)
+      return false;
+    if (T.in_h != T.out_h || T.in_w != T.out_w || !yl_dpp_supported(t.cin, t.cout, o.cout, T.out_h, T.out_w)) return false;
+    for (size_t r = 0; r < c->layers.size(); ++r) {
+      if (r == gend + q) continue;
+      const yl_layer& e = c->layers[r].d;
+      const bool reads_in = e.op != YL_OP_STEM && e.op != YL_OP_STEMBLOCK && e.in_slot == t.out_slot;
+      if (reads_in || e.res_slot == t.out_slot || e.up_slot == t.out_slot) return false;
+    }
+  }
+  return true;
+}
+
 yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* level_out, hipStream_t st,
                      hipEvent_t* evs /*nullable: num_layers+1 events*/, int chunk = 0,
                      const yl_post_cfg* fuse = nullptr /*non-null: head outputs decode in their epilogue*/,
@@ -548,6 +576,27 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
     // ---- level-batched run starting at i (not under per-layer timing, not with side lanes)
     size_t gend = i + 1;
     if (!evs && !lanes && c->opt_batch_levels && d.op == YL_OP_CONV) gend = layer_group_end(c, i, lend);
+    if (fuse && !evs && !lanes && d.op == YL_OP_CONV && d.dw_k == 3 && head_run_fusable(c, i, gend, lend)) {
+      YlConvP ps[4];
+      const size_t n = gend - i;
+      for (size_t q = 0; q < n; ++q) {
+        YlConvP o;
+        params(i + q, ps[q]);
+        params(gend + q, o);                               // the head-output conv: weights, bias, decode targets
+        ps[q].w3p = o.wp; ps[q].b3 = o.bias; ps[q].C3 = o.N;
+        ps[q].dec_boxes = o.dec_boxes; ps[q].dec_scores = o.dec_scores; ps[q].dec_cls = o.dec_cls;
+        ps[q].dec_N = o.dec_N; ps[q].dec_off = o.dec_off; ps[q].dec_C = o.dec_C; ps[q].dec_mode = o.dec_mode;
+        ps[q].dec_center = o.dec_center; ps[q].dec_wh = o.dec_wh; ps[q].dec_raw = o.dec_raw;
+        ps[q].dec_stride = o.dec_stride; ps[q].dec_hi = o.dec_hi;
+      }
+      const hipError_t e = yl_launch_conv_dpp(ps, (int)n, st);
+      if (e == hipSuccess) { i = gend + n; continue; }
+      if (e != hipErrorNotSupported) {
+        char b[256];
+        snprintf(b, sizeof(b), "layers %zu..%zu head launch failed: %s", i, gend + n - 1, hipGetErrorString(e));
+        return fail(c, YL_ERR_HIP, b);
+      }
+    }
     if (gend - i > 1) {
       YlConvP ps[4];
       for (size_t q = i; q < gend; ++q) params(q, ps[q - i]);
@@ -806,7 +855,7 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = tru
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
   const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10) |
                      (c->opt_batch_levels << 11) | (c->opt_hybrid << 12) | (c->opt_nms_groups << 13) |
-                     (c->opt_winograd << 17);
+                     (c->opt_winograd << 17) | (c->opt_fuse_head << 18);
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
@@ -928,7 +977,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   if (!g_inited[device_id]) {
     if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess || yl_stemblock_init() != hipSuccess ||
         yl_conv_init_bf16() != hipSuccess || yl_stemblock_init_bf16() != hipSuccess || yl_convc_init() != hipSuccess ||
-        yl_convc_init_bf16() != hipSuccess)
+        yl_convc_init_bf16() != hipSuccess || yl_dpp_init() != hipSuccess)
       return YL_ERR_HIP;
     g_inited[device_id] = true;
   }
@@ -951,8 +1000,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   c->N = off;
   if (c->N >= (1 << 20)) return fail(c, YL_ERR_UNSUPPORTED, "more than 2^20 candidates per image");
   if (d->num_layers == 0) return YL_OK;
-  HIPCHK(c, hipMalloc((void**)&c->zeros, 256));
-  HIPCHK(c, hipMemset(c->zeros, 0, 256));
+  HIPCHK(c, hipMalloc((void**)&c->zeros, 1024));
+  HIPCHK(c, hipMemset(c->zeros, 0, 1024));
   if (d->in_channels != 3) return fail(c, YL_ERR_UNSUPPORTED, "network input must have 3 channels");
   if (!d->layers || !d->slot_h || !d->slot_w || !d->slot_c) return fail(c, YL_ERR_INVALID, "null layer/slot arrays");
   c->slots.resize(d->num_slots);
@@ -1159,6 +1208,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!strcmp(name, "hybrid")) { c->opt_hybrid = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "batch_levels")) { c->opt_batch_levels = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "fuse_decode")) { c->opt_fuse_decode = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "fuse_head")) { c->opt_fuse_head = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "winograd")) { c->opt_winograd = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "lanes")) { c->opt_lanes = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }

@@ -25,6 +25,17 @@ __device__ __forceinline__ f32x4 yl_ld4(const float* p) { return *reinterpret_ca
 // clamp to [lo,hi] in ONE VALU op per element (v_med3_f32).  fp32 MFMA and fp32 VALU share the SIMD's FMA
 // lanes on gfx950 (same 64 FLOP/clk/SIMD peak; measured: removing VALU work shortens MFMA-bound kernels 1:1),
 // so epilogue instruction count is kernel time.  lo = -inf / hi = +inf give the one-sided / identity cases.
+// acc + a * b per component as two v_pk_fma_f32 (IEEE fma per lane and component, the bits of four fmaf calls, half the
+// VALU issue time).  On gfx950 the fp32 MFMA runs on the vector FMA lanes -- SQ counters of the fp32 kernels here show
+// MFMA busy cycles + 4 cycles per VALU instruction adding up to the SIMD's time -- so every VALU instruction saved in
+// a depthwise inner loop is MFMA time gained.
+__device__ __forceinline__ f32x4 yl_fma4(f32x4 a, f32x4 b, f32x4 acc) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ lo = __builtin_elementwise_fma((f32x2_){a.x, a.y}, (f32x2_){b.x, b.y}, (f32x2_){acc.x, acc.y});
+  const f32x2_ hi = __builtin_elementwise_fma((f32x2_){a.z, a.w}, (f32x2_){b.z, b.w}, (f32x2_){acc.z, acc.w});
+  return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
+
 __device__ __forceinline__ f32x4 yl_clamp4(f32x4 v, float lo, float hi) {
   f32x4 r;
   r.x = __builtin_amdgcn_fmed3f(v.x, lo, hi); r.y = __builtin_amdgcn_fmed3f(v.y, lo, hi);

@@ -1,0 +1,255 @@
+// Head branch of a pyramid level under yl_predict as ONE launch:
+//     depthwise 3x3 (+act)  ->  1x1 conv (+act)  ->  1x1 head-output conv  ->  decode
+// (the reference's head: DWConvBlock trunk + 1x1 `out` conv, /root/reference/scripts/model/model_v2.py:24-41, 262-318;
+// decode of utils_ms.py:26-123 in the epilogue as in yl_conv_pwt_kernel<.., DEC>).  Before: two launches per level --
+// yl_conv_dwc_kernel (depthwise waves + GEMM waves, B fragments through LDS, one GEMM wave idle at 6 n-tiles) wrote
+// the 96-channel trunk tensor, yl_conv_pwt_kernel read it back: 0.262 ms for the 80x80 level at B = 64, each half at
+// ~45 % of its MFMA time.
+//
+// Here every wave is autonomous, as in the stem block: lane (kq, pl) = pixel pl of a 4x4 tile, 4 consecutive channels.
+//   per 16-channel block kb:  nine float4 taps of the lane's pixel straight from L1/L2 (requested one block ahead),
+//                             bias + 9 fma (tap order of yl_conv_dwc_kernel) + activation  -> B operand of block kb,
+//                             6 n-tiles x 4 MFMAs against the trunk 1x1 weights (A fragments from LDS)
+//   bias + clamp in registers: the D fragment of n-tile nt IS the B fragment of k-block nt of the next GEMM
+//   6 k-blocks x NT3 n-tiles x 4 MFMAs against the head-output weights (LDS), decode epilogue (one wave = whole rows).
+// Both weight images (standard A-fragment packs of the two layers, 36 KiB each at 96 channels) and the depthwise taps
+// are copied to LDS once per workgroup (LDS-DMA); the grid is persistent, a workgroup walks a contiguous range of
+// tiles with its 8 waves interleaved (8 neighbouring tiles in flight share their halo lines in L1 / the XCD's L2).
+// Same k order, same arithmetic as the two kernels it replaces: bit-identical NMS inputs (tests/test_gpu_parity.py).
+// Nothing is written but boxes / scores / classes: the trunk tensor never exists.
+#include <stdlib.h>
+#include "yl_internal.h"
+#include "yl_dev.h"
+#include "yl_epi.h"
+
+#ifndef DPP_NW
+#define DPP_NW 8                       // waves per workgroup
+#endif
+#ifndef DPP_WPE
+#define DPP_WPE 2                      // waves per SIMD the register budget is set for
+#endif
+#ifndef DPP_EXP
+#define DPP_EXP 0                      // timing experiments (variant builds only, results WRONG): 1 no decode, 2 no tap loads,
+#endif                                 // 3 no depthwise arithmetic, 4 no MFMAs
+
+template <int KB /*Cin/16*/, int NT1 /*trunk n-tiles*/, int NT3 /*head-output n-tiles*/>
+__global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlConvMulti mp) {
+  int yl_k = 0;
+  if (mp.n > 1 && (int)blockIdx.x >= mp.p[1].blk0) yl_k = 1;
+  if (mp.n > 2 && (int)blockIdx.x >= mp.p[2].blk0) yl_k = 2;
+  if (mp.n > 3 && (int)blockIdx.x >= mp.p[3].blk0) yl_k = 3;
+  const YlConvP& p = mp.p[yl_k];
+  const int bx = (int)blockIdx.x - p.blk0, gx = p.nblk;
+  constexpr int Cin = KB * 16;
+  extern __shared__ __attribute__((aligned(16))) float dpp_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  f32x4* w1l = reinterpret_cast<f32x4*>(dpp_lds);                    // [KB][NT1][64] float4
+  f32x4* w3l = w1l + KB * NT1 * 64;                                  // [NT1][NT3][64] float4
+  float* dwl = reinterpret_cast<float*>(w3l + NT1 * NT3 * 64);       // [9][Cin] taps, [Cin] depthwise bias
+  float* b1l = dwl + 10 * Cin;                                       // [NT1 * 16] trunk bias (zero padded)
+  {
+    const f32x4* g1 = reinterpret_cast<const f32x4*>(p.wp);
+    for (int r = wave; r < KB * NT1; r += DPP_NW) yl_glds16(g1 + r * 64 + lane, w1l + r * 64);
+    const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
+    for (int r = wave; r < NT1 * NT3; r += DPP_NW) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
+    yl_glds_floats(p.dw_w, dwl, 9 * Cin, tid, DPP_NW * 64);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + 9 * Cin, Cin, tid, DPP_NW * 64);
+    else for (int i = tid; i < Cin; i += DPP_NW * 64) dwl[9 * Cin + i] = 0.0f;
+    yl_glds_floats(p.bias, b1l, NT1 * 16, tid, DPP_NW * 64);
+  }
+  __syncthreads();
+
+  const int H = p.H, W = p.W, OW = p.OW, OH = p.OH;                  // depthwise stride 1, 'same' padding: H == OH
+  const int tw = OW >> 2, th = OH >> 2;
+  const int tiles_img = tw * th;
+  const int ntiles = p.B * tiles_img;
+  // XCD-aware ranges (gx % 8 == 0 and blk0 % 8 == 0: workgroup b runs on XCD b % 8): XCD x owns the contiguous band
+  // [x*T/8, (x+1)*T/8) of the tiles, its gx/8 workgroups split the band evenly
+  int r0, r1;
+  {
+    const int x = bx & 7, j = bx >> 3, nj = gx >> 3;
+    const long b0 = ((long)ntiles * x) >> 3, b1 = ((long)ntiles * (x + 1)) >> 3;
+    r0 = (int)(b0 + ((b1 - b0) * j) / nj);
+    r1 = (int)(b0 + ((b1 - b0) * (j + 1)) / nj);
+  }
+  const float* const xin = p.x;
+  const float* const zl = p.zeros + 4 * kq;                          // >= 1 KiB of zeros: the same kb offsets apply
+  const float lo1 = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi1 = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float* const tapw = dwl + 4 * kq;                            // tap t of block kb: tapw[t * Cin + kb * 16]
+
+  // Software pipeline over the tap loads: the taps of block kb + 2 are requested while block kb is multiplied (two
+  // register sets), and the first block of the NEXT tile is requested before this tile's second GEMM and decode -- the
+  // trunk input comes from the Infinity Cache / HBM (it was written by the previous launch), ~1.5-2k cycles per
+  // request against 768 cycles of MFMAs per block.  (One block ahead, nothing across tiles: 0.299 ms per B = 64
+  // launch of the three levels; without the loads 0.255 ms.)
+  YlPix px[1];
+  const float* tp[9];
+  auto setup = [&](int tile) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tw, txi = trem - tyi * tw;
+    px[0].b = b; px[0].oy = 4 * tyi + (pl >> 2); px[0].ox = 4 * txi + (pl & 3); px[0].valid = true;
+    px[0].lin = ((size_t)b * OH + px[0].oy) * OW + px[0].ox;
+    // nine tap pointers of the lane's pixel (the zero buffer where a tap falls outside the image): centre pointer +
+    // wave-uniform deltas, row / column validity computed once
+    const float* const ctr = xin + (((long)b * H + px[0].oy) * W + px[0].ox) * Cin + 4 * kq;
+    bool rok[3], cok[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int iy = px[0].oy - p.dw_pad_t + d, ix = px[0].ox - p.dw_pad_l + d;
+      rok[d] = iy >= 0 && iy < H;
+      cok[d] = ix >= 0 && ix < W;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - p.dw_pad_t, dx = tap % 3 - p.dw_pad_l;                // wave-uniform
+      tp[tap] = (rok[tap / 3] && cok[tap % 3]) ? ctr + (dy * W + dx) * Cin : zl;
+    }
+  };
+  f32x4 xa[9], xb[9];                                                // taps of the even / odd blocks
+  auto fetch = [&](f32x4 (&dst)[9], int kb) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) dst[tap] = DPP_EXP == 2 ? (f32x4){1.f, 2.f, 3.f, (float)tap} : yl_ld4(tp[tap] + kb * 16);
+  };
+  int tile = r0 + wave;
+  if (tile < r1) { setup(tile); fetch(xa, 0); }
+  while (tile < r1) {
+    const YlPix pxc = px[0];                                         // the tile computed now
+    if (KB > 1) fetch(xb, 1);
+    f32x4 acc1[1][NT1];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) acc1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto block = [&](f32x4 (&xt)[9], int kb) {
+      f32x4 xq[1];
+      xq[0] = *reinterpret_cast<const f32x4*>(tapw + 9 * Cin + kb * 16);
+#pragma unroll
+      for (int tap = 0; tap < (DPP_EXP == 3 ? 1 : 9); ++tap) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(tapw + tap * Cin + kb * 16);
+        xq[0] = yl_fma4(xt[tap], w, xq[0]);
+      }
+      xq[0] = yl_actc(xq[0], p.dw_act, dlo, dhi);
+      if (kb + 2 < KB) fetch(xt, kb + 2);
+      f32x4 wq[NT1];
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) wq[nt] = w1l[(kb * NT1 + nt) * 64 + lane];
+      if (DPP_EXP == 4) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) acc1[0][nt] += wq[nt] * xq[0];
+      } else {
+        yl_mma_step<NT1, 1>(wq, xq, acc1);
+      }
+      asm volatile("" ::: "memory");     // keeps the A-fragment reads of later blocks behind this block's MFMAs (fully
+    };                                   // unrolled and unfenced, the scheduler hoists all 36: 256 VGPRs + scratch)
+#pragma unroll
+    for (int kb = 0; kb < KB; kb += 2) {
+      block(xa, kb);
+      if (kb + 1 < KB) block(xb, kb + 1);
+    }
+    const int next = tile + DPP_NW;
+    if (next < r1) { setup(next); fetch(xa, 0); }                    // in flight under the second GEMM and the decode
+    // trunk epilogue in registers: D fragment of n-tile nt = B fragment of k-block nt of the head-output GEMM
+    f32x4 acc3[1][NT3];
+#pragma unroll
+    for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NT1; ++kb) {
+      f32x4 hq[1];
+      hq[0] = yl_clamp4(acc1[0][kb] + *reinterpret_cast<const f32x4*>(b1l + kb * 16 + 4 * kq), lo1, hi1);
+      f32x4 wq[NT3];
+#pragma unroll
+      for (int nt = 0; nt < NT3; ++nt) wq[nt] = w3l[(kb * NT3 + nt) * 64 + lane];
+      if (DPP_EXP == 4) {
+#pragma unroll
+        for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += wq[nt] * hq[0];
+      } else {
+        yl_mma_step<NT3, 1>(wq, hq, acc3);
+      }
+      asm volatile("" ::: "memory");
+    }
+    const YlPix pxd[1] = {pxc};
+    if (DPP_EXP == 1) {
+      f32x4 t = acc3[0][0];
+#pragma unroll
+      for (int nt = 1; nt < NT3; ++nt) t += acc3[0][nt];
+      if (t.x == 1234.5f) p.dec_scores[pxd[0].lin] = t.y + t.z + t.w;
+    } else {
+      yl_epi_decode<NT3, 1>(p, acc3, pxd, 0, kq, lane, p.b3);
+    }
+    tile = next;
+  }
+}
+
+static size_t dpp_lds_bytes(int kb, int nt1, int nt3) {
+  return (size_t)(kb * nt1 + nt1 * nt3) * 1024 + (size_t)(10 * kb * 16 + nt1 * 16) * 4;
+}
+
+// shapes instantiated: (Cin/16, trunk n-tiles, head-output n-tiles)
+#define YL_DPP_SHAPES(X) X(6, 6, 6) X(4, 4, 6)
+
+bool yl_dpp_supported(int cin, int cout, int c3, int oh, int ow) {
+  if ((cin & 15) || (cout & 15) || (oh & 3) || (ow & 3)) return false;
+#define YL_DPP_CHECK(A, B, C) if (cin == A * 16 && cout == B * 16 && (c3 + 15) / 16 == C) return true;
+  YL_DPP_SHAPES(YL_DPP_CHECK)
+#undef YL_DPP_CHECK
+  return false;
+}
+
+template <int KB, int NT1, int NT3>
+static hipError_t dpp_go(const YlConvP* ps, int n, hipStream_t st, bool attr_only) {
+  const size_t lds = dpp_lds_bytes(KB, NT1, NT3);
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_dpp_kernel<KB, NT1, NT3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds);
+  YlConvMulti m;
+  m.n = n;
+  long total = 0;
+  for (int k = 0; k < n; ++k) { m.p[k] = ps[k]; total += (long)ps[k].B * (ps[k].OH >> 2) * (ps[k].OW >> 2); }
+  // one workgroup per CU (8 waves, two per SIMD), dealt to the problems in proportion to their tiles in multiples of 8
+  // (XCD-aligned ranges); a launch smaller than that gets one workgroup per 8 tiles
+  const int budget = YL_NUM_CU * (DPP_WPE * 4 / DPP_NW);
+  int at = 0;
+  for (int k = 0; k < n; ++k) {
+    const long t = (long)ps[k].B * (ps[k].OH >> 2) * (ps[k].OW >> 2);
+    long nb = (t * budget + total / 2) / total;
+    if (nb > (t + DPP_NW - 1) / DPP_NW) nb = (t + DPP_NW - 1) / DPP_NW;
+    nb = (nb + 4) / 8 * 8;
+    if (nb < 8) nb = 8;
+    m.p[k].blk0 = at;
+    m.p[k].nblk = (int)nb;
+    at += (int)nb;
+  }
+  hipLaunchKernelGGL((yl_conv_dpp_kernel<KB, NT1, NT3>), dim3((unsigned)at), dim3(DPP_NW * 64), lds, st, m);
+  return hipGetLastError();
+}
+
+// n <= 4 head branches of identical configuration (ps[k]: the trunk layer's parameters with w3p / b3 / C3 and the dec_*
+// fields of its head-output layer).  hipErrorNotSupported: shape not instantiated (the two-launch form runs).
+hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st) {
+  if (n < 1 || n > 4) return hipErrorNotSupported;
+  const YlConvP& q = ps[0];
+  if (q.k != 1 || q.dw_k != 3 || q.dw_stride != 1 || q.C1 > 0 || q.res || q.up || !q.w3p || !q.dec_boxes || q.dec_raw ||
+      q.act == YL_ACT_SILU || q.dw_act == YL_ACT_SILU)
+    return hipErrorNotSupported;
+  for (int k = 0; k < n; ++k)
+    if (!yl_dpp_supported(ps[k].Cin, ps[k].N, ps[k].C3, ps[k].OH, ps[k].OW) || ps[k].Cin != q.Cin || ps[k].N != q.N ||
+        ps[k].C3 != q.C3 || ps[k].H != ps[k].OH || ps[k].W != ps[k].OW)
+      return hipErrorNotSupported;
+  const int kb = q.Cin / 16, nt1 = q.N / 16, nt3 = (q.C3 + 15) / 16;
+#define YL_DPP_RUN(A, B, C) if (kb == A && nt1 == B && nt3 == C) return dpp_go<A, B, C>(ps, n, st, false);
+  YL_DPP_SHAPES(YL_DPP_RUN)
+#undef YL_DPP_RUN
+  return hipErrorNotSupported;
+}
+
+hipError_t yl_dpp_init() {
+  hipError_t e = hipSuccess;
+#define YL_DPP_ATTR(A, B, C) if (e == hipSuccess) e = dpp_go<A, B, C>(nullptr, 0, nullptr, true);
+  YL_DPP_SHAPES(YL_DPP_ATTR)
+#undef YL_DPP_ATTR
+  return e;
+}

@@ -81,14 +81,15 @@ __device__ __forceinline__ void yl_epi_generic(const YlConvP& p, f32x4 (&acc)[MT
 // (yl_decode.h, contraction off) on the same fp32 logits as the unfused path -> bit-identical NMS inputs.
 template <int NT, int MT>
 __device__ __forceinline__ void yl_epi_decode(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT], int nt0,
-                                              int kq, int lane) {
+                                              int kq, int lane, const float* bias_override = nullptr) {
 #pragma clang fp contract(off)
   const int C = p.dec_C;
+  const float* const bias = bias_override ? bias_override : p.bias;   // yl_conv_dpp_kernel: the chained conv's bias
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     f32x4 v[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt] + yl_ld4(p.bias + (nt0 + nt) * 16 + 4 * kq);
+    for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt] + yl_ld4(bias + (nt0 + nt) * 16 + 4 * kq);
     // ---- objectness: channel 4 = element 0 of the kq-1 lane
     const float tobj = __shfl(v[0].x, (lane & 15) + 16, 64);
     // ---- class logits: local first-maximum, then across the 4 lanes of the pixel

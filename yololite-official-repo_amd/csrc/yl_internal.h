@@ -139,6 +139,10 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
 hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_stemblock(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init();
+// depthwise 3x3 -> 1x1 -> 1x1 head output + decode as one launch (yl_dpp.hip)
+hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st);
+bool yl_dpp_supported(int cin, int cout, int c3, int oh, int ow);
+hipError_t yl_dpp_init();
 bool yl_stemblock_supported(int c1, int c2, int c3);
 hipError_t yl_conv_init();
 bool yl_uib_supported(int c1, int cmid, int n, int dk);
