@@ -863,6 +863,50 @@ def test_ir_fusion_is_bitwise_the_two_launch_form(S, B):
         assert torch.equal(a, r)
 
 
+@pytest.mark.parametrize("S,B,taken", [(640, 3, True), (384, 2, True), (128, 5, True), (352, 2, False)])
+def test_fused_head_launch_is_bitwise_and_never_writes_the_trunk_tensor(S, B, taken):
+    """yl_conv_dpp_kernel (round 3): under yl_predict the head branches of edge_n -- depthwise 3x3 -> 1x1 trunk -> 1x1 head
+    output -> decode -- run as ONE launch for all levels (option "fuse_head", default on).  Same k orders and arithmetic
+    as yl_conv_dwc/dwt_kernel + yl_conv_pwt_kernel<DEC>: detections of both post modes are the same BITS with the option
+    off; and the launch is really taken: the trunk tensors keep the previous call's contents.  352: a level grid is not a
+    multiple of the 4x4 wave tile -- the two-launch form runs, same result."""
+    meta = zoo_meta("edge_n", 80, S)
+    sd = synth_state_dict(meta, seed=12)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    ctx.set_option("reuse_slots", 0)                      # every tensor keeps its own memory: slots can be read back
+    trunks = [l for l in m.program.layers if ".trunk." in l.name and l.dw_k == 3]
+    assert len(trunks) == 3
+    xa, xb = _x(B, S, seed=51).to(DEV), _x(B, S, seed=52).to(DEV)
+
+    def run(x, mode, conf, iou, cap):
+        mo = 1024 if mode == _lib.POST_MAIN else ctx.N
+        d, c = ctx.predict(x, mode, conf, iou, per_class_cap=cap, max_out=mo)
+        return d.cpu().numpy().copy(), c.cpu().numpy().copy()
+
+    def slots():
+        return [ctx.read_slot(l.out_slot, B, (S // st, S // st, l.cout)).clone() for l, st in zip(trunks, (8, 16, 32))]
+
+    try:
+        ctx.set_option("fuse_head", 0)
+        ref = {k: run(xb, *k) for k in ((_lib.POST_MAIN, 0.25, 0.5, 300), (_lib.POST_EVAL, 0.001, 0.65, 0))}
+        run(xa, _lib.POST_MAIN, 0.25, 0.5, 300)
+        ta = slots()                                      # trunk outputs of xa, written by the two-launch form
+        ctx.set_option("fuse_head", 1)
+        for k, (d0, c0) in ref.items():
+            d1, c1 = run(xb, *k)
+            assert np.array_equal(c0, c1) and (k[0] != _lib.POST_EVAL or int(c0.sum()) > 0)
+            for i in range(B):
+                assert np.array_equal(d0[i, :c0[i]].view(np.uint32), d1[i, :c1[i]].view(np.uint32))
+        same = [torch.equal(a, b) for a, b in zip(ta, slots())]
+        assert all(same) if taken else not any(same)      # taken: untouched by the fused launches on xb
+        ctx.set_option("fuse_head", 0)
+        run(xb, _lib.POST_MAIN, 0.25, 0.5, 300)
+        assert not all(torch.equal(a, b) for a, b in zip(ta, slots()))
+    finally:
+        ctx.set_option("fuse_head", 1); ctx.set_option("reuse_slots", 1)
+
+
 @pytest.mark.parametrize("name,S,B", [("edge_n", 640, 2), ("edge_n", 320, 3)])
 def test_uib_and_lateral_fusion_through_the_ir_kernel_is_bitwise(name, S, B, monkeypatch):
     """Round 3: MobileNetV4 UIB blocks without a start depthwise and the FPN pairs lateral{k} (1x1 + bias + upsample-add)

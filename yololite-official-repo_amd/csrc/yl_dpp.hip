@@ -49,6 +49,7 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
   f32x4* w3l = w1l + KB * NT1 * 64;                                  // [NT1][NT3][64] float4
   float* dwl = reinterpret_cast<float*>(w3l + NT1 * NT3 * 64);       // [9][Cin] taps, [Cin] depthwise bias
   float* b1l = dwl + 10 * Cin;                                       // [NT1 * 16] trunk bias (zero padded)
+  float* b3l = b1l + NT1 * 16;                                       // [NT3 * 16] head-output bias (zero padded)
   {
     const f32x4* g1 = reinterpret_cast<const f32x4*>(p.wp);
     for (int r = wave; r < KB * NT1; r += DPP_NW) yl_glds16(g1 + r * 64 + lane, w1l + r * 64);
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
     if (p.dw_b) yl_glds_floats(p.dw_b, dwl + 9 * Cin, Cin, tid, DPP_NW * 64);
     else for (int i = tid; i < Cin; i += DPP_NW * 64) dwl[9 * Cin + i] = 0.0f;
     yl_glds_floats(p.bias, b1l, NT1 * 16, tid, DPP_NW * 64);
+    yl_glds_floats(p.b3, b3l, NT3 * 16, tid, DPP_NW * 64);
   }
   __syncthreads();
 
@@ -124,31 +126,41 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
     f32x4 acc1[1][NT1];
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) acc1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto block = [&](f32x4 (&xt)[9], int kb) {
-      f32x4 xq[1];
-      xq[0] = *reinterpret_cast<const f32x4*>(tapw + 9 * Cin + kb * 16);
+    // depthwise result of block kb (bias + 9 fma in the tap order of yl_conv_dwc_kernel, activation) = B operand of kb
+    auto dwise = [&](const f32x4 (&xt)[9], int kb) {
+      f32x4 q = *reinterpret_cast<const f32x4*>(tapw + 9 * Cin + kb * 16);
 #pragma unroll
-      for (int tap = 0; tap < (DPP_EXP == 3 ? 1 : 9); ++tap) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(tapw + tap * Cin + kb * 16);
-        xq[0] = yl_fma4(xt[tap], w, xq[0]);
-      }
-      xq[0] = yl_actc(xq[0], p.dw_act, dlo, dhi);
-      if (kb + 2 < KB) fetch(xt, kb + 2);
+      for (int tap = 0; tap < (DPP_EXP == 3 ? 1 : 9); ++tap)
+        q = yl_fma4(xt[tap], *reinterpret_cast<const f32x4*>(tapw + tap * Cin + kb * 16), q);
+      return yl_clamp4(q, dlo, dhi);                          // ReLU family only (SiLU is refused at launch): no branch in the region
+    };
+    // One region per block (the asm fences keep the scheduler from hoisting later blocks' 36 A-fragment reads: 256 VGPRs
+    // + scratch): A fragments of block kb, the MFMAs of block kb, and -- independent of them, for the scheduler to
+    // interleave -- the depthwise arithmetic of block kb + 1 and the tap requests of block kb + 2.
+    f32x4 xq[1], xn;
+    xq[0] = dwise(xa, 0);
+    if (2 < KB) fetch(xa, 2);
+    auto block = [&](f32x4 (&xnext)[9], int kb) {        // xnext: taps of block kb + 1 (then refilled with block kb + 3)
       f32x4 wq[NT1];
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) wq[nt] = w1l[(kb * NT1 + nt) * 64 + lane];
+      if (kb + 1 < KB) {
+        xn = dwise(xnext, kb + 1);
+        if (kb + 3 < KB) fetch(xnext, kb + 3);
+      }
       if (DPP_EXP == 4) {
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) acc1[0][nt] += wq[nt] * xq[0];
       } else {
         yl_mma_step<NT1, 1>(wq, xq, acc1);
       }
-      asm volatile("" ::: "memory");     // keeps the A-fragment reads of later blocks behind this block's MFMAs (fully
-    };                                   // unrolled and unfenced, the scheduler hoists all 36: 256 VGPRs + scratch)
+      xq[0] = xn;
+      asm volatile("" ::: "memory");
+    };
 #pragma unroll
     for (int kb = 0; kb < KB; kb += 2) {
-      block(xa, kb);
-      if (kb + 1 < KB) block(xb, kb + 1);
+      block(xb, kb);
+      if (kb + 1 < KB) block(xa, kb + 1);
     }
     const int next = tile + DPP_NW;
     if (next < r1) { setup(next); fetch(xa, 0); }                    // in flight under the second GEMM and the decode
@@ -178,14 +190,16 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
       for (int nt = 1; nt < NT3; ++nt) t += acc3[0][nt];
       if (t.x == 1234.5f) p.dec_scores[pxd[0].lin] = t.y + t.z + t.w;
     } else {
-      yl_epi_decode<NT3, 1>(p, acc3, pxd, 0, kq, lane, p.b3);
+#pragma unroll
+      for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += *reinterpret_cast<const f32x4*>(b3l + nt * 16 + 4 * kq);
+      yl_epi_decode<NT3, 1, true>(p, acc3, pxd, 0, kq, lane);
     }
     tile = next;
   }
 }
 
 static size_t dpp_lds_bytes(int kb, int nt1, int nt3) {
-  return (size_t)(kb * nt1 + nt1 * nt3) * 1024 + (size_t)(10 * kb * 16 + nt1 * 16) * 4;
+  return (size_t)(kb * nt1 + nt1 * nt3) * 1024 + (size_t)(10 * kb * 16 + nt1 * 16 + nt3 * 16) * 4;
 }
 
 // shapes instantiated: (Cin/16, trunk n-tiles, head-output n-tiles)

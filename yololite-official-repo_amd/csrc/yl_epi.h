@@ -79,17 +79,18 @@ __device__ __forceinline__ void yl_epi_generic(const YlConvP& p, f32x4 (&acc)[MT
 // reference exactly: (conf, idx) = sigmoid(cls).max(-1), FIRST maximum -- i.e. the smallest class whose
 // sigmoid equals sigmoid(max logit) (see yl_decode_score_kernel for the band argument).  Same arithmetic
 // (yl_decode.h, contraction off) on the same fp32 logits as the unfused path -> bit-identical NMS inputs.
-template <int NT, int MT>
+// BIASED: the caller has already added the bias (yl_conv_dpp_kernel keeps the head-output bias in LDS)
+template <int NT, int MT, bool BIASED = false>
 __device__ __forceinline__ void yl_epi_decode(const YlConvP& p, f32x4 (&acc)[MT][NT], const YlPix (&px)[MT], int nt0,
-                                              int kq, int lane, const float* bias_override = nullptr) {
+                                              int kq, int lane) {
 #pragma clang fp contract(off)
   const int C = p.dec_C;
-  const float* const bias = bias_override ? bias_override : p.bias;   // yl_conv_dpp_kernel: the chained conv's bias
+  const float* const bias = p.bias;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     f32x4 v[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt] + yl_ld4(bias + (nt0 + nt) * 16 + 4 * kq);
+    for (int nt = 0; nt < NT; ++nt) v[nt] = BIASED ? acc[mt][nt] : acc[mt][nt] + yl_ld4(bias + (nt0 + nt) * 16 + 4 * kq);
     // ---- objectness: channel 4 = element 0 of the kq-1 lane
     const float tobj = __shfl(v[0].x, (lane & 15) + 16, 64);
     // ---- class logits: local first-maximum, then across the 4 lanes of the pixel
