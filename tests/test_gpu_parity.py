@@ -496,7 +496,8 @@ def test_liveness_slot_reuse_is_bitwise_and_smaller(name, seg):
             assert torch.equal(v[2][b, :n], ref[2][b, :n]), k
         if seg:
             assert torch.equal(v[1], ref[1]) and torch.equal(v[4], ref[4]), k
-    assert mem[(1, 2)] * 3 < mem[(0, 2)], mem
+    # (streams = 2 after streams = 1: the chunk arenas keep the capacity of the 16-image chunk -- buffers only grow)
+    assert mem[(1, 1)] * 3 < mem[(0, 1)] and mem[(1, 2)] * 2 < mem[(0, 2)], mem
     ctx.set_option("reuse_slots", 1); ctx.set_option("streams", 2)
 
 
@@ -907,7 +908,7 @@ def test_fused_head_launch_is_bitwise_and_never_writes_the_trunk_tensor(S, B, ta
         ctx.set_option("fuse_head", 1); ctx.set_option("reuse_slots", 1)
 
 
-@pytest.mark.parametrize("name,S,B", [("edge_n", 640, 2), ("edge_n", 320, 3)])
+@pytest.mark.parametrize("name,S,B", [("edge_n", 640, 2), ("edge_n", 384, 3), ("edge_n", 320, 3)])
 def test_uib_and_lateral_fusion_through_the_ir_kernel_is_bitwise(name, S, B, monkeypatch):
     """Round 3: MobileNetV4 UIB blocks without a start depthwise and the FPN pairs lateral{k} (1x1 + bias + upsample-add)
     -> smooth{k} (depthwise block) run through yl_ir_kernel where it is instantiated; blocks.1.1 (1x1) is chained in the
@@ -920,7 +921,9 @@ def test_uib_and_lateral_fusion_through_the_ir_kernel_is_bitwise(name, S, B, mon
     monkeypatch.setenv("YL_FUSE_UIR", "0"); monkeypatch.setenv("YL_FUSE_LAT", "0"); monkeypatch.setenv("YL_FUSE_CHAIN", "0")
     mu = _hip_for(meta, sd)
     names_f = [l.name for l in mf.program.layers]
-    assert any("+smooth" in n for n in names_f) and any(n.endswith(".uib") for n in names_f)
+    # 320: the 20x20 / 40x40 grids have no 8x8 / 8x16 workgroup tiling -- those blocks keep the two-launch form (the 4x20
+    # tiling was measured slower and is not instantiated); only the chained 1x1 remains
+    assert S == 320 or (any("+smooth" in n for n in names_f) and any(n.endswith(".uib") for n in names_f))
     assert any(l.c3 > 0 and l.op == 1 for l in mf.program.layers)           # blocks.1.0 with blocks.1.1 chained in its epilogue
     assert not any("+smooth" in l.name or l.name.endswith(".uib") or (l.c3 > 0 and l.op == 1) for l in mu.program.layers)
     assert len(mu.program.layers) > len(mf.program.layers)
