@@ -372,6 +372,9 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     ctx.set_option("hybrid", args.hybrid)
     ctx.set_option("nms_groups", args.nms_groups)
     ctx.set_option("winograd", args.winograd)
+    for kv in args.opt:                                      # developer A/B: any other context option, name=value
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     max_out = MAX_OUT                                    # packed result rows per image
     gat = None
     if gather:
@@ -585,6 +588,7 @@ def main():
     ap.add_argument("--hybrid", type=int, default=0, help="full-batch launches for the high-resolution layers, chunks only for the low-resolution run")
     ap.add_argument("--batch-levels", type=int, default=1, help="smooth / head layers of all pyramid levels as one launch")
     ap.add_argument("--fuse-decode", type=int, default=1, help="decode inside the head-output conv epilogue")
+    ap.add_argument("--opt", action="append", default=[], help="extra context option name=value (developer A/B), repeatable")
     ap.add_argument("--lanes", type=int, default=0, help="side-stream lane for the coarse-level neck/head layers")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16-MFMA compute mode (f4; NOT the headline: reduced precision)")
     ap.add_argument("--winograd", type=int, default=0, help="1: dense 3x3 stride-1 convs (>= 64 channels) as Winograd F(2x2,3x3): "

@@ -418,7 +418,10 @@ static hipError_t sb_launch(const YlConvP& p0, hipStream_t st, bool attr_only, s
   YlConvP p = p0;
   if (p.stride != 2 || p.k != 3) return hipErrorInvalidValue;   // the staged input block is 11 x 35 per channel
   // strips of ~10 tiles: long enough that the one extra m-tile of a strip's first tile is noise (1.4 of 147 MFMAs per
-  // tile), short enough that every wave of the 8-waves-per-CU grid gets several (640 x 640, B = 64: 5 each)
+  // tile), short enough that every wave of the 8-waves-per-CU grid gets several (640 x 640, B = 64: 5 each).
+  // (A makespan-minimising length -- 5 tiles for the 32-image chunks of the two-stream plan, 5 instead of 2.5 strips per
+  // wave -- was measured SLOWER in the real step: 37.55k vs 37.8k images/s; the two chunk streams fill each other's
+  // tails, fewer and longer strips cost less.)
   const int tpr = (p.OW + SB_TC - 1) / SB_TC, tpc = (p.OH + SB_TR - 1) / SB_TR;
   int nsp = (tpr + 5) / 10;
   if (nsp < 1) nsp = 1;
