@@ -878,6 +878,10 @@ def test_fused_head_launch_is_bitwise_and_never_writes_the_trunk_tensor(S, B, ta
     ctx.set_option("reuse_slots", 0)                      # every tensor keeps its own memory: slots can be read back
     trunks = [l for l in m.program.layers if ".trunk." in l.name and l.dw_k == 3]
     assert len(trunks) == 3
+    # the same option covers yl_conv_dpq_kernel: blocks.2.5 (depthwise 3x3 -> 1x1 48->192 -> 1x1 192->48 + residual, a
+    # MobileNetV4 UIB block with a start depthwise only) as one launch; its expanded tensor is never written either
+    exp = [l for l in m.program.layers if l.name.endswith("blocks.2.5.pw_exp.conv")]
+    assert len(exp) == 1 and exp[0].dw_k == 3 and exp[0].cout == 192
     xa, xb = _x(B, S, seed=51).to(DEV), _x(B, S, seed=52).to(DEV)
 
     def run(x, mode, conf, iou, cap):
@@ -886,7 +890,8 @@ def test_fused_head_launch_is_bitwise_and_never_writes_the_trunk_tensor(S, B, ta
         return d.cpu().numpy().copy(), c.cpu().numpy().copy()
 
     def slots():
-        return [ctx.read_slot(l.out_slot, B, (S // st, S // st, l.cout)).clone() for l, st in zip(trunks, (8, 16, 32))]
+        return [ctx.read_slot(l.out_slot, B, (S // st, S // st, l.cout)).clone()
+                for l, st in zip(trunks + exp, (8, 16, 32, 16))]
 
     try:
         ctx.set_option("fuse_head", 0)
@@ -901,7 +906,10 @@ def test_fused_head_launch_is_bitwise_and_never_writes_the_trunk_tensor(S, B, ta
                 assert np.array_equal(d0[i, :c0[i]].view(np.uint32), d1[i, :c1[i]].view(np.uint32))
         same = [torch.equal(a, b) for a, b in zip(ta, slots())]
         assert all(same) if taken else not any(same)      # taken: untouched by the fused launches on xb
+        lv1 = [t.clone() for t in m(xb)]                  # raw levels (yl_forward): the pair launch, no head fusion
         ctx.set_option("fuse_head", 0)
+        for a, b in zip(m(xb), lv1):
+            assert torch.equal(a, b)
         run(xb, _lib.POST_MAIN, 0.25, 0.5, 300)
         assert not all(torch.equal(a, b) for a, b in zip(ta, slots()))
     finally:

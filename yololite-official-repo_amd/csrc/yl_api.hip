@@ -538,6 +538,28 @@ bool head_run_fusable(const yl_ctx* c, size_t i, size_t gend, size_t lend) {
   return true;
 }
 
+// depthwise 3x3 -> 1x1 expand -> 1x1 project (+residual) as ONE launch (yl_conv_dpq_kernel): layer i is the depthwise +
+// expand conv, layer i + 1 the plain 1x1 that consumes it, nothing else reads the expanded tensor, shape instantiated
+bool pair_fusable(const yl_ctx* c, size_t i, size_t lend) {
+  if (!c->opt_fuse_head || c->opt_bf16 || i + 1 >= lend) return false;
+  const DevLayer& T = c->layers[i];
+  const yl_layer& t = T.d; const yl_layer& o = c->layers[i + 1].d;
+  if (t.op != YL_OP_CONV || t.k != 1 || t.dw_k != 3 || t.dw_stride != 1 || t.c2 > 0 || t.c3 > 0 || t.head_level >= 0 ||
+      t.res_slot >= 0 || t.up_slot >= 0 || t.in_shift || t.act == YL_ACT_SILU || t.dw_act == YL_ACT_SILU || t.out_slot < 0)
+    return false;
+  if (o.op != YL_OP_CONV || o.head_level >= 0 || o.k != 1 || o.dw_k > 0 || o.c2 > 0 || o.c3 > 0 || o.in_slot != t.out_slot ||
+      o.cin != t.cout || o.act == YL_ACT_SILU || o.up_slot >= 0 || o.in_shift || o.res_slot == t.out_slot)
+    return false;
+  if (T.in_h != T.out_h || T.in_w != T.out_w || !yl_dpq_supported(t.cin, t.cout, o.cout, T.out_h, T.out_w)) return false;
+  for (size_t r = 0; r < c->layers.size(); ++r) {
+    if (r == i + 1) continue;
+    const yl_layer& e = c->layers[r].d;
+    const bool reads_in = e.op != YL_OP_STEM && e.op != YL_OP_STEMBLOCK && e.in_slot == t.out_slot;
+    if (reads_in || e.res_slot == t.out_slot || e.up_slot == t.out_slot) return false;
+  }
+  return true;
+}
+
 yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* level_out, hipStream_t st,
                      hipEvent_t* evs /*nullable: num_layers+1 events*/, int chunk = 0,
                      const yl_post_cfg* fuse = nullptr /*non-null: head outputs decode in their epilogue*/,
@@ -594,6 +616,19 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
       if (e != hipErrorNotSupported) {
         char b[256];
         snprintf(b, sizeof(b), "layers %zu..%zu head launch failed: %s", i, gend + n - 1, hipGetErrorString(e));
+        return fail(c, YL_ERR_HIP, b);
+      }
+    }
+    if (!evs && !lanes && gend == i + 1 && d.op == YL_OP_CONV && d.dw_k == 3 && pair_fusable(c, i, lend)) {
+      YlConvP pt, po;
+      params(i, pt);
+      params(i + 1, po);
+      pt.w3p = po.wp; pt.b3 = po.bias; pt.C3 = po.N; pt.act3 = po.act; pt.res = po.res; pt.out = po.out;
+      const hipError_t e = yl_launch_conv_dpq(pt, st);
+      if (e == hipSuccess) { i += 2; continue; }
+      if (e != hipErrorNotSupported) {
+        char b[256];
+        snprintf(b, sizeof(b), "layers %zu..%zu fused launch failed: %s", i, i + 1, hipGetErrorString(e));
         return fail(c, YL_ERR_HIP, b);
       }
     }

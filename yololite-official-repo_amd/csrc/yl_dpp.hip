@@ -198,6 +198,194 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same chain with a STORE epilogue and a wide middle: depthwise 3x3 (+act) -> 1x1 expand (+act) -> 1x1 project
+// (+bias, +residual) -- MobileNetV4 UIB blocks with a start depthwise and no middle one (edge_n blocks.2.5: 48 -> 192 ->
+// 48 at 40x40; timm `uir`, /root/reference/scripts/model/model_v2.py:79-121 consumes the features).  Before: two launches
+// (yl_conv_dwh/dwt_kernel wrote the 192-channel tensor, yl_conv_pwt_kernel read it back: 79 MB each way at B = 64).
+// The expanded row does not fit the registers at once: the expand GEMM runs in CHUNKS of 6 n-tiles (the depthwise
+// results of all KB blocks stay in registers), and each chunk's 6 D fragments are consumed at once as 6 k-blocks of the
+// project GEMM -- whose k order (ascending over all n-tiles of the expand) is that of the stand-alone launch.  The
+// residual initialises the project accumulators as in yl_conv_pwt_kernel (pre-add).  Bit-identical to the two launches.
+template <int KB /*Cin/16*/, int NC1 /*expand n-tiles / 6*/, int NT3 /*project n-tiles*/>
+__global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpq_kernel(YlConvP p) {
+  constexpr int Cin = KB * 16, NT1 = NC1 * 6;
+  const int bx = (int)blockIdx.x, gx = (int)gridDim.x;
+  extern __shared__ __attribute__((aligned(16))) float dpp_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  f32x4* w1l = reinterpret_cast<f32x4*>(dpp_lds);                    // [KB][NT1][64] float4
+  f32x4* w3l = w1l + KB * NT1 * 64;                                  // [NT1][NT3][64] float4
+  float* dwl = reinterpret_cast<float*>(w3l + NT1 * NT3 * 64);       // [9][Cin] taps, [Cin] depthwise bias
+  float* b1l = dwl + 10 * Cin;                                       // [NT1 * 16] expand bias (zero padded)
+  {
+    const f32x4* g1 = reinterpret_cast<const f32x4*>(p.wp);
+    for (int r = wave; r < KB * NT1; r += DPP_NW) yl_glds16(g1 + r * 64 + lane, w1l + r * 64);
+    const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
+    for (int r = wave; r < NT1 * NT3; r += DPP_NW) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
+    yl_glds_floats(p.dw_w, dwl, 9 * Cin, tid, DPP_NW * 64);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + 9 * Cin, Cin, tid, DPP_NW * 64);
+    else for (int i = tid; i < Cin; i += DPP_NW * 64) dwl[9 * Cin + i] = 0.0f;
+    yl_glds_floats(p.bias, b1l, NT1 * 16, tid, DPP_NW * 64);
+  }
+  __syncthreads();
+  const int H = p.H, W = p.W, OW = p.OW, OH = p.OH, N3 = p.C3;
+  const int tw = OW >> 2, th = OH >> 2;
+  const int tiles_img = tw * th;
+  const int ntiles = p.B * tiles_img;
+  int r0, r1;
+  if ((gx & 7) == 0) {                                               // XCD bands, see yl_conv_dpp_kernel
+    const int x = bx & 7, j = bx >> 3, nj = gx >> 3;
+    const long b0 = ((long)ntiles * x) >> 3, b1 = ((long)ntiles * (x + 1)) >> 3;
+    r0 = (int)(b0 + ((b1 - b0) * j) / nj);
+    r1 = (int)(b0 + ((b1 - b0) * (j + 1)) / nj);
+  } else {
+    r0 = (int)(((long)ntiles * bx) / gx); r1 = (int)(((long)ntiles * (bx + 1)) / gx);
+  }
+  const float* const xin = p.x;
+  const float* const zl = p.zeros + 4 * kq;
+  const float lo1 = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi1 = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float lo3 = (p.act3 == YL_ACT_RELU || p.act3 == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi3 = (p.act3 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float* const tapw = dwl + 4 * kq;
+  const bool pre_add = p.res != nullptr && p.act3 == YL_ACT_NONE;
+
+  size_t lin = 0;
+  const float* tp[9];
+  auto setup = [&](int tile) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tw, txi = trem - tyi * tw;
+    const int oy = 4 * tyi + (pl >> 2), ox = 4 * txi + (pl & 3);
+    lin = ((size_t)b * OH + oy) * OW + ox;
+    const float* const ctr = xin + lin * Cin + 4 * kq;
+    bool rok[3], cok[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int iy = oy - p.dw_pad_t + d, ix = ox - p.dw_pad_l + d;
+      rok[d] = iy >= 0 && iy < H;
+      cok[d] = ix >= 0 && ix < W;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - p.dw_pad_t, dx = tap % 3 - p.dw_pad_l;
+      tp[tap] = (rok[tap / 3] && cok[tap % 3]) ? ctr + (dy * W + dx) * Cin : zl;
+    }
+  };
+  f32x4 xa[9], xb[9];
+  auto fetch = [&](f32x4 (&dst)[9], int kb) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) dst[tap] = yl_ld4(tp[tap] + kb * 16);
+  };
+  auto dwise = [&](const f32x4 (&xt)[9], int kb) {
+    f32x4 q = *reinterpret_cast<const f32x4*>(tapw + 9 * Cin + kb * 16);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) q = yl_fma4(xt[tap], *reinterpret_cast<const f32x4*>(tapw + tap * Cin + kb * 16), q);
+    return yl_clamp4(q, dlo, dhi);
+  };
+  int tile = r0 + wave;
+  if (tile < r1) { setup(tile); fetch(xa, 0); }
+  while (tile < r1) {
+    const size_t linc = lin;                                         // the tile computed now
+    if (KB > 1) fetch(xb, 1);
+    f32x4 acc3[1][NT3];
+#pragma unroll
+    for (int nt = 0; nt < NT3; ++nt) {
+      const int n = nt * 16 + 4 * kq;
+      acc3[0][nt] = (pre_add && n < N3) ? yl_ld4(p.res + linc * N3 + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // depthwise results of every block stay in registers (xq); block kb + 1 is computed inside the region of the first
+    // chunk's MFMAs of block kb, tap requests run two blocks ahead (as in yl_conv_dpp_kernel)
+    f32x4 xq[KB][1];
+    xq[0][0] = dwise(xa, 0);
+    if (2 < KB) fetch(xa, 2);
+    const int next = tile + DPP_NW;
+#pragma unroll
+    for (int c = 0; c < NC1; ++c) {
+      f32x4 acc1[1][6];
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) acc1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        f32x4 wq[6];
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) wq[nt] = w1l[(kb * NT1 + c * 6 + nt) * 64 + lane];
+        if (c == 0 && kb + 1 < KB) {
+          if ((kb & 1) == 0) { xq[kb + 1][0] = dwise(xb, kb + 1); if (kb + 3 < KB) fetch(xb, kb + 3); }
+          else { xq[kb + 1][0] = dwise(xa, kb + 1); if (kb + 3 < KB) fetch(xa, kb + 3); }
+        }
+        yl_mma_step<6, 1>(wq, xq[kb], acc1);
+        asm volatile("" ::: "memory");                               // see yl_conv_dpp_kernel
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        // next tile's first taps: in flight under the last 6 project steps and the epilogue.  (Requested earlier --
+        // before the second chunk -- the kernel needs 256 VGPRs + scratch instead of 166.)
+        if (c == NC1 - 1 && j == 0 && next < r1) { setup(next); fetch(xa, 0); }
+        const int kb3 = c * 6 + j;
+        f32x4 hq[1];
+        hq[0] = yl_clamp4(acc1[0][j] + *reinterpret_cast<const f32x4*>(b1l + kb3 * 16 + 4 * kq), lo1, hi1);
+        f32x4 wq[NT3];
+#pragma unroll
+        for (int nt = 0; nt < NT3; ++nt) wq[nt] = w3l[(kb3 * NT3 + nt) * 64 + lane];
+        yl_mma_step<NT3, 1>(wq, hq, acc3);
+        asm volatile("" ::: "memory");
+      }
+    }
+    float* orow = p.out + linc * N3;
+#pragma unroll
+    for (int nt = 0; nt < NT3; ++nt) {
+      const int n = nt * 16 + 4 * kq;
+      f32x4 v = yl_clamp4(acc3[0][nt] + yl_ld4(p.b3 + n), lo3, hi3);
+      if (!pre_add && p.res && n < N3) v += yl_ld4(p.res + linc * N3 + n);
+      if (n < N3) *reinterpret_cast<f32x4*>(orow + n) = v;
+    }
+    tile = next;
+  }
+}
+
+// shapes instantiated: (Cin/16, expand n-tiles / 6, project n-tiles)
+#define YL_DPQ_SHAPES(X) X(3, 2, 3)
+
+bool yl_dpq_supported(int cin, int cmid, int cout, int oh, int ow) {
+  if ((cin & 15) || (cmid % 96) || (cout & 3) || (oh & 3) || (ow & 3)) return false;
+#define YL_DPQ_CHECK(A, B, C) if (cin == A * 16 && cmid == B * 96 && (cout + 15) / 16 == C) return true;
+  YL_DPQ_SHAPES(YL_DPQ_CHECK)
+#undef YL_DPQ_CHECK
+  return false;
+}
+
+template <int KB, int NC1, int NT3>
+static hipError_t dpq_go(const YlConvP& p, hipStream_t st, bool attr_only) {
+  const size_t lds = (size_t)(KB * NC1 * 6 + NC1 * 6 * NT3) * 1024 + (size_t)(10 * KB * 16 + NC1 * 96) * 4;
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_dpq_kernel<KB, NC1, NT3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds);
+  const long t = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
+  long nb = YL_NUM_CU * (DPP_WPE * 4 / DPP_NW);
+  if (nb > (t + DPP_NW - 1) / DPP_NW) nb = (t + DPP_NW - 1) / DPP_NW;
+  if (nb >= 8) nb &= ~7L;
+  hipLaunchKernelGGL((yl_conv_dpq_kernel<KB, NC1, NT3>), dim3((unsigned)nb), dim3(DPP_NW * 64), lds, st, p);
+  return hipGetLastError();
+}
+
+// p: the depthwise -> expand layer's parameters with w3p / b3 / C3 / act3, `res` and `out` of the project layer
+hipError_t yl_launch_conv_dpq(const YlConvP& p, hipStream_t st) {
+  if (p.k != 1 || p.dw_k != 3 || p.dw_stride != 1 || p.C1 > 0 || p.up || !p.w3p || p.act == YL_ACT_SILU ||
+      p.dw_act == YL_ACT_SILU || p.act3 == YL_ACT_SILU || p.H != p.OH || p.W != p.OW ||
+      !yl_dpq_supported(p.Cin, p.N, p.C3, p.OH, p.OW))
+    return hipErrorNotSupported;
+  const int kb = p.Cin / 16, nc1 = p.N / 96, nt3 = (p.C3 + 15) / 16;
+#define YL_DPQ_RUN(A, B, C) if (kb == A && nc1 == B && nt3 == C) return dpq_go<A, B, C>(p, st, false);
+  YL_DPQ_SHAPES(YL_DPQ_RUN)
+#undef YL_DPQ_RUN
+  return hipErrorNotSupported;
+}
+
 static size_t dpp_lds_bytes(int kb, int nt1, int nt3) {
   return (size_t)(kb * nt1 + nt1 * nt3) * 1024 + (size_t)(10 * kb * 16 + nt1 * 16 + nt3 * 16) * 4;
 }
@@ -262,6 +450,10 @@ hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st) {
 
 hipError_t yl_dpp_init() {
   hipError_t e = hipSuccess;
+  YlConvP q0{};
+#define YL_DPQ_ATTR(A, B, C) if (e == hipSuccess) e = dpq_go<A, B, C>(q0, nullptr, true);
+  YL_DPQ_SHAPES(YL_DPQ_ATTR)
+#undef YL_DPQ_ATTR
 #define YL_DPP_ATTR(A, B, C) if (e == hipSuccess) e = dpp_go<A, B, C>(nullptr, 0, nullptr, true);
   YL_DPP_SHAPES(YL_DPP_ATTR)
 #undef YL_DPP_ATTR
