@@ -301,12 +301,18 @@ size_t layer_group_end(const yl_ctx* c, size_t i, size_t lend) {
 // Place the slots inside a chunk arena.  Liveness is tracked per LAUNCH GROUP (a level-batched run reads and writes
 // all of its layers' tensors at once): slot s is live from the group that produces it to the group of its last
 // consumer, inclusive; first-fit over the gaps of the live set.  reuse == false: every slot gets its own range.
+bool pair_fusable(const yl_ctx* c, size_t i, size_t lend, bool ignore_options);
+
 void plan_slots(yl_ctx* c, bool reuse) {
   const size_t NL = c->layers.size(), NS = c->slots.size();
   std::vector<int> grp(NL, 0);
   int g = 0;
   for (size_t i = 0; i < NL; ++g) {
-    const size_t e = layer_group_end(c, i, NL);
+    size_t e = layer_group_end(c, i, NL);
+    // two layers that run_layers may send out as ONE launch (yl_conv_dpq_kernel) are one group: the second layer's
+    // output is written while the first layer's inputs are still being read by other tiles, so it must not be placed
+    // over them (whatever the options say when the plan is made)
+    if (e == i + 1 && pair_fusable(c, i, NL, true)) e = i + 2;
     for (size_t q = i; q < e; ++q) grp[q] = g;
     i = e;
   }
@@ -540,8 +546,8 @@ bool head_run_fusable(const yl_ctx* c, size_t i, size_t gend, size_t lend) {
 
 // depthwise 3x3 -> 1x1 expand -> 1x1 project (+residual) as ONE launch (yl_conv_dpq_kernel): layer i is the depthwise +
 // expand conv, layer i + 1 the plain 1x1 that consumes it, nothing else reads the expanded tensor, shape instantiated
-bool pair_fusable(const yl_ctx* c, size_t i, size_t lend) {
-  if (!c->opt_fuse_head || c->opt_bf16 || i + 1 >= lend) return false;
+bool pair_fusable(const yl_ctx* c, size_t i, size_t lend, bool ignore_options) {
+  if ((!ignore_options && (!c->opt_fuse_head || c->opt_bf16)) || i + 1 >= lend) return false;
   const DevLayer& T = c->layers[i];
   const yl_layer& t = T.d; const yl_layer& o = c->layers[i + 1].d;
   if (t.op != YL_OP_CONV || t.k != 1 || t.dw_k != 3 || t.dw_stride != 1 || t.c2 > 0 || t.c3 > 0 || t.head_level >= 0 ||
@@ -619,7 +625,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         return fail(c, YL_ERR_HIP, b);
       }
     }
-    if (!evs && !lanes && gend == i + 1 && d.op == YL_OP_CONV && d.dw_k == 3 && pair_fusable(c, i, lend)) {
+    if (!evs && !lanes && gend == i + 1 && d.op == YL_OP_CONV && d.dw_k == 3 && pair_fusable(c, i, lend, false)) {
       YlConvP pt, po;
       params(i, pt);
       params(i + 1, po);

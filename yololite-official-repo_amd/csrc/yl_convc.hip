@@ -699,7 +699,11 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // previous tile's tap reads are complete
     stage_store(stg);
     // (Requesting the NEXT tile's first halo block under the last block of this one -- the pipelining that pays in
-    // yl_conv_dpp_kernel -- was measured here: 37.54k vs 37.79k images/s on the headline step, slower.)
+    // yl_conv_dpp_kernel -- was measured here: 37.54k vs 37.79k images/s on the headline step, slower.  So was chaining
+    // the next block's plain 1x1 `pw_exp` behind this kernel's epilogue with both outputs written, for the five
+    // `pw_proj` -> `pw_exp` pairs of edge_n's 20x20 stage: one-stream launch times at B = 64, 45.4 us chained against
+    // 29.4 + 20.2 for the 5x5 pairs, 53.6 against 23.7 + 20.2 for the 3x3 pairs (one of them feeds 64 -> 480); headline
+    // unchanged at 38.8k with five launches fewer per chunk -- not kept.)
     for (int kb = 0; kb < KB; ++kb) {
       const bool more = kb + 1 < KB;
       if (more) stage_load(kb + 1, stg);
