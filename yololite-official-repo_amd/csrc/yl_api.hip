@@ -625,6 +625,23 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         return fail(c, YL_ERR_HIP, b);
       }
     }
+    // wide depthwise 3x3 -> 1x1 layer (more than 96 outputs) on its own: yl_conv_dpq_kernel's expand-only form computes
+    // the depthwise part once per pixel
+    if (!evs && !lanes && gend == i + 1 && d.op == YL_OP_CONV && d.dw_k == 3 && d.dw_stride == 1 && d.k == 1 && d.c2 == 0 &&
+        d.c3 == 0 && c->opt_fuse_head && !c->opt_bf16 && d.head_level < 0 && d.res_slot < 0 && d.up_slot < 0 && !d.in_shift &&
+        d.cout > 96 && !pair_fusable(c, i, lend, false) && c->layers[i].in_h == c->layers[i].out_h &&
+        yl_dpq_supported(d.cin, d.cout, 0, c->layers[i].out_h, c->layers[i].out_w)) {
+      YlConvP pt;
+      params(i, pt);
+      pt.w3p = nullptr;
+      const hipError_t e = yl_launch_conv_dpq(pt, st);
+      if (e == hipSuccess) { ++i; continue; }
+      if (e != hipErrorNotSupported) {
+        char b[256];
+        snprintf(b, sizeof(b), "layer %zu launch failed: %s", i, hipGetErrorString(e));
+        return fail(c, YL_ERR_HIP, b);
+      }
+    }
     if (!evs && !lanes && gend == i + 1 && d.op == YL_OP_CONV && d.dw_k == 3 && pair_fusable(c, i, lend, false)) {
       YlConvP pt, po;
       params(i, pt);

@@ -222,8 +222,10 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpq_kernel(YlCon
   {
     const f32x4* g1 = reinterpret_cast<const f32x4*>(p.wp);
     for (int r = wave; r < KB * NT1; r += DPP_NW) yl_glds16(g1 + r * 64 + lane, w1l + r * 64);
-    const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
-    for (int r = wave; r < NT1 * NT3; r += DPP_NW) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
+    if constexpr (NT3 > 0) {
+      const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
+      for (int r = wave; r < NT1 * NT3; r += DPP_NW) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
+    }
     yl_glds_floats(p.dw_w, dwl, 9 * Cin, tid, DPP_NW * 64);
     if (p.dw_b) yl_glds_floats(p.dw_b, dwl + 9 * Cin, Cin, tid, DPP_NW * 64);
     else for (int i = tid; i < Cin; i += DPP_NW * 64) dwl[9 * Cin + i] = 0.0f;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpq_kernel(YlCon
   while (tile < r1) {
     const size_t linc = lin;                                         // the tile computed now
     if (KB > 1) fetch(xb, 1);
-    f32x4 acc3[1][NT3];
+    f32x4 acc3[1][NT3 > 0 ? NT3 : 1];
 #pragma unroll
     for (int nt = 0; nt < NT3; ++nt) {
       const int n = nt * 16 + 4 * kq;
@@ -321,6 +323,18 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpq_kernel(YlCon
         yl_mma_step<6, 1>(wq, xq[kb], acc1);
         asm volatile("" ::: "memory");                               // see yl_conv_dpp_kernel
       }
+      if constexpr (NT3 == 0) {
+        // wide expand only (no project conv): the chunk's six n-tiles are stored; the depthwise part is computed ONCE
+        // per pixel (yl_conv_dwh_kernel recomputes it for every n-chunk of a layer with more than 96 outputs)
+        if (c == NC1 - 1 && next < r1) { setup(next); fetch(xa, 0); }
+        float* orow1 = p.out + linc * p.N;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int n = (c * 6 + j) * 16 + 4 * kq;
+          *reinterpret_cast<f32x4*>(orow1 + n) =
+              yl_clamp4(acc1[0][j] + *reinterpret_cast<const f32x4*>(b1l + (c * 6 + j) * 16 + 4 * kq), lo1, hi1);
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         // next tile's first taps: in flight under the last 6 project steps and the epilogue.  (Requested earlier --
@@ -329,13 +343,15 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpq_kernel(YlCon
         const int kb3 = c * 6 + j;
         f32x4 hq[1];
         hq[0] = yl_clamp4(acc1[0][j] + *reinterpret_cast<const f32x4*>(b1l + kb3 * 16 + 4 * kq), lo1, hi1);
-        f32x4 wq[NT3];
+        f32x4 wq[NT3 > 0 ? NT3 : 1];
 #pragma unroll
         for (int nt = 0; nt < NT3; ++nt) wq[nt] = w3l[(kb3 * NT3 + nt) * 64 + lane];
-        yl_mma_step<NT3, 1>(wq, hq, acc3);
+        yl_mma_step<(NT3 > 0 ? NT3 : 1), 1>(wq, hq, acc3);
         asm volatile("" ::: "memory");
       }
+      }
     }
+    if constexpr (NT3 > 0) {
     float* orow = p.out + linc * N3;
 #pragma unroll
     for (int nt = 0; nt < NT3; ++nt) {
@@ -344,14 +360,16 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpq_kernel(YlCon
       if (!pre_add && p.res && n < N3) v += yl_ld4(p.res + linc * N3 + n);
       if (n < N3) *reinterpret_cast<f32x4*>(orow + n) = v;
     }
+    }
     tile = next;
   }
 }
 
 // shapes instantiated: (Cin/16, expand n-tiles / 6, project n-tiles)
-#define YL_DPQ_SHAPES(X) X(3, 2, 3)
+#define YL_DPQ_SHAPES(X) X(3, 2, 3) X(3, 3, 0)
 
 bool yl_dpq_supported(int cin, int cmid, int cout, int oh, int ow) {
+  // cout == 0: the wide-expand-only form (no project conv)
   if ((cin & 15) || (cmid % 96) || (cout & 3) || (oh & 3) || (ow & 3)) return false;
 #define YL_DPQ_CHECK(A, B, C) if (cin == A * 16 && cmid == B * 96 && (cout + 15) / 16 == C) return true;
   YL_DPQ_SHAPES(YL_DPQ_CHECK)
@@ -375,11 +393,12 @@ static hipError_t dpq_go(const YlConvP& p, hipStream_t st, bool attr_only) {
 
 // p: the depthwise -> expand layer's parameters with w3p / b3 / C3 / act3, `res` and `out` of the project layer
 hipError_t yl_launch_conv_dpq(const YlConvP& p, hipStream_t st) {
-  if (p.k != 1 || p.dw_k != 3 || p.dw_stride != 1 || p.C1 > 0 || p.up || !p.w3p || p.act == YL_ACT_SILU ||
-      p.dw_act == YL_ACT_SILU || p.act3 == YL_ACT_SILU || p.H != p.OH || p.W != p.OW ||
-      !yl_dpq_supported(p.Cin, p.N, p.C3, p.OH, p.OW))
+  const int c3 = p.w3p ? p.C3 : 0;                                   // no project conv: the wide-expand-only form
+  if (p.k != 1 || p.dw_k != 3 || p.dw_stride != 1 || p.C1 > 0 || p.up || p.act == YL_ACT_SILU ||
+      p.dw_act == YL_ACT_SILU || (p.w3p && p.act3 == YL_ACT_SILU) || (!p.w3p && p.res) || p.dec_boxes ||
+      p.H != p.OH || p.W != p.OW || !yl_dpq_supported(p.Cin, p.N, c3, p.OH, p.OW))
     return hipErrorNotSupported;
-  const int kb = p.Cin / 16, nc1 = p.N / 96, nt3 = (p.C3 + 15) / 16;
+  const int kb = p.Cin / 16, nc1 = p.N / 96, nt3 = (c3 + 15) / 16;
 #define YL_DPQ_RUN(A, B, C) if (kb == A && nc1 == B && nt3 == C) return dpq_go<A, B, C>(p, st, false);
   YL_DPQ_SHAPES(YL_DPQ_RUN)
 #undef YL_DPQ_RUN
