@@ -188,13 +188,16 @@ def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
     ctx.set_option("lanes", 0); ctx.set_option("batch_levels", 1)
 
 
-@pytest.mark.parametrize("name,B,S", [("edge_n", 3, 320), ("edge_n", 2, 640), ("edge_m", 2, 320), ("yololite_m", 1, 256)])
+@pytest.mark.parametrize("name,B,S", [("edge_n", 3, 320), ("edge_n", 2, 640), ("edge_n", 3, 384), ("edge_n", 5, 128),
+                                      ("edge_m", 2, 320), ("yololite_m", 1, 256)])
 def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S, monkeypatch):
     """Alternative kernels of yl_convc.hip sum every output's k blocks in the same order as the kernels they replace
     -> identical bits.  "tile_m" 6: wave-autonomous 1x1 / depthwise kernels and the streamed dense 3x3 kernel OFF; 7:
     producer / consumer depthwise -> 1x1 kernel (opt-in) ON, with YL_DWC_ALL=1 on every layer shape it supports.
     Exception: yl_conv_kxk_kernel (yololite_m's dense 3x3) walks K channel-block-major instead of tap-major (cache
-    locality), a different fp32 summation order of the same 2952 products: compared at rounding-noise tolerance."""
+    locality), a different fp32 summation order of the same 2952 products: compared at rounding-noise tolerance.
+    "tile_m" 6 also turns off yl_conv_s2c_kernel (round 3: blocks.1.0 3x3 s2 + chained 1x1 from an LDS-staged patch; taken
+    where the output width is a multiple of 8: 640, 384, 128 here -- image borders included)."""
     monkeypatch.setenv("YL_DWC_ALL", "1")          # this test only: the opt-in kernel on every shape it supports
     meta = zoo_meta(name, 80, S)
     sd = synth_state_dict(meta, seed=4)

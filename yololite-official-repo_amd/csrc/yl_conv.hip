@@ -1252,6 +1252,12 @@ static int yl_partition_blocks(YlConvMulti& m, const long* tiles, int gx) {
 // launch (YlConvMulti) -- and launch.  tile_hint: 0 = auto, 1/2 = force MT.
 hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStream_t st) {
   if (n < 1 || n > 4) return hipErrorInvalidValue;
+#if !YL_BF16
+  if (n == 1 && ps[0].w3p && ps[0].k == 3 && ps[0].stride == 2 && tile_hint != 6) {   // 3x3 s2 + chained 1x1, staged patch
+    const hipError_t e = yl_launch_conv_s2c(ps[0], st);
+    if (e != hipErrorNotSupported) return e;
+  }
+#endif
   YlConvMulti m = {};
   m.n = n;
   int big = 0;

@@ -405,6 +405,170 @@ hipError_t yl_launch_conv_dpq(const YlConvP& p, hipStream_t st) {
   return hipErrorNotSupported;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense 3x3 stride-2 conv on a 16-channel input with a 1x1 conv chained behind it (edge_n blocks.1.0 16 -> 48 @160 -> 80
+// + blocks.1.1 48 -> 32, mobilenetv4_conv_small_050 `cn` blocks), wave-autonomous with the input patch STAGED in LDS like
+// the stem block's: one wave owns a 2x8 output tile; the 5 x 17 input pixels under it are five contiguous 1088-byte rows
+// of the NHWC tensor, copied into a wave-private LDS buffer by six asynchronous 16-byte-per-lane LDS-DMA loads (double
+// buffered: the next tile's patch is requested before this tile is computed; out-of-image chunks read the zero buffer);
+// per tap ONE ds_read_b128 is the B fragment (the linear patch layout costs bank conflicts on 9 reads per 132 MFMAs: not
+// worth a padded copy through registers), A fragments of both convs from LDS (33 KiB shared by the 8 waves), the 1x1
+// chained in registers, the tile's stores held back and issued in front of the next patch request (vmcnt is one
+// in-order counter).  yl_conv_mfma_kernel<3,2,1> spent 4.5 VALU instructions per MFMA on per-tap address / bounds
+// arithmetic (SQ counters: 1.5e7 VALU instructions x 4 cycles against 1.08e8 MFMA cycles per B = 64 launch) -- and fp32
+// VALU time is MFMA time.  Same k order (tap-major), same epilogues: bit-identical.
+template <int NT /*n-tiles of the 3x3*/, int NT3 /*n-tiles of the chained 1x1*/>
+__global__ __launch_bounds__(DPP_NW * 64, 2) void yl_conv_s2c_kernel(YlConvP p) {
+  constexpr int PR = 5, PC = 17, RCH = PC * 4, NCH = PR * RCH, NDMA = (NCH + 63) / 64;   // 340 16-byte chunks, 6 loads
+  constexpr int BUF_F = NDMA * 256;                                  // floats per patch buffer
+  const int bx = (int)blockIdx.x, gx = (int)gridDim.x;
+  extern __shared__ __attribute__((aligned(16))) float dpp_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  f32x4* w2l = reinterpret_cast<f32x4*>(dpp_lds);                    // [9][NT][64] float4
+  f32x4* w3l = w2l + 9 * NT * 64;                                    // [NT][NT3][64] float4
+  float* b2l = reinterpret_cast<float*>(w3l + NT * NT3 * 64);        // [NT * 16], [NT3 * 16]
+  float* b3l = b2l + NT * 16;
+  float* patch = b3l + NT3 * 16 + wave * 2 * BUF_F;                  // two buffers per wave
+  {
+    const f32x4* g2 = reinterpret_cast<const f32x4*>(p.wp);
+    for (int r = wave; r < 9 * NT; r += DPP_NW) yl_glds16(g2 + r * 64 + lane, w2l + r * 64);
+    const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
+    for (int r = wave; r < NT * NT3; r += DPP_NW) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
+    yl_glds_floats(p.bias, b2l, NT * 16, tid, DPP_NW * 64);
+    yl_glds_floats(p.b3, b3l, NT3 * 16, tid, DPP_NW * 64);
+  }
+  __syncthreads();
+  const int H = p.H, W = p.W, OW = p.OW, OH = p.OH, C3 = p.C3;
+  const int tw = OW >> 3, th = OH >> 1;
+  const int tiles_img = tw * th;
+  const int ntiles = p.B * tiles_img;
+  int r0, r1;
+  if ((gx & 7) == 0) {                                               // XCD bands, see yl_conv_dpp_kernel
+    const int x = bx & 7, j = bx >> 3, nj = gx >> 3;
+    const long b0 = ((long)ntiles * x) >> 3, b1 = ((long)ntiles * (x + 1)) >> 3;
+    r0 = (int)(b0 + ((b1 - b0) * j) / nj);
+    r1 = (int)(b0 + ((b1 - b0) * (j + 1)) / nj);
+  } else {
+    r0 = (int)(((long)ntiles * bx) / gx); r1 = (int)(((long)ntiles * (bx + 1)) / gx);
+  }
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float lo3 = (p.act3 == YL_ACT_RELU || p.act3 == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi3 = (p.act3 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  // the lane's chunk of every DMA load: (patch row, pixel, 16-byte quarter of the pixel's 64 bytes)
+  int crow[NDMA], cpx[NDMA], coff[NDMA];
+#pragma unroll
+  for (int k = 0; k < NDMA; ++k) {
+    int e = k * 64 + lane;
+    e = e < NCH ? e : NCH - 1;
+    crow[k] = e / RCH;
+    const int ch = e - crow[k] * RCH;
+    cpx[k] = ch >> 2;
+    coff[k] = (crow[k] * W + cpx[k]) * 16 + (ch & 3) * 4;
+  }
+  const int ty = pl >> 3, tx = pl & 7;
+  const int rbase = ((2 * ty) * RCH + (2 * tx) * 4 + kq) * 4;       // tap (ky, kx): + (ky * RCH + kx * 4) * 4 floats
+  auto request = [&](int tile, float* buf) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tw, txi = trem - tyi * tw;
+    const int iy0 = 2 * (2 * tyi) - p.pad_t, ix0 = 2 * (8 * txi) - p.pad_l;
+    const float* const img = p.x + (size_t)b * H * W * 16;
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + PR <= H && ix0 + PC <= W) {  // interior: uniform base + per-lane constants
+      const float* const org = img + ((long)iy0 * W + ix0) * 16;
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k) yl_glds16(org + coff[k], buf + k * 256);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k) {
+        const int iy = iy0 + crow[k], ix = ix0 + cpx[k];
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        yl_glds16(in ? img + ((long)iy0 * W + ix0) * 16 + coff[k] : p.zeros, buf + k * 256);
+      }
+    }
+  };
+  f32x4 ov[NT3];
+  float* o_row = p.out;
+  bool o_valid = false;
+  auto flush_out = [&]() {
+#pragma unroll
+    for (int j = 0; j < NT3; ++j) {
+      const int n = j * 16 + 4 * kq;
+      if (o_valid && n < C3) *reinterpret_cast<f32x4*>(o_row + n) = ov[j];
+    }
+  };
+  int tile = r0 + wave, cur = 0;
+  if (tile < r1) request(tile, patch);
+  while (tile < r1) {
+    const int next = tile + DPP_NW;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this tile's patch has landed
+    flush_out();                                                     // previous tile's outputs, in front of the next request
+    if (next < r1) request(next, patch + (cur ^ 1) * BUF_F);
+    const float* pb = patch + cur * BUF_F + rbase;
+    f32x4 acc[1][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      f32x4 xq[1], wq[NT];
+      xq[0] = *reinterpret_cast<const f32x4*>(pb + ((tap / 3) * RCH + (tap % 3) * 4) * 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wq[nt] = w2l[(tap * NT + nt) * 64 + lane];
+      yl_mma_step<NT, 1>(wq, xq, acc);
+    }
+    f32x4 a3[1][NT3];
+#pragma unroll
+    for (int j = 0; j < NT3; ++j) a3[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 v[1], w3[NT3];
+      v[0] = yl_clamp4(acc[0][nt] + *reinterpret_cast<const f32x4*>(b2l + nt * 16 + 4 * kq), lo, hi);
+#pragma unroll
+      for (int j = 0; j < NT3; ++j) w3[j] = w3l[(nt * NT3 + j) * 64 + lane];
+      yl_mma_step<NT3, 1>(w3, v, a3);
+    }
+    {
+      const int b = tile / tiles_img;
+      const int trem = tile - b * tiles_img;
+      const int tyi = trem / tw, txi = trem - tyi * tw;
+      const size_t lin = ((size_t)b * OH + 2 * tyi + ty) * OW + 8 * txi + tx;
+      o_row = p.out + lin * C3;
+      o_valid = true;
+#pragma unroll
+      for (int j = 0; j < NT3; ++j)
+        ov[j] = yl_clamp4(a3[0][j] + *reinterpret_cast<const f32x4*>(b3l + j * 16 + 4 * kq), lo3, hi3);
+    }
+    tile = next;
+    cur ^= 1;
+  }
+  flush_out();
+}
+
+static size_t s2c_lds_bytes(int nt, int nt3) {
+  return (size_t)(9 * nt + nt * nt3) * 1024 + (size_t)(nt + nt3) * 64 + (size_t)DPP_NW * 2 * 6 * 1024;
+}
+
+bool yl_s2c_supported(int cin, int cout, int c3, int oh, int ow) {
+  return cin == 16 && cout == 48 && c3 > 16 && c3 <= 32 && (c3 & 3) == 0 && (oh & 1) == 0 && (ow & 7) == 0;
+}
+
+// dense 3x3 stride-2 conv (16 -> 48) + chained 1x1 (-> 32).  hipErrorNotSupported: other shapes (yl_conv_mfma_kernel)
+hipError_t yl_launch_conv_s2c(const YlConvP& p, hipStream_t st) {
+  static const int off = getenv("YL_S2C") ? atoi(getenv("YL_S2C")) == 0 : 0;   // developer A/B: YL_S2C=0
+  if (off || !p.w3p || p.k != 3 || p.stride != 2 || p.dw_k || p.C1 > 0 || p.res || p.up || p.in_shift || p.dec_boxes ||
+      p.act == YL_ACT_SILU || p.act3 == YL_ACT_SILU || !yl_s2c_supported(p.Cin, p.N, p.C3, p.OH, p.OW) ||
+      p.OH != (p.H + 2 * p.pad_t - 3) / 2 + 1 || p.OW != (p.W + 2 * p.pad_l - 3) / 2 + 1)
+    return hipErrorNotSupported;
+  const long t = (long)p.B * (p.OH >> 1) * (p.OW >> 3);
+  long nb = YL_NUM_CU;
+  if (nb > (t + DPP_NW - 1) / DPP_NW) nb = (t + DPP_NW - 1) / DPP_NW;
+  if (nb >= 8) nb &= ~7L;
+  hipLaunchKernelGGL((yl_conv_s2c_kernel<3, 2>), dim3((unsigned)nb), dim3(DPP_NW * 64), s2c_lds_bytes(3, 2), st, p);
+  return hipGetLastError();
+}
+
 static size_t dpp_lds_bytes(int kb, int nt1, int nt3) {
   return (size_t)(kb * nt1 + nt1 * nt3) * 1024 + (size_t)(10 * kb * 16 + nt1 * 16 + nt3 * 16) * 4;
 }
@@ -468,7 +632,8 @@ hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st) {
 }
 
 hipError_t yl_dpp_init() {
-  hipError_t e = hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)yl_conv_s2c_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)s2c_lds_bytes(3, 2));
   YlConvP q0{};
 #define YL_DPQ_ATTR(A, B, C) if (e == hipSuccess) e = dpq_go<A, B, C>(q0, nullptr, true);
   YL_DPQ_SHAPES(YL_DPQ_ATTR)

@@ -143,6 +143,8 @@ hipError_t yl_stemblock_init();
 hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st);
 bool yl_dpp_supported(int cin, int cout, int c3, int oh, int ow);
 hipError_t yl_dpp_init();
+// dense 3x3 stride-2 conv (16 -> 48) + chained 1x1 from an LDS-staged patch (yl_dpp.hip)
+hipError_t yl_launch_conv_s2c(const YlConvP& p, hipStream_t st);
 // depthwise 3x3 -> 1x1 expand -> 1x1 project (+residual) as one launch (yl_dpp.hip)
 hipError_t yl_launch_conv_dpq(const YlConvP& p, hipStream_t st);
 bool yl_dpq_supported(int cin, int cmid, int cout, int oh, int ow);
