@@ -193,9 +193,11 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * head outputs of all pyramid levels in one launch each),
  * "fuse_decode" (0/1, default 1: yl_predict decodes inside the head-output convs; the raw level tensors are
  * then NOT materialised unless the model has mask coefficients),
- * "fuse_head" (0/1, default 1: with "fuse_decode" and "batch_levels", a head branch whose shape is instantiated --
- * depthwise 3x3 -> 1x1 trunk of 96 or 64 channels feeding the 1x1 head output -- runs trunk, output conv and decode as
- * ONE launch for all levels; the trunk tensor is never written.  Same detections bit for bit),
+ * "fuse_head" (0/1, default 1: run-time launch fusion of layer pairs whose shapes are instantiated.  With "fuse_decode"
+ * and "batch_levels", a head branch -- depthwise 3x3 -> 1x1 trunk of 96 or 64 channels feeding the 1x1 head output --
+ * runs trunk, output conv and decode as ONE launch for all levels; a depthwise 3x3 -> 1x1 expand layer followed by the
+ * 1x1 project conv that is its only consumer (48 -> 192 -> 48) runs as one launch in every call.  The intermediate
+ * tensors are then never written (yl_read_slot of those slots returns stale data).  Same results bit for bit),
  * "time_split" (0/1, default 0: see yl_last_timing), "pre_norm" (0/1: see yl_preprocess),
  * "reuse_slots" (0/1, default 1: activation tensors share memory by liveness inside one arena per batch chunk;
  * 0 keeps every tensor of the forward pass),
