@@ -406,7 +406,9 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    reps = 7
+    for _ in range(3):                                       # the eager timed path itself, untimed: clocks / caches settle
+        ctx.forward(x, timed=True)
+    reps = 15
     lay = np.median(np.stack([np.asarray(ctx.forward(x, timed=True)[1]) for _ in range(reps)]), axis=0)   # median: a
     # host hiccup between two eager launches must not crown a 30 us layer "dominant kernel"
 
