@@ -1301,6 +1301,10 @@ hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
 // WAVE: 2.25-4x the expansion MFMAs; the workgroup-level halo here costs 1.2x (stride 2) to 1.9x (5x5 stride 1).  Same
 // k orders (input channel blocks ascending; slabs = the projection's k blocks ascending; taps (dy,dx)) and epilogues as
 // the two-launch form: bit-identical results.
+// (Round 3, second half: a wave-autonomous form of the 48 -> 96 -> 48 blocks on an LDS-DMA-staged 6x6 input patch -- the
+// recipe of yl_conv_s2c_kernel, no workgroup barrier, 288 MFMAs per 16 pixels instead of 198 -- was built and was
+// bit-identical: 49.1 us per B = 64 launch against 46.2 us here, and 38.4k against 40.0k images/s on the two-stream
+// headline (118 KB of LDS per CU also keeps the other chunk's kernels off the CU).  Not kept.)
 template <int KBI /*ceil(C1/16)*/, int NT, int DK, int DS, int MT, int RBN /*wave rows*/, int CBN /*wave columns*/>
 __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 3) ? 3 : 2) void yl_ir_kernel(YlConvP p) {
   constexpr int NWV = RBN * CBN, NTH = NWV * 64;                   // waves / threads per workgroup
