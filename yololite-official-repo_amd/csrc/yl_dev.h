@@ -26,9 +26,9 @@ __device__ __forceinline__ f32x4 yl_ld4(const float* p) { return *reinterpret_ca
 // lanes on gfx950 (same 64 FLOP/clk/SIMD peak; measured: removing VALU work shortens MFMA-bound kernels 1:1),
 // so epilogue instruction count is kernel time.  lo = -inf / hi = +inf give the one-sided / identity cases.
 // acc + a * b per component as two v_pk_fma_f32 (IEEE fma per lane and component, the bits of four fmaf calls, half the
-// VALU issue time).  On gfx950 the fp32 MFMA runs on the vector FMA lanes -- SQ counters of the fp32 kernels here show
-// MFMA busy cycles + 4 cycles per VALU instruction adding up to the SIMD's time -- so every VALU instruction saved in
-// a depthwise inner loop is MFMA time gained.
+// VALU issue time).  On gfx950 the fp32 MFMA runs on the vector FMA lanes (its peak is the vector peak), and kernels whose
+// VALU count was cut got faster by about the cut even when MFMA-bound -- so VALU instructions saved in a depthwise inner
+// loop are MFMA time gained.
 __device__ __forceinline__ f32x4 yl_fma4(f32x4 a, f32x4 b, f32x4 acc) {
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
   const f32x2_ lo = __builtin_elementwise_fma((f32x2_){a.x, a.y}, (f32x2_){b.x, b.y}, (f32x2_){acc.x, acc.y});
