@@ -1304,7 +1304,11 @@ hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
 // (Round 3, second half: a wave-autonomous form of the 48 -> 96 -> 48 blocks on an LDS-DMA-staged 6x6 input patch -- the
 // recipe of yl_conv_s2c_kernel, no workgroup barrier, 288 MFMAs per 16 pixels instead of 198 -- was built and was
 // bit-identical: 49.1 us per B = 64 launch against 46.2 us here, and 38.4k against 40.0k images/s on the two-stream
-// headline (118 KB of LDS per CU also keeps the other chunk's kernels off the CU).  Not kept.)
+// headline (118 KB of LDS per CU also keeps the other chunk's kernels off the CU).  Not kept.  Likewise a START-depthwise
+// form of this kernel for edge_n blocks.2.0 (dw5 -> 32->96 -> dw5 s2 -> 96->48 as one launch: the expansion's B fragments
+// computed per halo pixel from 25 x 2 float4 taps read straight from L1/L2, bit-identical, the 157 MB expanded tensor
+// never written): 35.4k against 40.0k images/s -- 300 dependent tap loads per lane and tile at two workgroups per CU;
+// it would need the block input staged in LDS (68 KB per 8x8 tile).  Not kept.)
 template <int KBI /*ceil(C1/16)*/, int NT, int DK, int DS, int MT, int RBN /*wave rows*/, int CBN /*wave columns*/>
 __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 3 && NT <= 3) ? 3 : 2) void yl_ir_kernel(YlConvP p) {
   constexpr int NWV = RBN * CBN, NTH = NWV * 64;                   // waves / threads per workgroup
