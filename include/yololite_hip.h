@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 2
+#define YL_ABI_VERSION 3
 #define YL_MAX_LEVELS 8
 
 typedef struct yl_ctx yl_ctx;
@@ -52,9 +52,15 @@ enum {
   YL_OP_CONV = 1,  /* dense kxk conv (groups=1) on NHWC, optional depthwise prologue, fused
                       bias/act/residual/nearest-upsample-add epilogue, optional head-layout store  */
   YL_OP_DW = 2,    /* stand-alone depthwise kxk conv on NHWC with bias/act                         */
-  YL_OP_STEMBLOCK = 3 /* fused network entry: stem 3x3 s2 (w,b,act) -> dense 3x3 s2 pad 1 (w2,b2,act2, cout c2)
+  YL_OP_STEMBLOCK = 3, /* fused network entry: stem 3x3 s2 (w,b,act) -> dense 3x3 s2 pad 1 (w2,b2,act2, cout c2)
                          -> optional 1x1 (w3,b3,act3, cout c3), NCHW input to NHWC output; the stem's
                          full-resolution activation (the largest tensor of the network) never reaches HBM  */
+  YL_OP_SE = 4     /* squeeze-excite gate of timm's SqueezeExcite (efficientnetv2 `ir_..._se0.25` blocks behind
+                      model_v2.py:94-100): in_slot [B,H,W,cin] -> out_slot [B,1,1,cin],
+                      gate = sigmoid(w2 . act(w . mean_hw(x) + b) + b2); w = conv_reduce [cout][cin][1][1], b [cout],
+                      w2 = conv_expand [cin][cout][1][1], b2 [cin] (cout = the reduced width, c2 must equal cin).
+                      The spatial mean is a fixed-order two-pass sum (no floating-point atomics: bitwise repeatable).
+                      The gate multiplies the INPUT of the conv that names it in `scale_slot`.                     */
 };
 
 /*
@@ -98,6 +104,10 @@ typedef struct {
   const float* b2;
   const float* w3;
   const float* b3;
+  int32_t scale_slot;         /* YL_OP_CONV, 1x1 stride 1, no depthwise prologue: slot [B,1,1,cin] (a YL_OP_SE output) whose
+                                 values multiply the conv's input per image and input channel before the GEMM
+                                 (x * gate, then conv_pwl: timm InvertedResidual.forward); -1 = none                 */
+  int32_t reserved0;          /* 0                                                                                */
 } yl_layer;
 
 /*
@@ -211,6 +221,22 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * (scripts/helpers/evaluate.py:399,415).  NOT the parity path: results differ from fp32 at the 1e-2
  * relative level.) */
 yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
+/* Current value of an option (the library's default if it was never written; values are stored clamped to the
+ * option's range, e.g. "streams" 1..4).  YL_ERR_INVALID for an unknown name.  Also "dev_select" (default 0): a word of
+ * DEVELOPER kernel-selection switches for A/B runs and the bitwise kernel-equivalence tests -- per context, carried
+ * with every launch; never needed in production (bit 0: stand-alone depthwise through the one-output-per-lane kernel,
+ * 1: no weight-streaming 1x1 kernel, 2: no staged-patch 3x3 s2 kernel, 3: producer/consumer depthwise kernel on every
+ * shape it supports (with "tile_m" 7), 4: no wave-autonomous depthwise kernel, 5-6: streamed depthwise->1x1 kernel
+ * variant (0 default, 1 one n-group per item, 2 off), 7-8: streamed dense 3x3 waves per workgroup (0 auto, 1 four,
+ * 2 eight, 3 off for 4-n-tile layers), 9: two m-tiles per wave in its 4-wave form).                                */
+yl_status yl_get_option(const yl_ctx* ctx, const char* name, int32_t* value);
+/* Host-side query, no device needed: would yl_create accept a fused inverted-residual block (yl_layer with c2 > 0:
+ * 1x1 expand c_in -> c_mid, depthwise dw_k x dw_k stride dw_stride, 1x1 project c_mid -> c_out) producing an
+ * out_h x out_w tensor?  Returns 1 (workgroup-level-halo kernel yl_ir_kernel), 2 (per-wave kernel yl_uib_kernel:
+ * stride 1, in/out grids multiples of 4) or 0 (not instantiated: emit the block as separate layers).  The host
+ * "compiler" (program.py) asks this instead of mirroring the kernels' shape tables.                                */
+int32_t yl_query_fused_block(int32_t c_in, int32_t c_mid, int32_t c_out, int32_t dw_k, int32_t dw_stride, int32_t out_h,
+                             int32_t out_w);
 
 /* ---- pre-processing ----------------------------------------------------------------------------
  * Replaces letterbox() + cv2.cvtColor + /255 + (x-mean)/std + transpose of tools/infer.py:121-131,446-453
@@ -235,6 +261,12 @@ yl_status yl_preprocess(yl_ctx* ctx, const uint8_t* packed_u8_dev, const yl_pre_
  * xyxy pixels clamped to [0,S-1], obj [B,N,1] logits, cls [B,N,C] logits; N = sum A_l*S_l^2.        */
 yl_status yl_decode(yl_ctx* ctx, const float* const* levels_dev, int32_t batch, int32_t center_mode,
                     int32_t wh_mode, float* box_dev, float* obj_dev, float* cls_dev, void* stream);
+
+/* Forward + decode in ONE call: the exported "decoded" wire format of the reference (export/export_onnx.py:283-296:
+ * boxes_xyxy [B,N,4], obj_logits [B,N,1], cls_logits [B,N,C]) straight from the network input; the raw level tensors
+ * stay in the context's own buffers (not handed out).  Same arithmetic as yl_forward followed by yl_decode.       */
+yl_status yl_forward_decoded(yl_ctx* ctx, const float* x_dev, int32_t batch, int32_t center_mode, int32_t wh_mode,
+                             float* box_dev, float* obj_dev, float* cls_dev, void* stream);
 
 /* ---- post-processing --------------------------------------------------------------------------
  * Replaces the score/threshold/per-class-NMS/(top-k)/(back-map) code of tools/infer.py:460-516

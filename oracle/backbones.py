@@ -11,10 +11,14 @@ restatement of timm's published model definitions FROM RECOLLECTION:
 
 * ``mobilenetv4_conv_small`` / ``mobilenetv4_conv_small_050``  (timm ``_gen_mobilenet_v4``)
 * ``tf_efficientnet_lite0..4``                                 (timm ``_gen_efficientnet_lite``)
+* ``tf_efficientnetv2_b0..b3``                                 (timm ``_gen_efficientnetv2_base``: ConvBnAct stage,
+  fused-MBConv ``er`` = EdgeResidual, MBConv ``ir`` with SqueezeExcite, SiLU, TF-SAME padding, BN eps 1e-3,
+  channel rounding with round_limit 0) -- the backbones of /root/reference/configs/v2_models/yololite_{n,s,m}.yaml
 
 PARITY UNPINNED: no reference test or golden vector covers the backbone.  The only
-checksum is the published parameter count of edge_n (0.553 M,
-/root/reference/BENCHMARK.md:353) which this restatement reproduces (0.5524 M at C=3).
+checksums are the published parameter counts (/root/reference/BENCHMARK.md:353-357): edge_n 0.553 M (this
+restatement: 0.5524 M at C=3), edge_m 2.950 M (2.949 M), and for the efficientnetv2 family yololite_n 8.923 M
+and yololite_m 17.916 M (tests/test_oracle_golden.py::test_param_checksums_of_the_published_models).
 
 Module/parameter names follow timm's state_dict layout (``conv_stem``, ``bn1``,
 ``blocks.<stage>.<idx>.<conv|bn1|dw_start.conv|...>``) so that reference checkpoints
@@ -40,10 +44,10 @@ def make_divisible(v: float, divisor: int = 8, min_value: Optional[int] = None,
     return new_v
 
 
-def round_channels(ch: int, multiplier: float = 1.0, divisor: int = 8) -> int:
+def round_channels(ch: int, multiplier: float = 1.0, divisor: int = 8, round_limit: float = 0.9) -> int:
     if not multiplier:
         return ch
-    return make_divisible(ch * multiplier, divisor)
+    return make_divisible(ch * multiplier, divisor, round_limit=round_limit)
 
 
 def _act(name: str) -> nn.Module:
@@ -92,14 +96,44 @@ def _conv(cin, cout, k, s, groups=1, same=False):
 
 
 # ----------------------------------------------------------------------------- blocks
-class ConvBnAct(nn.Module):                      # timm 'cn'
-    def __init__(self, cin, cout, k, s, act, eps, same):
+class ConvBnAct(nn.Module):                      # timm 'cn' (``_skip``: residual when shapes allow, efficientnetv2 stage 0)
+    def __init__(self, cin, cout, k, s, act, eps, same, skip=False):
         super().__init__()
+        self.has_skip = bool(skip) and s == 1 and cin == cout
         self.conv = _conv(cin, cout, k, s, same=same)
         self.bn1 = BatchNormAct2d(cout, eps, act)
 
     def forward(self, x):
-        return self.bn1(self.conv(x))
+        y = self.bn1(self.conv(x))
+        return x + y if self.has_skip else y
+
+
+class SqueezeExcite(nn.Module):                  # timm efficientnet SqueezeExcite (act = the block's act, gate = sigmoid)
+    def __init__(self, ch, rd, act):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(ch, rd, 1, bias=True)
+        self.act1 = _act(act)
+        self.conv_expand = nn.Conv2d(rd, ch, 1, bias=True)
+
+    def forward(self, x):
+        g = x.mean((2, 3), keepdim=True)
+        g = self.conv_expand(self.act1(self.conv_reduce(g)))
+        return x * torch.sigmoid(g)
+
+
+class EdgeResidual(nn.Module):                   # timm 'er' (fused MBConv): k x k expand (strided) -> 1x1 project
+    def __init__(self, cin, cout, k, s, exp_ratio, act, eps, same):
+        super().__init__()
+        self.has_skip = (cin == cout and s == 1)
+        mid = make_divisible(cin * exp_ratio, 8)
+        self.conv_exp = _conv(cin, mid, k, s, same=same)
+        self.bn1 = BatchNormAct2d(mid, eps, act)
+        self.conv_pwl = _conv(mid, cout, 1, 1, same=same)
+        self.bn2 = BatchNormAct2d(cout, eps, "none")
+
+    def forward(self, x):
+        y = self.bn2(self.conv_pwl(self.bn1(self.conv_exp(x))))
+        return x + y if self.has_skip else y
 
 
 class _ConvNorm(nn.Module):                      # timm ConvNormAct used inside UIB
@@ -148,8 +182,14 @@ class DepthwiseSeparableConv(nn.Module):         # timm 'ds'
         return x + y if self.has_skip else y
 
 
-class InvertedResidual(nn.Module):               # timm 'ir'
-    def __init__(self, cin, cout, k, s, exp_ratio, act, eps, same):
+def se_channels(mid: int, se_ratio: float, exp_ratio: float) -> int:
+    """timm EfficientNetBuilder (se_from_exp=False): the ratio refers to the block INPUT, so it is divided by the
+    expansion ratio before SqueezeExcite applies it to the expanded width; rd_round_fn = python round()."""
+    return int(round(mid * (se_ratio / exp_ratio)))
+
+
+class InvertedResidual(nn.Module):               # timm 'ir' (+ SqueezeExcite between the depthwise conv and the projection)
+    def __init__(self, cin, cout, k, s, exp_ratio, act, eps, same, se_ratio=0.0):
         super().__init__()
         self.has_skip = (cin == cout and s == 1)
         mid = make_divisible(cin * exp_ratio, 8)
@@ -157,11 +197,12 @@ class InvertedResidual(nn.Module):               # timm 'ir'
         self.bn1 = BatchNormAct2d(mid, eps, act)
         self.conv_dw = _conv(mid, mid, k, s, groups=mid, same=same)
         self.bn2 = BatchNormAct2d(mid, eps, act)
+        self.se = SqueezeExcite(mid, se_channels(mid, se_ratio, exp_ratio), act) if se_ratio else nn.Identity()
         self.conv_pwl = _conv(mid, cout, 1, 1, same=same)
         self.bn3 = BatchNormAct2d(cout, eps, "none")
 
     def forward(self, x):
-        y = self.bn3(self.conv_pwl(self.bn2(self.conv_dw(self.bn1(self.conv_pw(x))))))
+        y = self.bn3(self.conv_pwl(self.se(self.bn2(self.conv_dw(self.bn1(self.conv_pw(x)))))))
         return x + y if self.has_skip else y
 
 
@@ -169,10 +210,15 @@ class InvertedResidual(nn.Module):               # timm 'ir'
 def _parse(block: str) -> dict:
     """'uir_r4_a0_k3_s1_e2_c96' -> {'type':'uir','r':4,'a':0,'k':3,'s':1,'e':2.0,'c':96}"""
     parts = block.split("_")
-    d = {"type": parts[0], "r": 1, "e": 1.0}
+    d = {"type": parts[0], "r": 1, "e": 1.0, "a": 0, "skip": False, "se": 0.0}
     for p in parts[1:]:
-        key, val = p[0], p[1:]
-        d[key] = float(val) if key == "e" else int(val)
+        if p == "skip":
+            d["skip"] = True
+        elif p.startswith("se"):
+            d["se"] = float(p[2:])
+        else:
+            key, val = p[0], p[1:]
+            d[key] = float(val) if key == "e" else int(val)
     return d
 
 
@@ -195,6 +241,25 @@ EFFNET_LITE = [
     ["ir_r1_k3_s1_e6_c320"],
 ]
 
+EFFNETV2_BASE = [
+    ["cn_r1_k3_s1_e1_c16_skip"],
+    ["er_r2_k3_s2_e4_c32"],
+    ["er_r2_k3_s2_e4_c48"],
+    ["ir_r3_k3_s2_e4_c96_se0.25"],
+    ["ir_r5_k3_s1_e6_c112_se0.25"],
+    ["ir_r8_k3_s2_e6_c192_se0.25"],
+]
+
+# tiny efficientnetv2-style net (NOT a timm model): ConvBnAct with skip, fused MBConv (strided + residual), MBConv + SE
+ORACLE_TINY_V2 = [
+    ["cn_r2_k3_s1_e1_c8_skip"],
+    ["er_r2_k3_s2_e2_c12"],
+    ["er_r1_k3_s2_e4_c16"],
+    ["ir_r2_k3_s2_e4_c24_se0.25"],
+    ["ir_r2_k3_s1_e3_c24_se0.25"],
+    ["ir_r2_k3_s2_e4_c32_se0.25"],
+]
+
 # Tiny MobileNetV4-style net exercising every block flavour (cn k3/k1, uir with dw_start only,
 # dw_mid only, both, strided, residual).  NOT a timm model: it exists so that fixtures which
 # carry a full state_dict stay a few tens of KB (tests/golden/make_fixtures.py).
@@ -206,8 +271,14 @@ ORACLE_TINY = [
     ["cn_r1_k1_s1_e1_c32"],
 ]
 
-# name -> (arch, channel multiplier, depth multiplier, act, bn eps, tf-same padding, fix first/last depth, stem)
+# name -> (arch, channel multiplier, depth multiplier, act, bn eps, tf-same padding, fix first/last depth, stem
+#          [, round_limit of the channel rounding: 0.9 default, 0.0 for efficientnetv2_base])
 _ZOO = {
+    "tf_efficientnetv2_b0":       (EFFNETV2_BASE, 1.0, 1.0, "silu", 1e-3, True, False, 32, 0.0),
+    "tf_efficientnetv2_b1":       (EFFNETV2_BASE, 1.0, 1.1, "silu", 1e-3, True, False, 32, 0.0),
+    "tf_efficientnetv2_b2":       (EFFNETV2_BASE, 1.1, 1.2, "silu", 1e-3, True, False, 32, 0.0),
+    "tf_efficientnetv2_b3":       (EFFNETV2_BASE, 1.2, 1.4, "silu", 1e-3, True, False, 32, 0.0),
+    "oracle_tiny_v2":             (ORACLE_TINY_V2, 1.0, 1.0, "silu", 1e-3, True, False, 16, 0.0),
     "mobilenetv4_conv_small":     (MNV4_CONV_SMALL, 1.0, 1.0, "relu", 1e-5, False, False, 32),
     "mobilenetv4_conv_small_050": (MNV4_CONV_SMALL, 0.5, 1.0, "relu", 1e-5, False, False, 32),
     "tf_efficientnet_lite0":      (EFFNET_LITE, 1.0, 1.0, "relu6", 1e-3, True, True, 32),
@@ -225,7 +296,8 @@ class FeatureBackbone(nn.Module):
 
     def __init__(self, name: str, out_indices: Optional[Sequence[int]] = None):
         super().__init__()
-        arch, cmult, dmult, act, eps, same, fix_fl, stem = _ZOO[name]   # timm keeps the stem at 32
+        arch, cmult, dmult, act, eps, same, fix_fl, stem = _ZOO[name][:8]   # timm keeps the stem at 32
+        rlim = _ZOO[name][8] if len(_ZOO[name]) > 8 else 0.9
         self.conv_stem = _conv(3, stem, 3, 2, same=same)
         self.bn1 = BatchNormAct2d(stem, eps, act)
 
@@ -243,17 +315,19 @@ class FeatureBackbone(nn.Module):
                 rep = d["r"]
                 if dmult != 1.0 and not (fix_fl and si in (0, n_stage - 1)):
                     rep = int(math.ceil(rep * dmult))
-                cout = round_channels(d["c"], cmult)
+                cout = round_channels(d["c"], cmult, round_limit=rlim)
                 for r in range(rep):
                     s = d["s"] if r == 0 else 1
                     if d["type"] == "cn":
-                        blk = ConvBnAct(cin, cout, d["k"], s, act, eps, same)
+                        blk = ConvBnAct(cin, cout, d["k"], s, act, eps, same, skip=d["skip"])
+                    elif d["type"] == "er":
+                        blk = EdgeResidual(cin, cout, d["k"], s, d["e"], act, eps, same)
                     elif d["type"] == "uir":
                         blk = UniversalInvertedResidual(cin, cout, d["a"], d["k"], s, d["e"], act, eps, same)
                     elif d["type"] == "ds":
                         blk = DepthwiseSeparableConv(cin, cout, d["k"], s, act, eps, same)
                     elif d["type"] == "ir":
-                        blk = InvertedResidual(cin, cout, d["k"], s, d["e"], act, eps, same)
+                        blk = InvertedResidual(cin, cout, d["k"], s, d["e"], act, eps, same, se_ratio=d["se"])
                     else:
                         raise ValueError(bstr)
                     red *= s

@@ -232,6 +232,13 @@ MODEL_ZOO = {
                    width_multiple=0.85, fpn_channels=288, head_depth=2),
     "yololite_m": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite2", depth_multiple=1.0,
                        width_multiple=1.0, fpn_channels=328, head_depth=2),
+    # /root/reference/configs/v2_models/yololite_{n,s,m}.yaml (tf_efficientnetv2_b0 / b1 / b2)
+    "yololite_n_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b0", depth_multiple=1.0,
+                          width_multiple=1.0, fpn_channels=196, head_depth=1),
+    "yololite_s_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b1", depth_multiple=1.0,
+                          width_multiple=1.0, fpn_channels=256, head_depth=2),
+    "yololite_m_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b2", depth_multiple=1.0,
+                          width_multiple=1.0, fpn_channels=328, head_depth=2),
 }
 
 

@@ -44,15 +44,14 @@ def _rows(dets, counts, b):
 
 
 def _assert_boxes_equal_after_rounding(got, exp):
-    """north_star: box coordinates equal after integer rounding.  A coordinate whose fraction sits within 2e-3 of
-    .5 may round either way under the ~1e-5 px fp32 drift of two different summation orders: for those (and only
-    those) the raw values must agree to 1e-3 px instead."""
+    """north_star: box coordinates equal after integer rounding.  The only waiver: a coordinate that rounds differently
+    while the RAW values agree to 1e-4 px (the value sits on a .5 boundary inside the fp32 drift of two summation
+    orders) -- anything else is a failure."""
     got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
     assert got.shape == exp.shape
     bad = np.rint(got) != np.rint(exp)
     if bad.any():
-        frac = np.abs(exp[bad] - np.floor(exp[bad]) - 0.5)
-        assert (frac < 2e-3).all() and (np.abs(got[bad] - exp[bad]) < 1e-3).all(), (got[bad], exp[bad])
+        assert (np.abs(got[bad] - exp[bad]) < 1e-4).all(), (got[bad], exp[bad])
     np.testing.assert_allclose(got, exp, rtol=0, atol=1e-3)
 
 
@@ -76,28 +75,74 @@ def _safe_images(scores, boxes_unused, conf, cand, need=3):
     return ok[:need]
 
 
-def _assert_all_safe_images(dets, counts, exp, ref_scores, conf, images, min_safe, exp_index=None):
+def _iou64(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    iw = max(min(a[2], b[2]) - max(a[0], b[0]), 0.0)
+    ih = max(min(a[3], b[3]) - max(a[1], b[1]), 0.0)
+    inter = iw * ih
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
+
+
+def _assert_first_divergence_is_a_threshold_flip(got, exp_b, exp_s, exp_c, iou_thr, band=1e-5):
+    """Two detection lists of ONE image (class ascending, score descending inside a class) that are not equal: locate
+    the FIRST position where they differ.  Every kept box of that class with a higher score is then common to both
+    lists, so the divergent detection D (present in one list, absent from the other) was decided by its largest IoU
+    with those common boxes -- which must sit within `band` of the NMS threshold (one side computed > thr, the other
+    <= thr inside the fp32 drift).  Anything else is a real disagreement."""
+    gb, gs, gc = got
+    n = min(len(gc), len(exp_c))
+    same = lambda j: int(gc[j]) == int(exp_c[j]) and abs(float(gs[j]) - float(exp_s[j])) <= 1e-4 and \
+        np.abs(gb[j] - exp_b[j]).max() <= 1e-3
+    j = next((k for k in range(n) if not same(k)), n)
+    assert j < max(len(gc), len(exp_c)), "lists are equal"
+    cand = []                                       # (class, -score, box) of the entries at position j of both lists
+    if j < len(gc):
+        cand.append((int(gc[j]), -float(gs[j]), gb[j], "hip"))
+    if j < len(exp_c):
+        cand.append((int(exp_c[j]), -float(exp_s[j]), exp_b[j], "oracle"))
+    cls, _, dbox, side = min(cand, key=lambda t: (t[0], t[1]))           # the one that sorts first is the extra detection
+    # common kept boxes of that class in front of position j
+    common = [exp_b[k] for k in range(j) if int(exp_c[k]) == cls]
+    assert common, ("first divergence has no earlier kept box of its class to be suppressed by", j, cls, side)
+    top = max(_iou64(dbox, k) for k in common)
+    assert abs(top - iou_thr) <= band, (f"first differing detection (position {j}, class {cls}, extra on the {side} side): "
+                                        f"deciding IoU {top:.7f} is not within {band} of the threshold {iou_thr}")
+    return j, cls, top
+
+
+def _assert_all_safe_images(dets, counts, exp, ref_scores, conf, images, min_safe_frac=0.9, exp_index=None, iou_thr=0.5,
+                            what=""):
     """north_star on EVERY threshold-safe image of `images` (exp lists are indexed by position unless exp_index maps
-    image -> position).  One image may deviate in its detection LIST (an NMS pair whose IoU sits within the fp32 drift
-    of the threshold flips the greedy walk; conf-threshold flips are excluded by the safety margin) -- it must still
-    agree in count to +-2; every other safe image is held to class ids, 1e-4 scores and rounded boxes."""
+    image -> position).  Safe = every candidate score keeps > 2e-5 from `conf` (no threshold decision inside the fp32
+    drift of the forward pass); at least `min_safe_frac` of the images must be safe.  Every safe image is held to class
+    ids, 1e-4 scores and rounded boxes -- except that at most ONE image may differ in its detection list, and only if
+    the first differing detection is PROVEN to be an NMS decision on the threshold (its deciding IoU within 1e-5 of
+    iou_thr, _assert_first_divergence_is_a_threshold_flip) with the counts within +-2.  Prints how many images were
+    held to the bar."""
+    images = list(images)
     safe = [b for b in images if float((ref_scores[b if exp_index is None else exp_index[b]] - conf).abs().min()) > 2e-5]
-    assert len(safe) >= min_safe, (len(safe), min_safe)
     odd = []
     for b in safe:
         i = b if exp_index is None else exp_index[b]
         gb, gs, gc = _rows(dets, counts, b)
         if gc.tolist() != exp["classes"][i].tolist():
             assert abs(len(gc) - len(exp["classes"][i])) <= 2, (b, len(gc), len(exp["classes"][i]))
-            odd.append(b)
+            flip = _assert_first_divergence_is_a_threshold_flip((gb, gs, gc), exp["boxes"][i], exp["scores"][i],
+                                                                exp["classes"][i], iou_thr)
+            odd.append((b, flip))
             continue
         _assert_north_star((gb, gs, gc), exp, i)
+    print(f"[parity {what}] images held to class ids / 1e-4 scores / rounded boxes: {len(safe) - len(odd)} of {len(images)} "
+          f"(threshold-safe {len(safe)}, list differs by a proven IoU-threshold flip: {odd})")
+    assert len(safe) >= min_safe_frac * len(images), (len(safe), len(images))
     assert len(odd) <= 1, odd
-    return [b for b in safe if b not in odd]
+    return [b for b in safe if b not in [o[0] for o in odd]]
 
 
-def test_bench_configuration_edge_n_b64_parity():
-    wl = bench.build_workload("edge_n", 640, 64, seed=1, dev=DEV)
+@pytest.mark.parametrize("seed", [1, 2])
+def test_bench_configuration_edge_n_b64_parity(seed):
+    """seed 1 is the benchmark's weight seed; seed 2 a second model (and input batch) held to the same bar"""
+    wl = bench.build_workload("edge_n", 640, 64, seed=seed, dev=DEV, rank=seed - 1)
     ctx, x, meta, sd = wl["ctx"], wl["x"], wl["meta"], wl["sd"]
     mo = bench.MAX_OUT
     # ---- reference schedule: eager, one stream, per-level launches, decode kernel
@@ -131,18 +176,20 @@ def test_bench_configuration_edge_n_b64_parity():
         ref_lv = orc(x.cpu())
     ref_s = _score_tensor(ref_lv)
     exp = opost.pipeline_main(ref_lv, 640, 0.4, 0.5, 300)
-    _assert_all_safe_images(d1, c1, exp, ref_s, 0.4, range(64), min_safe=32)
+    _assert_all_safe_images(d1, c1, exp, ref_s, 0.4, range(64), what=f"edge_n B=64 seed {seed}")
     # raw head tensors: decoded scores within the 1e-4 bar everywhere (not only on survivors), all 64 images
     lv = wl["model"](x)
     got_s = _score_tensor([t.cpu() for t in lv])
     assert float((got_s - ref_s).abs().max()) <= 1e-4
 
 
-@pytest.mark.parametrize("name,seg", [("yololite_m", False), ("edge_m", True)])
-def test_full_size_configs_3_and_4(name, seg):
-    """BASELINE configs 3 / 4 at 640x640 B=32: bitwise determinism and batch invariance of the raw levels, the
-    bench schedule against the eager one, sampled images against the oracle (detections; masks for config 4)."""
-    wl = bench.build_workload(name, 640, 32, seed=1, seg=seg, dev=DEV)
+@pytest.mark.parametrize("name,seg,seed", [("yololite_m", False, 1), ("edge_m", True, 1), ("yololite_m", False, 2),
+                                           ("edge_m", True, 2), ("yololite_m_v2", False, 1)])
+def test_full_size_configs_3_and_4(name, seg, seed):
+    """BASELINE configs 3 / 4 at 640x640 B=32 (two weight seeds each; plus the published efficientnetv2 yololite_m):
+    bitwise determinism and batch invariance of the raw levels, the bench schedule against the eager one, ALL 32 images
+    against the oracle (detections; masks of two images for config 4)."""
+    wl = bench.build_workload(name, 640, 32, seed=seed, seg=seg, dev=DEV, rank=seed - 1)
     ctx, x, meta, sd, model = wl["ctx"], wl["x"], wl["meta"], wl["sd"], wl["model"]
     a = model(x)
     b = model(x)
@@ -169,14 +216,21 @@ def test_full_size_configs_3_and_4(name, seg):
         for bb in range(32):
             assert torch.equal(d1[bb, :cn[bb]], d0[bb, :cn[bb]]), (rep, bb)
     orc = _oracle(meta, sd)
-    cand = [0, 4, 9, 13, 18, 22, 27, 31]                               # the oracle forward costs ~1 s per image here
+    cand = list(range(32))                                             # every image (the oracle forward costs ~1 s each)
+    parts = []
     with torch.no_grad():
-        ref = orc(x[cand].cpu())
-    ref_lv, ref_pr = (ref if seg else (ref, None))
+        for i0_ in range(0, 32, 4):                                    # 4 images at a time: host memory
+            parts.append(orc(x[i0_:i0_ + 4].cpu()))
+    if seg:
+        ref_lv = [torch.cat([p[0][l] for p in parts]) for l in range(len(parts[0][0]))]
+        ref_pr = torch.cat([p[1] for p in parts])
+    else:
+        ref_lv, ref_pr = [torch.cat([p[l] for p in parts]) for l in range(len(parts[0]))], None
     det_lv = [t[..., :85] for t in ref_lv]
     exp = opost.pipeline_main(det_lv, 640, 0.4, 0.5, 300)
     pos = {b: i for i, b in enumerate(cand)}
-    safe = _assert_all_safe_images(d1, c1, exp, _score_tensor(det_lv), 0.4, cand, min_safe=3, exp_index=pos)
+    safe = _assert_all_safe_images(d1, c1, exp, _score_tensor(det_lv), 0.4, cand, exp_index=pos,
+                                   what=f"{name}{'+seg' if seg else ''} B=32 seed {seed}")
     sel = [pos[b] for b in safe][:2]
     got_s = _score_tensor([t[cand].cpu() for t in la])
     assert float((got_s - _score_tensor(det_lv)).abs().max()) <= 1e-4

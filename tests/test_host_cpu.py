@@ -83,7 +83,9 @@ def test_program_edge_n_macs_and_layout():
 
 
 @pytest.mark.parametrize("name,feat", [("edge_m", [(80, 80, 64), (40, 40, 96), (20, 20, 960)]),
-                                       ("yololite_m", [(80, 80, 48), (40, 40, 120), (20, 20, 352)])])
+                                       ("yololite_m", [(80, 80, 48), (40, 40, 120), (20, 20, 352)]),
+                                       ("yololite_n_v2", [(80, 80, 48), (40, 40, 112), (20, 20, 192)]),
+                                       ("yololite_m_v2", [(80, 80, 56), (40, 40, 120), (20, 20, 208)])])
 def test_program_other_configs(name, feat):
     meta = zoo_meta(name, 80, 640)
     p = build_program(meta, synth_state_dict(meta))
@@ -94,7 +96,7 @@ def test_program_other_configs(name, feat):
 def test_state_dict_keys_match_oracle_model():
     """Key set / shapes the builder consumes == the reference-compatible module's state_dict."""
     from oracle import model as om
-    for name in ("edge_n", "yololite_m"):
+    for name in ("edge_n", "yololite_m", "yololite_m_v2"):
         meta = zoo_meta(name, 7, 128, use_p6=(name == "edge_n"))
         sd = synth_state_dict(meta)
         m = om.build_from_meta(meta)
@@ -104,6 +106,21 @@ def test_state_dict_keys_match_oracle_model():
             assert tuple(v.shape) == tuple(msd[k].shape), k
         p = build_program(meta, msd)
         assert [k for k in msd if k not in p.known_keys] == []
+
+
+def test_fused_block_query_is_the_librarys_own_table():
+    """program.py used to carry hand-copied mirrors of the kernels' shape tables; it now asks the library
+    (yl_query_fused_block: host-side code of the .so).  Spot values + what the programs built from it look like."""
+    from yololite_amd import _lib
+    q = _lib.load().yl_query_fused_block
+    assert q(48, 96, 48, 3, 1, 40, 40) == 1            # edge_n's 40x40 UIB blocks: workgroup-level-halo kernel
+    assert q(16, 96, 24, 3, 2, 160, 160) == 1          # yololite_m blocks.1.0
+    assert q(64, 256, 64, 5, 1, 20, 20) == 2           # 20x20 grids: the per-wave kernel only (fuse_uib)
+    assert q(48, 96, 48, 3, 1, 41, 41) == 0 and q(48, 96, 48, 7, 1, 40, 40) == 0 and q(0, 96, 48, 3, 1, 40, 40) == 0
+    meta = zoo_meta("edge_n", 80, 640)
+    n_all = len(build_program(meta, synth_state_dict(meta)).layers)
+    n_dw3 = len(build_program(meta, synth_state_dict(meta), fuse_dw="dw3").layers)
+    assert n_dw3 > n_all                                # "dw3": the 5x5 depthwise convs stay separate launches everywhere
 
 
 def test_missing_weight_raises_and_meta_errors():

@@ -177,6 +177,37 @@ def test_param_count_checksum():
     assert abs(n - 2.950e6) < 0.002e6
 
 
+def test_param_checksums_of_the_published_models():
+    """The efficientnetv2 family (configs/v2_models/*.yaml) has TWO reference-held checksums: yololite_n 8.923 M and
+    yololite_m 17.916 M parameters (BENCHMARK.md:356-357, nc = 3 like dataset.yaml:7).  The restated tf_efficientnetv2_b0 /
+    b2 backbones + the reference's neck / heads reproduce both within 0.05 %; the feature-extractor parts alone also
+    reproduce timm's published totals (7.14 / 8.14 / 10.10 / 14.36 M for b0-b3) once the classifier-only conv_head +
+    fc are added back."""
+    from oracle import backbones as ob
+    for name, pub in (("yololite_n_v2", 8.923e6), ("yololite_m_v2", 17.916e6)):
+        n = sum(p.numel() for p in omodel.DetectorOracle(num_classes=3, **omodel.MODEL_ZOO[name]).parameters())
+        assert abs(n - pub) / pub < 5e-4, (name, n)
+    for name, last, feat, pub in (("tf_efficientnetv2_b0", 192, 1280, 7.14e6), ("tf_efficientnetv2_b1", 192, 1280, 8.14e6),
+                                  ("tf_efficientnetv2_b2", 208, 1408, 10.10e6), ("tf_efficientnetv2_b3", 232, 1536, 14.36e6)):
+        m = ob.create_model(name)
+        assert m.feature_info[-1]["num_chs"] == last and [i["reduction"] for i in m.feature_info] == [2, 4, 8, 16, 32]
+        n = sum(p.numel() for p in m.parameters()) + last * feat + 2 * feat + feat * 1000 + 1000
+        assert abs(n - pub) / pub < 1e-3, (name, n)
+
+
+def test_published_macs_of_the_v2_models():
+    """BENCHMARK.md:356-357 publishes 11.473 / 27.239 GMAC for yololite_n / yololite_m (v2).  A thop-style profiler
+    matches module TYPES exactly and therefore skips timm's Conv2dSame (the strided TF-SAME convs: stem, the first
+    fused-MBConv of stages 1 and 2, two strided depthwise convs); conv MACs of this build's program minus those five
+    layers agree with the published figures to 0.3 % (the rest: BatchNorm / activation terms the profiler adds)."""
+    from yololite_amd.program import build_program, synth_state_dict, zoo_meta
+    for name, pub in (("yololite_n_v2", 11.473e9), ("yololite_m_v2", 27.239e9)):
+        meta = zoo_meta(name, 3, 640)
+        p = build_program(meta, synth_state_dict(meta))
+        same = sum(l.macs for l in p.layers if (l.stride == 2 or l.dw_stride == 2) and l.op in (0, 1, 2))
+        assert abs((p.macs - same) - pub) / pub < 3e-3, (name, p.macs, same)
+
+
 def test_preproc_oracle_matches_reference_flow_on_identity_resize(golden_dir):
     """oracle/preproc.py letterbox + normalise equals the reference flow captured in the main() fixture for
     the same-size images (the only resize the cv2 stub allowed); the bilinear path itself is unpinned."""

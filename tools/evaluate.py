@@ -9,7 +9,7 @@ list and are out of scope.
     python tools/evaluate.py --weights W.pt --test_folder D [--img_size S] [--batch_size 8] [--device 0]
 D holds images/ (or the images directly); labels are not needed for this part."""
 import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see bench.py: keep the chunk streams on their own HW queues
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # also the package default (yololite_amd._lib); here before torch is imported
 
 import argparse
 import json

@@ -11,7 +11,7 @@ and letterboxed/normalised on the GPU (yl_preprocess, OpenCV-style fixed-point b
 the annotated *_pred.jpg is not drawn (cosmetics, out of scope), --device cpu is refused (no CPU path).
 Like the reference's main path, --max_det is NOT forwarded to the per-class NMS (cap 300 per class)."""
 import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see bench.py: keep the chunk streams on their own HW queues
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # also the package default (yololite_amd._lib); here before torch is imported
 
 import argparse
 import json

@@ -5,20 +5,51 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
+import warnings
+
+
+def _default_hw_queues():
+    """The executor overlaps two batch chunks on two internal HIP streams.  ROCm maps streams onto
+    GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin at creation; once RCCL (or a host with many
+    torch streams) has created its own streams, a chunk stream can share a hardware queue with the caller's
+    stream, which serialises the chunks and their fork/join barriers (measured: -25 % images/s as soon as
+    init_process_group("nccl") has run).  8 queues avoid the aliasing.  The variable is read when the HIP
+    runtime initialises (first device call), so it is set HERE -- on import of the package, whatever the host
+    program is (bench.py, the CLIs, a serving process) -- unless the user chose a value; if the runtime is
+    already up the default cannot take effect any more and that is said loudly."""
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    t = sys.modules.get("torch")
+    try:
+        late = t is not None and t.cuda.is_initialized()
+    except Exception:   # pragma: no cover
+        late = False
+    if late:
+        warnings.warn("yololite_amd: the HIP runtime was initialised before this package was imported, so "
+                      "GPU_MAX_HW_QUEUES=8 cannot be applied; export it in the environment (multi-stream overlap "
+                      "of the executor degrades by ~25 % next to RCCL streams otherwise)", RuntimeWarning)
+
+
+_default_hw_queues()
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # YOLOLITE_HIP_LIB selects another build of the same ABI (kernel A/B runs); default: the in-tree library
 LIB_PATH = os.environ.get("YOLOLITE_HIP_LIB") or os.path.join(_HERE, "libyololite_hip.so")
 
-YL_ABI_VERSION = 2
+YL_ABI_VERSION = 3
 YL_MAX_LEVELS = 8
 YL_OK = 0
 ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
-OP_STEM, OP_CONV, OP_DW, OP_STEMBLOCK = 0, 1, 2, 3
+OP_STEM, OP_CONV, OP_DW, OP_STEMBLOCK, OP_SE = 0, 1, 2, 3, 4
 POST_MAIN, POST_FALLBACK, POST_EVAL = 0, 1, 2
 CENTER = {"v8": 0, "simple": 1}
 WH = {"softplus": 0, "v8": 1, "exp": 2}
 NMS_TORCHVISION, NMS_GREEDY = 0, 1
+
+# "dev_select" bits (developer A/B, bitwise kernel-equivalence tests; see yl_get_option in the header)
+DEV_DW_TILE_OFF, DEV_PWS_OFF, DEV_S2C_OFF, DEV_DWC_ALL, DEV_DWT_OFF = 1, 2, 4, 8, 16
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -30,7 +61,7 @@ class yl_layer(C.Structure):
         "k", "stride", "pad_t", "pad_l", "act", "in_shift", "dw_k", "dw_stride", "dw_pad_t", "dw_pad_l", "dw_act")] + [
         ("w", _fp), ("b", _fp), ("dw_w", _fp), ("dw_b", _fp),
         ("c2", C.c_int32), ("act2", C.c_int32), ("c3", C.c_int32), ("act3", C.c_int32),
-        ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp)]
+        ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("scale_slot", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class yl_model_desc(C.Structure):
@@ -64,6 +95,9 @@ SYMBOLS = [
     ("yl_activation_bytes", C.c_int64, [_vp]),
     ("yl_read_slot", C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     ("yl_set_option", C.c_int32, [_vp, C.c_char_p, C.c_int32]),
+    ("yl_get_option", C.c_int32, [_vp, C.c_char_p, _ip]),
+    ("yl_query_fused_block", C.c_int32, [C.c_int32] * 7),
+    ("yl_forward_decoded", C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     ("yl_preprocess", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     ("yl_decode", C.c_int32, [_vp, _vpp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     ("yl_postprocess", C.c_int32, [_vp, _vpp, C.c_int32, C.POINTER(yl_post_cfg), _vp, _vp, _vp, _vp]),

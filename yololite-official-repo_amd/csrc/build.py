@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build libyololite_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
-eight translation units (two of them compiled twice: fp32 and bf16-MFMA builds), one shared library with a plain C ABI (include/yololite_hip.h).
+nine translation units (three of them compiled twice: fp32 and bf16-MFMA builds), one shared library with a plain C ABI (include/yololite_hip.h).
 
     python yololite-official-repo_amd/csrc/build.py [--force | --asan]
 """
@@ -19,6 +19,7 @@ UNITS = [   # (source, extra flags, object name)
     ("yl_stemblock.hip", [], "yl_stemblock.o"),
     ("yl_convc.hip", [], "yl_convc.o"),
     ("yl_dpp.hip", [], "yl_dpp.o"),
+    ("yl_se.hip", [], "yl_se.o"),
     ("yl_convc.hip", ["-DYL_BF16=1"], "yl_convc_bf16.o"),
     # bf16-MFMA inference mode: the same two units compiled again under distinct symbol names (yl_dev.h)
     ("yl_conv.hip", ["-DYL_BF16=1"], "yl_conv_bf16.o"),

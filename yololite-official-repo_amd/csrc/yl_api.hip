@@ -57,8 +57,11 @@ struct yl_ctx {
   // B = 64: 3.8 GB with one buffer per tensor -> a few hundred MB, so that a chunk's producer -> consumer pairs have
   // a chance to meet in the 256 MB Infinity Cache instead of HBM.  "reuse_slots" 0 keeps every tensor (debugging).
   char* arena[4] = {nullptr, nullptr, nullptr, nullptr};
+  int arena_capi[4] = {0, 0, 0, 0};        // images arena i is allocated for (a single-chunk call grows arena 0 only)
+  float* se_scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // YL_OP_SE partial sums of a chunk: [capi][se_unit]
+  size_t se_unit = 0;                      // floats per image: max over the SE layers of P * C
   int plan_n = 0;                          // the current job's batch is split into this many chunks
-  int arena_n = 0, arena_cap = 0;          // allocated: arenas, images per arena (capacity; plan_n / plan_cap <= these)
+  int arena_n = 0, arena_cap = 0;          // allocated: arenas, images of the largest one (plan_n / plan_cap <= these)
   int plan_b0[5] = {0, 0, 0, 0, 0};        // chunk i covers images [plan_b0[i], plan_b0[i + 1])
   int plan_cap = 0;                        // images of the largest chunk
   size_t arena_unit = 0;                   // arena bytes per image of a chunk (peak of the live set)
@@ -97,6 +100,7 @@ struct yl_ctx {
                              // NOT bit-identical to the direct convolution: fp32 rounding of the transforms)
   int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
   int opt_fuse_head = 1;     // ... and the head trunk (depthwise 3x3 -> 1x1) in the same launch (yl_conv_dpp_kernel)
+  int opt_dev = 0;    // developer kernel-selection word (YL_DEV_*, "dev_select"); rides in every YlConvP
   int opt_bf16 = 0;   // 1: conv / stem-block launches use the bf16-MFMA builds (fp32 storage, fp32 accumulate)
   // batch chunks run on `opt_streams` internal streams (fork/join around every call): the
   // latency-bound low-resolution layers of one chunk overlap the bandwidth-bound layers of another
@@ -266,7 +270,10 @@ void drop_graph(yl_ctx* c) {
 
 void free_act(yl_ctx* c) {
   drop_graph(c);
-  for (int i = 0; i < 4; ++i) { hipFree(c->arena[i]); c->arena[i] = nullptr; }
+  for (int i = 0; i < 4; ++i) {
+    hipFree(c->arena[i]); c->arena[i] = nullptr; c->arena_capi[i] = 0;
+    hipFree(c->se_scratch[i]); c->se_scratch[i] = nullptr;
+  }
   for (auto& s : c->slots) { hipFree(s.pin); s.pin = nullptr; }
   for (int l = 0; l < YL_MAX_LEVELS; ++l) { hipFree(c->level_buf[l]); c->level_buf[l] = nullptr; }
   c->cap_batch = 0; c->plan_n = 0; c->arena_n = 0; c->arena_cap = 0; c->act_batch = 0;
@@ -282,7 +289,7 @@ size_t layer_group_end(const yl_ctx* c, size_t i, size_t lend) {
     return a.op == YL_OP_CONV && e.op == YL_OP_CONV && a.cin == e.cin && a.cout == e.cout && a.k == e.k &&
            a.stride == e.stride && a.pad_t == e.pad_t && a.pad_l == e.pad_l && a.act == e.act &&
            a.in_shift == e.in_shift && a.dw_k == e.dw_k && a.dw_stride == e.dw_stride && a.dw_pad_t == e.dw_pad_t &&
-           a.dw_pad_l == e.dw_pad_l && a.dw_act == e.dw_act && a.c2 == 0 && e.c2 == 0 && a.res_slot < 0 &&
+           a.dw_pad_l == e.dw_pad_l && a.dw_act == e.dw_act && a.c2 == 0 && e.c2 == 0 && a.scale_slot < 0 && e.scale_slot < 0 && a.res_slot < 0 &&
            e.res_slot < 0 && a.up_slot < 0 && e.up_slot < 0 && (a.head_level >= 0) == (e.head_level >= 0) &&
            (a.cout + 15) / 16 <= 8;
   };
@@ -312,7 +319,9 @@ void plan_slots(yl_ctx* c, bool reuse) {
     // two layers that run_layers may send out as ONE launch (yl_conv_dpq_kernel) are one group: the second layer's
     // output is written while the first layer's inputs are still being read by other tiles, so it must not be placed
     // over them (whatever the options say when the plan is made)
-    if (e == i + 1 && pair_fusable(c, i, NL, true)) e = i + 2;
+    // (also when the first layer of the pair is the LAST member of a level-batched run -- with "batch_levels"
+    // 0 run_layers sees it alone and may fuse it with its successor)
+    if (pair_fusable(c, e - 1, NL, true)) e = e + 1;
     for (size_t q = i; q < e; ++q) grp[q] = g;
     i = e;
   }
@@ -321,8 +330,8 @@ void plan_slots(yl_ctx* c, bool reuse) {
   for (size_t i = 0; i < NL; ++i) {
     const yl_layer& d = c->layers[i].d;
     if (d.head_level < 0 && d.out_slot >= 0 && grp[i] < def[d.out_slot]) def[d.out_slot] = grp[i];
-    const int ins[3] = {(d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? -1 : d.in_slot, d.res_slot, d.up_slot};
-    for (int k = 0; k < 3; ++k)
+    const int ins[4] = {(d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? -1 : d.in_slot, d.res_slot, d.up_slot, d.scale_slot};
+    for (int k = 0; k < 4; ++k)
       if (ins[k] >= 0 && grp[i] > last[ins[k]]) last[ins[k]] = grp[i];
   }
   for (size_t s = 0; s < NS; ++s) {
@@ -389,14 +398,26 @@ yl_status ensure_act(yl_ctx* c, int B, int n) {
   // the batch, so graphs of several batch sizes live side by side in the LRU), and the level buffers / prototypes of
   // the previous batch stay where yl_masks* reads them.  Slot addresses inside an arena scale with plan_cap
   // (slot_addr), i.e. a job's addresses are a function of (B, n) as long as the allocation does not move.
-  if (B > c->cap_batch || n > c->arena_n || cap > c->arena_cap || reuse != c->plan_reuse || c->arena_n == 0) {
+  // Per-arena capacity: a single-chunk call (time_split, per-layer timing) after a two-chunk run grows
+  // arena 0 to the full batch and leaves the others at the chunk size -- not every arena at the full batch.
+  bool grow = B > c->cap_batch || n > c->arena_n || reuse != c->plan_reuse || c->arena_n == 0;
+  for (int i = 0; i < n && !grow; ++i) grow = cap > c->arena_capi[i];
+  if (grow) {
     const int newB = B > c->cap_batch ? B : c->cap_batch, newn = n > c->arena_n ? n : c->arena_n;
-    const int newcap = cap > c->arena_cap ? cap : c->arena_cap;
+    int capi[4], newcap = 0;
+    for (int i = 0; i < 4; ++i) {
+      capi[i] = i < newn ? c->arena_capi[i] : 0;
+      if (i < n && cap > capi[i]) capi[i] = cap;
+      if (capi[i] > newcap) newcap = capi[i];
+    }
     free_act(c);                                             // also drops the cached graphs (addresses change)
     c->plan_reuse = reuse;
     plan_slots(c, reuse);
-    for (int i = 0; i < newn; ++i)
-      if (c->arena_unit) HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)newcap));
+    for (int i = 0; i < newn; ++i) {
+      if (c->arena_unit) HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)capi[i]));
+      if (c->se_unit) HIPCHK(c, hipMalloc((void**)&c->se_scratch[i], c->se_unit * sizeof(float) * (size_t)capi[i]));
+      c->arena_capi[i] = capi[i];
+    }
     for (auto& s : c->slots)
       if (s.pinned) HIPCHK(c, hipMalloc((void**)&s.pin, s.sz * (size_t)newB));
     for (int l = 0; l < c->L; ++l)
@@ -487,6 +508,8 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
     p.N = d.c3 > 0 ? d.c3 : d.c2;
   }
   if (d.res_slot >= 0) p.res = slot_ptr(d.res_slot);
+  if (d.scale_slot >= 0) p.scale = slot_ptr(d.scale_slot);
+  p.dev = (unsigned)c->opt_dev;
   if (d.up_slot >= 0) {
     p.up = slot_ptr(d.up_slot);
     p.UH = c->slots[d.up_slot].h; p.UW = c->slots[d.up_slot].w;
@@ -554,7 +577,8 @@ bool pair_fusable(const yl_ctx* c, size_t i, size_t lend, bool ignore_options) {
       t.res_slot >= 0 || t.up_slot >= 0 || t.in_shift || t.act == YL_ACT_SILU || t.dw_act == YL_ACT_SILU || t.out_slot < 0)
     return false;
   if (o.op != YL_OP_CONV || o.head_level >= 0 || o.k != 1 || o.dw_k > 0 || o.c2 > 0 || o.c3 > 0 || o.in_slot != t.out_slot ||
-      o.cin != t.cout || o.act == YL_ACT_SILU || o.up_slot >= 0 || o.in_shift || o.res_slot == t.out_slot)
+      o.cin != t.cout || o.act == YL_ACT_SILU || o.up_slot >= 0 || o.in_shift || o.res_slot == t.out_slot ||
+      o.scale_slot >= 0 || t.scale_slot >= 0)
     return false;
   if (T.in_h != T.out_h || T.in_w != T.out_w || !yl_dpq_supported(t.cin, t.cout, o.cout, T.out_h, T.out_w)) return false;
   for (size_t r = 0; r < c->layers.size(); ++r) {
@@ -674,8 +698,8 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
     hipStream_t ls = ln ? sd : st;
     if (lanes) {
       bool cross = false;
-      const int ins[3] = {d.in_slot, d.res_slot, d.up_slot};
-      for (int k = 0; k < 3; ++k)
+      const int ins[4] = {d.in_slot, d.res_slot, d.up_slot, d.scale_slot};
+      for (int k = 0; k < 4; ++k)
         if (ins[k] >= 0 && d.op != YL_OP_STEM && d.op != YL_OP_STEMBLOCK && prod[ins[k]] != ln) cross = true;
       if (ln == 1 && !side_used) cross = true;             // first side launch: order after everything enqueued so far
       if (cross) {
@@ -688,6 +712,19 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
     }
     hipError_t e;
     switch (d.op) {
+      case YL_OP_SE: {
+        const DevLayer& L = c->layers[i];
+        YlSeP sp;
+        sp.x = p.x; sp.gate = p.out;
+        sp.w1 = L.wp; sp.b1 = L.bias; sp.w2 = L.w2p; sp.b2 = L.b2;
+        sp.B = B; sp.HW = L.in_h * L.in_w; sp.C = d.cin; sp.RD = d.cout; sp.act = d.act;
+        sp.P = yl_se_parts(sp.HW, sp.C);
+        int ch = 0;                                          // the chunk arena these images live in
+        while (ch + 1 < c->plan_n && b0 >= c->plan_b0[ch + 1]) ++ch;
+        sp.partial = c->se_scratch[ch] + (size_t)(b0 - c->plan_b0[ch]) * c->se_unit;
+        e = yl_launch_se(sp, ls);
+        break;
+      }
       case YL_OP_STEM: e = yl_launch_stem(p, ls); break;
       case YL_OP_CONV: e = c->opt_bf16 ? yl_launch_conv_bf16(p, c->opt_tile_m, ls) : yl_launch_conv(p, c->opt_tile_m, ls); break;
       case YL_OP_STEMBLOCK: e = c->opt_bf16 ? yl_launch_stemblock_bf16(p, ls) : yl_launch_stemblock(p, ls); break;
@@ -742,7 +779,7 @@ void assign_lanes(yl_ctx* c) {
     if (d.head_level < 0 && d.out_slot >= 0)
       for (size_t j = ii + 1; j < n; ++j) {
         const yl_layer& e = c->layers[j].d;
-        if (e.in_slot == d.out_slot || e.res_slot == d.out_slot || e.up_slot == d.out_slot) r |= reach[j];
+        if (e.in_slot == d.out_slot || e.res_slot == d.out_slot || e.up_slot == d.out_slot || e.scale_slot == d.out_slot) r |= reach[j];
       }
     reach[ii] = r;
   }
@@ -908,14 +945,16 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = tru
     return walk_plan(c, j, st, n, segs, nseg, [&](int g, int i, int b0, int bn, hipStream_t ws) -> yl_status {
       return run_piece(c, j, segs[g], b0, bn, ws, i);
     });
-  std::vector<unsigned char> key(sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), 0);
+  std::vector<unsigned char> key(sizeof(Job) + sizeof(yl_post_cfg) + 3 * sizeof(int), 0);
   memcpy(key.data(), &j, sizeof(Job));
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
   const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10) |
                      (c->opt_batch_levels << 11) | (c->opt_hybrid << 12) | (c->opt_nms_groups << 13) |
                      (c->opt_winograd << 17) | (c->opt_fuse_head << 18);
+  const int devkey = c->opt_dev;
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
+  memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), &devkey, sizeof(int));
   // the cfg POINTER is part of Job but not of the identity of the work: blank it in the key
   memset(key.data() + offsetof(Job, cfg), 0, sizeof(void*));
   yl_ctx::GraphEntry* ge = nullptr;
@@ -1078,9 +1117,40 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       snprintf(msg, sizeof(msg), "layer %d: %s", i, what);
       return fail(c, YL_ERR_INVALID, msg);
     };
-    if (l.op < YL_OP_STEM || l.op > YL_OP_STEMBLOCK) return bad("unknown op");
+    if (l.op < YL_OP_STEM || l.op > YL_OP_SE) return bad("unknown op");
     if (!l.w) return bad("weights are NULL");
     if (l.k < 1 || l.stride < 1) return bad("bad kernel geometry");
+    if (l.reserved0 != 0) return bad("reserved0 must be 0");
+    if (l.op == YL_OP_SE) {
+      // squeeze-excite gate: in_slot [H,W,cin] -> out_slot [1,1,cin]; w/b = conv_reduce [cout][cin], w2/b2 = conv_expand [cin][cout]
+      if (l.in_slot < 0 || l.in_slot >= d->num_slots || l.out_slot < 0 || l.out_slot >= d->num_slots) return bad("bad slot");
+      const Slot& si = c->slots[l.in_slot]; const Slot& so = c->slots[l.out_slot];
+      if (si.c != l.cin || so.c != l.cin || so.h != 1 || so.w != 1) return bad("squeeze-excite: out_slot must be [1,1,cin]");
+      if (!l.w2 || !l.b || !l.b2 || l.c2 != l.cin || l.cout < 1 || l.cout > 256 || l.cin > 4096 || (l.cin & 3))
+        return bad("squeeze-excite: needs w [cout][cin], b, w2 [cin][cout], b2, c2 == cin, cout <= 256, cin % 4 == 0 and <= 4096");
+      if (l.k != 1 || l.stride != 1 || l.dw_k || l.c3 || l.res_slot >= 0 || l.up_slot >= 0 || l.scale_slot >= 0 || l.head_level >= 0 ||
+          l.in_shift)
+        return bad("squeeze-excite: plain layer fields only");
+      L.in_h = si.h; L.in_w = si.w; L.out_h = L.out_w = 1;
+      std::vector<float> w1(l.w, l.w + (size_t)l.cout * l.cin), b1(l.b, l.b + l.cout);
+      std::vector<float> w2(l.w2, l.w2 + (size_t)l.cin * l.cout), b2(l.b2, l.b2 + l.cin);
+      yl_status s2;
+      if ((s2 = upload(c, w1, &L.wp)) != YL_OK || (s2 = upload(c, b1, &L.bias)) != YL_OK ||
+          (s2 = upload(c, w2, &L.w2p)) != YL_OK || (s2 = upload(c, b2, &L.b2)) != YL_OK)
+        return s2;
+      const size_t unit = (size_t)yl_se_parts(si.h * si.w, l.cin) * l.cin;
+      if (unit > c->se_unit) c->se_unit = unit;
+      L.d.w = L.d.b = L.d.dw_w = L.d.dw_b = nullptr;
+      L.d.w2 = L.d.b2 = L.d.w3 = L.d.b3 = nullptr;
+      c->layers.push_back(L);
+      continue;
+    }
+    if (l.scale_slot >= 0) {
+      if (l.scale_slot >= d->num_slots || l.op != YL_OP_CONV || l.k != 1 || l.stride != 1 || l.dw_k || l.c2 || l.c3 || l.in_shift)
+        return bad("scale_slot needs a plain 1x1 stride-1 conv");
+      const Slot& g = c->slots[l.scale_slot];
+      if (g.h != 1 || g.w != 1 || g.c != l.cin) return bad("scale_slot must be [1,1,cin]");
+    }
     if (l.op == YL_OP_STEMBLOCK) {
       L.in_h = L.in_w = d->img_size;
       if (l.cin != 3 || l.k != 3) return fail(c, YL_ERR_UNSUPPORTED, "stem must be 3x3 with 3 input channels");
@@ -1271,7 +1341,29 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!strcmp(name, "lanes")) { c->opt_lanes = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "dev_select")) { c->opt_dev = value & 0x3ff; drop_graph(c); return YL_OK; }
   return fail(c, YL_ERR_INVALID, std::string("unknown option ") + name);
+}
+
+yl_status yl_get_option(const yl_ctx* c, const char* name, int32_t* value) {
+  if (!c || !name || !value) return YL_ERR_INVALID;
+  const struct { const char* n; int v; } tab[] = {
+      {"graph", c->opt_graph}, {"mfma_bf16", c->opt_bf16}, {"nms_groups", c->opt_nms_groups}, {"time_split", c->opt_time_split},
+      {"pre_norm", c->opt_pre_norm}, {"reuse_slots", c->opt_reuse}, {"hybrid", c->opt_hybrid}, {"batch_levels", c->opt_batch_levels},
+      {"fuse_decode", c->opt_fuse_decode}, {"fuse_head", c->opt_fuse_head}, {"winograd", c->opt_winograd}, {"lanes", c->opt_lanes},
+      {"tile_m", c->opt_tile_m}, {"streams", c->opt_streams}, {"dev_select", c->opt_dev}};
+  for (const auto& t : tab)
+    if (!strcmp(name, t.n)) { *value = t.v; return YL_OK; }
+  return YL_ERR_INVALID;
+}
+
+int32_t yl_query_fused_block(int32_t c_in, int32_t c_mid, int32_t c_out, int32_t dw_k, int32_t dw_stride, int32_t out_h,
+                             int32_t out_w) {
+  if (c_in < 1 || c_mid < 1 || c_out < 1 || out_h < 1 || out_w < 1) return 0;
+  if (yl_ir_supported(c_in, c_mid, c_out, dw_k, dw_stride, out_h, out_w)) return 1;
+  // per-wave kernel: stride 1 (input grid == output grid), grids multiples of 4 (the checks of yl_create)
+  if (dw_stride == 1 && !(out_h & 3) && !(out_w & 3) && yl_uib_supported(c_in, c_mid, c_out, dw_k)) return 2;
+  return 0;
 }
 
 static yl_status forward_impl(yl_ctx* c, const float* x, int B, float* const* level_out, hipStream_t st,
@@ -1321,7 +1413,8 @@ yl_status yl_last_timing(yl_ctx* c, float* infer_ms, float* post_ms) {
 
 int64_t yl_activation_bytes(const yl_ctx* c) {
   if (!c || c->plan_n < 1) return 0;
-  int64_t t = (int64_t)c->arena_unit * c->arena_cap * c->arena_n;
+  int64_t t = 0;
+  for (int i = 0; i < c->arena_n; ++i) t += (int64_t)(c->arena_unit + c->se_unit * sizeof(float)) * c->arena_capi[i];
   for (const auto& s : c->slots)
     if (s.pinned) t += (int64_t)s.sz * c->cap_batch;
   return t;
@@ -1359,6 +1452,21 @@ yl_status yl_decode(yl_ctx* c, const float* const* levels, int32_t B, int32_t ce
   HIPCHK(c, hipSetDevice(c->device));
   YlLevels lv;
   fill_levels(c, levels, lv);
+  HIPCHK(c, yl_launch_decode_only(lv, B, center_mode, wh_mode, box, obj, cls, (hipStream_t)stream));
+  return YL_OK;
+}
+
+yl_status yl_forward_decoded(yl_ctx* c, const float* x, int32_t B, int32_t center_mode, int32_t wh_mode, float* box,
+                             float* obj, float* cls, void* stream) {
+  if (!c || !box || !obj) return YL_ERR_INVALID;
+  if (c->C > 0 && !cls) return fail(c, YL_ERR_INVALID, "cls_dev is NULL");
+  if (center_mode < 0 || center_mode > 1 || wh_mode < 0 || wh_mode > 2) return fail(c, YL_ERR_INVALID, "bad mode");
+  // the raw levels go to the context's own buffers (two chunk streams, hipGraph: as yl_forward), the decode follows on
+  // the caller's stream behind the join
+  yl_status s = forward_impl(c, x, B, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
+  if (s != YL_OK) return s;
+  YlLevels lv;
+  fill_levels(c, c->level_buf, lv);
   HIPCHK(c, yl_launch_decode_only(lv, B, center_mode, wh_mode, box, obj, cls, (hipStream_t)stream));
   return YL_OK;
 }

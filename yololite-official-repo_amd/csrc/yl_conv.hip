@@ -58,7 +58,8 @@
 #include "yl_decode.h"
 #include "yl_epi.h"
 
-enum { YL_CM_PW = 0, YL_CM_KXK = 1, YL_CM_DWPRO = 2, YL_CM_DW3 = 3, YL_CM_DW5 = 5 };
+enum { YL_CM_PW = 0, YL_CM_KXK = 1, YL_CM_DWPRO = 2, YL_CM_DW3 = 3, YL_CM_DW5 = 5,
+       YL_CM_PWSC = 6 /* 1x1 conv whose input is multiplied by a squeeze-excite gate [B][Cin] (YlConvP::scale) */ };
 
 // ------------------------------------------------------------------------------------------------
 // B-operand fetch: 4 consecutive input channels [c, c+4) of the lane's pixel for tap (ky,kx).
@@ -74,6 +75,9 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
   // loaded registers are first touched by their consumer and the load latency stays hidden
   if (MODE == YL_CM_PW) {
     return yl_ld4(cin_ok ? p.x + px.lin * p.Cin + cs : p.zeros);
+  } else if (MODE == YL_CM_PWSC) {
+    // x * gate first (one fp32 rounding, as timm's `x * self.gate(x_se)`), then the GEMM
+    return yl_ld4(cin_ok ? p.x + px.lin * p.Cin + cs : p.zeros) * yl_ld4(p.scale + (size_t)px.b * p.Cin + cs);
   } else if (MODE == YL_CM_KXK) {
     // p.H/p.W are the dims of the (virtually upsampled) tensor the conv sees; the stored tensor is
     // (H >> in_shift) x (W >> in_shift): nearest-neighbour upsampling folded into the addressing
@@ -447,9 +451,6 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 && MODE <= 1) ? YL_PW_WAVES : 3)
 #ifndef YL_DWH_PREADD
 #define YL_DWH_PREADD 1
 #endif
-#ifndef YL_DWH_EXP
-#define YL_DWH_EXP 0      // timing experiments (variant builds; results WRONG): 1 no stores, 2 no MFMAs, 3 no taps, 4 no halo loads
-#endif
 template <int NT, int DK, int DS>
 __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
   YL_SELECT_PROBLEM(mp)
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
 #if YL_DWH_BUF
       r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
 #else
-      r[j] = yl_ld4((YL_DWH_EXP != 4 && off < OOB) ? p.x + (off >> 2) : p.zeros);
+      r[j] = yl_ld4(off < OOB ? p.x + (off >> 2) : p.zeros);
 #endif
     }
   };
@@ -604,9 +605,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
       const int c = kb * 16 + 4 * kq;
       const int cs = c < p.Cin ? c : p.Cin - 4;
       f32x4 s = yl_ld4(dwl + DK * DK * p.Cin + cs);
-      if (YL_DWH_EXP == 3) {
-        s += *reinterpret_cast<const f32x4*>(halo + rbase);
-      } else if (DK == 3) {
+      if (DK == 3) {
 #pragma unroll
         for (int dy = 0; dy < DK; ++dy)
 #pragma unroll
@@ -635,19 +634,11 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
       f32x4 wq[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
-      if (YL_DWH_EXP == 2) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[0][nt] += wq[nt] * xq[0];
-      } else yl_mma_step<NT, 1>(wq, xq, acc);
+      yl_mma_step<NT, 1>(wq, xq, acc);
       if (more) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // this step's tap reads are complete
         stage_store(stg);
       }
-    }
-    if (YL_DWH_EXP == 1) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(acc[0][nt].x), "v"(acc[0][nt].y), "v"(acc[0][nt].z), "v"(acc[0][nt].w));
-      continue;
     }
     if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, !bias0);
@@ -1062,6 +1053,7 @@ static hipError_t yl_conv_attr_modes() {
   if ((e = yl_conv_attr<NT, MT, YL_CM_KXK>()) != hipSuccess) return e;
   if ((e = yl_conv_attr<NT, MT, YL_CM_DW3>()) != hipSuccess) return e;
   if ((e = yl_conv_attr<NT, MT, YL_CM_DW5>()) != hipSuccess) return e;
+  if ((e = yl_conv_attr<NT, MT, YL_CM_PWSC>()) != hipSuccess) return e;
   return yl_conv_attr<NT, MT, YL_CM_DWPRO>();
 }
 template <int MT>
@@ -1196,6 +1188,7 @@ static int yl_conv_resident(int mode, size_t lds) {
   if (mode == YL_CM_KXK) return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_KXK>, lds);
   if (mode == YL_CM_DW3) return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_DW3>, lds);
   if (mode == YL_CM_DW5) return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_DW5>, lds);
+  if (mode == YL_CM_PWSC) return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_PWSC>, lds);
   return yl_resident_blocks(yl_conv_mfma_kernel<NT, MT, YL_CM_DWPRO>, lds);
 }
 template <int MT>
@@ -1216,6 +1209,7 @@ static void yl_conv_go(const YlConvMulti& m, int mode, dim3 grid, size_t lds, hi
   else if (mode == YL_CM_KXK) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_KXK>), grid, dim3(256), lds, st, m);
   else if (mode == YL_CM_DW3) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DW3>), grid, dim3(256), lds, st, m);
   else if (mode == YL_CM_DW5) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DW5>), grid, dim3(256), lds, st, m);
+  else if (mode == YL_CM_PWSC) hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_PWSC>), grid, dim3(256), lds, st, m);
   else hipLaunchKernelGGL((yl_conv_mfma_kernel<NT, MT, YL_CM_DWPRO>), grid, dim3(256), lds, st, m);
 }
 template <int MT>
@@ -1253,7 +1247,7 @@ static int yl_partition_blocks(YlConvMulti& m, const long* tiles, int gx) {
 hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStream_t st) {
   if (n < 1 || n > 4) return hipErrorInvalidValue;
 #if !YL_BF16
-  if (n == 1 && ps[0].w3p && ps[0].k == 3 && ps[0].stride == 2 && tile_hint != 6) {   // 3x3 s2 + chained 1x1, staged patch
+  if (n == 1 && ps[0].w3p && ps[0].k == 3 && ps[0].stride == 2 && tile_hint != 6 && !(ps[0].dev & YL_DEV_S2C_OFF)) {   // 3x3 s2 + chained 1x1, staged patch
     const hipError_t e = yl_launch_conv_s2c(ps[0], st);
     if (e != hipErrorNotSupported) return e;
   }
@@ -1266,10 +1260,12 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
     if (ps[k].M > ps[big].M) big = k;
     if (ps[k].NTtot != ps[0].NTtot || ps[k].KB != ps[0].KB || ps[k].TK != ps[0].TK || ps[k].dw_k != ps[0].dw_k ||
         ps[k].dw_stride != ps[0].dw_stride || ps[k].k != ps[0].k || ps[k].stride != ps[0].stride ||
-        ps[k].N != ps[0].N || ps[k].Cin != ps[0].Cin || (ps[k].C1 > 0) != (ps[0].C1 > 0))
+        ps[k].N != ps[0].N || ps[k].Cin != ps[0].Cin || (ps[k].C1 > 0) != (ps[0].C1 > 0) ||
+        (ps[k].scale != nullptr) != (ps[0].scale != nullptr))
       return hipErrorInvalidValue;
   }
   const YlConvP& p = m.p[big];                              // decisions follow the largest problem
+  if (p.scale && (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || p.w3p)) return hipErrorInvalidValue;
   const int nts[6] = {1, 2, 3, 4, 6, 8};
   int NT = 8;
   if (p.NTtot <= 8) {
@@ -1397,7 +1393,7 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   else CH = (int)((budget < 48 * 1024 ? budget : 48 * 1024) / step_bytes);   // stream K in chunks
   const size_t lds = (size_t)CH * step_bytes + extra;
   const int mode = p.dw_k == 3 ? YL_CM_DW3 : p.dw_k == 5 ? YL_CM_DW5 : p.dw_k > 0 ? YL_CM_DWPRO
-                   : ((p.k == 1 && p.stride == 1) ? YL_CM_PW : YL_CM_KXK);
+                   : ((p.k == 1 && p.stride == 1) ? (p.scale ? YL_CM_PWSC : YL_CM_PW) : YL_CM_KXK);
   long tiles[4], ttotal = 0;
   for (int k = 0; k < n; ++k) {
     m.p[k].CH = CH;
@@ -1445,7 +1441,7 @@ static hipError_t yl_launch_dw_tile(const YlConvP& p, hipStream_t st) {
 }
 
 hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st) {
-  static const bool tile_off = getenv("YL_DW_TILE") && atoi(getenv("YL_DW_TILE")) == 0;
+  const bool tile_off = (p.dev & YL_DEV_DW_TILE_OFF) != 0;       // developer A/B (yl_set_option "dev_select")
   if (!tile_off && (p.Cin & 3) == 0 && p.N == p.Cin) {
     if (p.k == 3 && p.stride == 1) return yl_launch_dw_tile<3, 1>(p, st);
     if (p.k == 3 && p.stride == 2) return yl_launch_dw_tile<3, 2>(p, st);

@@ -453,11 +453,7 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
   }
   constexpr int UK = 2;
   const int cin4 = Cin - 4;
-#if defined(YL_PWT_EXP) && YL_PWT_EXP >= 2        // timing experiment: no loads / MFMAs (results WRONG)
-  for (int kb0 = 0; kb0 < 0; kb0 += UK) {
-#else
   for (int kb0 = 0; kb0 < KB; kb0 += UK) {
-#endif
     f32x4 a[UK][NTW], bq[UK][MT];
 #pragma unroll
     for (int u = 0; u < UK; ++u) {
@@ -476,23 +472,6 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
   }
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
-#if defined(YL_PWT_EXP) && YL_PWT_EXP == 3        // timing experiment: same bytes, every store instruction 1 KiB contiguous (WRONG layout)
-  {
-    float* o = p.out + ((size_t)mg * MT * 16) * N + (size_t)nt0 * 16 * (MT * 16);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) *reinterpret_cast<f32x4*>(o + ((mt * NTW + nt) * 64 + lane) * 4) = acc[mt][nt];
-    return;
-  }
-#endif
-#if defined(YL_PWT_EXP) && YL_PWT_EXP == 1        // timing experiment: no stores (results WRONG)
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(acc[mt][nt].x), "v"(acc[mt][nt].y), "v"(acc[mt][nt].z), "v"(acc[mt][nt].w));
-  return;
-#endif
   if (DEC) { yl_epi_decode<NTW, MT>(p, acc, px, nt0, kq, lane); return; }   // head output under yl_predict (one wave = whole rows)
   if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NTW, MT>(p, acc, px, nt0, kq);
   else yl_epi_fast<NTW, MT>(p, acc, px, nt0, kq, lo, hi, true);
@@ -523,7 +502,7 @@ hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st) {
   long Mtot = 0;
   for (int k = 0; k < n; ++k) {
     const YlConvP& p = ps[k];
-    if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift) return hipErrorNotSupported;
+    if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || p.scale) return hipErrorNotSupported;
     const bool dec = p.dec_boxes && !p.dec_raw;
     if ((p.N & 3) && !dec) return hipErrorNotSupported;
     if (p.dec_boxes && !dec) return hipErrorNotSupported;
@@ -859,12 +838,9 @@ hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st) {
   //   K=N=96 dw3 80x80:  dwh 143 | 10: 163 | 11: 137 | 20: 147 | 21: 141        K=96 N=48 dw3: dwh 32.9 | 11: 29.2
   //   K=256 N=64 dw5:    dwh 49.7 | 10: 35.1 | 11: 49.3 | 20: 34.9             K=32 N=96 dw5 s2: dwh 76 | 11: 70
   // -> one m-tile per wave (the 4x8 tile needs ~190 VGPRs: 2 waves per SIMD), LDS weight image while it is <= 36 KB.
-  // YL_DWT = "<mt><wl>" forces one configuration on every supported layer (ablation; mt 2 needs -DYL_DWT_MT2),
-  // "0" disables the kernel.
-  static const char* force = getenv("YL_DWT");
-  if (force && force[0] == '0') return hipErrorNotSupported;
+  // ("dev_select" bit 4 disables the kernel: developer A/B)
+  if (p.dev & YL_DEV_DWT_OFF) return hipErrorNotSupported;
   bool two = false, wl = p.KB * p.NTtot <= 36;
-  if (force) { two = force[0] == '2' && p.dw_stride == 1; wl = force[1] == '1'; }
   for (int k = 0; k < m.n; ++k) {
     if ((m.p[k].OH & 3) || (m.p[k].OW & 3)) return hipErrorNotSupported;
     if (m.p[k].OW & 7) two = false;
@@ -1064,8 +1040,9 @@ static hipError_t kxk_go(const YlConvP& p0, int gy, hipStream_t st, bool attr_on
 // so that a weight fragment read feeds 8 MFMAs).  hipErrorNotSupported otherwise (yl_conv_mfma_kernel runs the layer).
 hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
   if (p.k != 3 || p.dw_k > 0 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.w3p) return hipErrorNotSupported;
-  static const int NWsel = getenv("YL_KXK_NW") ? atoi(getenv("YL_KXK_NW")) : 0;
-  static const int MTsel = getenv("YL_KXK_MT") ? atoi(getenv("YL_KXK_MT")) : 1;
+  static const int nwtab[4] = {0, 4, 8, -1};                  // developer A/B ("dev_select" bits 7-9)
+  const int NWsel = nwtab[YL_DEV_KXK_NW(p.dev)];
+  const int MTsel = (p.dev & YL_DEV_KXK_MT2) ? 2 : 1;
   if (p.NTtot == 4) {
     if ((size_t)p.TK * 4 * 1024 <= 96 * 1024 || NWsel < 0) return hipErrorNotSupported;
     return NWsel == 8 ? kxk_go<4, 1, 8>(p, 1, st, false) : kxk_go<4, 2, 4>(p, 1, st, false);
@@ -1249,9 +1226,8 @@ static hipError_t pws_nw(const YlConvP& p, hipStream_t st, bool eight, bool attr
 // plain 1x1 stride-1 layers (N % 4 == 0, no decode epilogue) with enough channels on both sides that the weight
 // stream pays: K >= 80 and >= 6 n-tiles.  hipErrorNotSupported otherwise (yl_conv_pwt_kernel runs the layer).
 hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
-  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || (p.N & 3) || p.dec_boxes) return hipErrorNotSupported;
-  static const int sel = getenv("YL_PWS") ? atoi(getenv("YL_PWS")) : 1;       // 0: off (A/B runs)
-  if (!sel || p.KB < 5 || p.NTtot < 6) return hipErrorNotSupported;
+  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || (p.N & 3) || p.dec_boxes || p.scale) return hipErrorNotSupported;
+  if ((p.dev & YL_DEV_PWS_OFF) || p.KB < 5 || p.NTtot < 6) return hipErrorNotSupported;     // (dev: A/B runs)
   // n-tiles per item, from {6..13}: the makespan of the launch in MFMA units -- (16-pixel x n-group) wave items dealt
   // to 1024 SIMDs, each NT x KB x 4 MFMAs long -- with a penalty when fewer than 1.5 waves per SIMD exist (one wave
   // alone cannot keep a matrix pipe busy); ties go to the larger NT (fewer passes over the activations).  E.g. 1248 ->
@@ -1740,8 +1716,9 @@ static hipError_t dwk_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
 // single problem.  hipErrorNotSupported otherwise (yl_conv_mfma_kernel's streamed mode then runs the layer).
 hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
   if (p.dw_k != 3 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.KB < 12 || p.NTtot <= 8) return hipErrorNotSupported;
-  // YL_DWK: 0 = off, 1 = one n-group per item (depthwise recomputed per group), 2 = a wave holds every n-group
-  static const int sel = getenv("YL_DWK") ? atoi(getenv("YL_DWK")) : 2;
+  // developer A/B ("dev_select" bits 5-6): 2 = off, 1 = one n-group per item (depthwise recomputed per group),
+  // 0 = default: a wave holds every n-group
+  const int sel = YL_DEV_DWK(p.dev) == 2 ? 0 : (YL_DEV_DWK(p.dev) == 1 ? 1 : 2);
   if (sel == 0) return hipErrorNotSupported;
   if (p.NTtot == 21) return sel == 2 ? dwk_go<7, 3, 4>(p, st, false) : dwk_go<7, 1, 4>(p, st, false);
   if (p.NTtot == 16) return sel == 2 ? dwk_go<8, 2, 4>(p, st, false) : dwk_go<8, 1, 4>(p, st, false);
@@ -2037,8 +2014,8 @@ hipError_t yl_launch_conv_dwc(YlConvMulti& m, hipStream_t st) {
   // Measured per layer (edge_n, B = 64, eager): the producer / consumer split pays where the depthwise phase is
   // long -- K >= 192 channels on a stride-1 depthwise (28 vs 38 us for 3x3, 44 vs 50 us for 5x5 at 20x20) -- and
   // loses on the short-K layers, where two or three of the four depthwise waves idle and the per-tile barrier costs
-  // more than the weight prologue it replaces.  YL_DWC_ALL=1 lifts the restriction (A/B runs).
-  const bool all = getenv("YL_DWC_ALL") != nullptr;     // read per launch: tests set it for ONE case (monkeypatch)
+  // more than the weight prologue it replaces.  "dev_select" bit 3 lifts the restriction (A/B runs).
+  const bool all = (p.dev & YL_DEV_DWC_ALL) != 0;       // "dev_select" bit 3: the bitwise-equivalence test
   if (!all && (p.KB < 12 || p.dw_stride != 1)) return hipErrorNotSupported;
   if (!((p.dw_k == 3 || p.dw_k == 5) && (p.dw_stride == 1 || p.dw_stride == 2))) return hipErrorNotSupported;
   const int HP = 3 * p.dw_stride + p.dw_k;

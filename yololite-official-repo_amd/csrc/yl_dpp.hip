@@ -28,9 +28,6 @@
 #ifndef DPP_WPE
 #define DPP_WPE 2                      // waves per SIMD the register budget is set for
 #endif
-#ifndef DPP_EXP
-#define DPP_EXP 0                      // timing experiments (variant builds only, results WRONG): 1 no decode, 2 no tap loads,
-#endif                                 // 3 no depthwise arithmetic, 4 no MFMAs
 
 template <int KB /*Cin/16*/, int NT1 /*trunk n-tiles*/, int NT3 /*head-output n-tiles*/>
 __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlConvMulti mp) {
@@ -116,7 +113,7 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
   f32x4 xa[9], xb[9];                                                // taps of the even / odd blocks
   auto fetch = [&](f32x4 (&dst)[9], int kb) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) dst[tap] = DPP_EXP == 2 ? (f32x4){1.f, 2.f, 3.f, (float)tap} : yl_ld4(tp[tap] + kb * 16);
+    for (int tap = 0; tap < 9; ++tap) dst[tap] = yl_ld4(tp[tap] + kb * 16);
   };
   int tile = r0 + wave;
   if (tile < r1) { setup(tile); fetch(xa, 0); }
@@ -130,7 +127,7 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
     auto dwise = [&](const f32x4 (&xt)[9], int kb) {
       f32x4 q = *reinterpret_cast<const f32x4*>(tapw + 9 * Cin + kb * 16);
 #pragma unroll
-      for (int tap = 0; tap < (DPP_EXP == 3 ? 1 : 9); ++tap)
+      for (int tap = 0; tap < 9; ++tap)
         q = yl_fma4(xt[tap], *reinterpret_cast<const f32x4*>(tapw + tap * Cin + kb * 16), q);
       return yl_clamp4(q, dlo, dhi);                          // ReLU family only (SiLU is refused at launch): no branch in the region
     };
@@ -148,12 +145,7 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
         xn = dwise(xnext, kb + 1);
         if (kb + 3 < KB) fetch(xnext, kb + 3);
       }
-      if (DPP_EXP == 4) {
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) acc1[0][nt] += wq[nt] * xq[0];
-      } else {
-        yl_mma_step<NT1, 1>(wq, xq, acc1);
-      }
+      yl_mma_step<NT1, 1>(wq, xq, acc1);
       xq[0] = xn;
       asm volatile("" ::: "memory");
     };
@@ -175,25 +167,13 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
       f32x4 wq[NT3];
 #pragma unroll
       for (int nt = 0; nt < NT3; ++nt) wq[nt] = w3l[(kb * NT3 + nt) * 64 + lane];
-      if (DPP_EXP == 4) {
-#pragma unroll
-        for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += wq[nt] * hq[0];
-      } else {
-        yl_mma_step<NT3, 1>(wq, hq, acc3);
-      }
+      yl_mma_step<NT3, 1>(wq, hq, acc3);
       asm volatile("" ::: "memory");
     }
     const YlPix pxd[1] = {pxc};
-    if (DPP_EXP == 1) {
-      f32x4 t = acc3[0][0];
 #pragma unroll
-      for (int nt = 1; nt < NT3; ++nt) t += acc3[0][nt];
-      if (t.x == 1234.5f) p.dec_scores[pxd[0].lin] = t.y + t.z + t.w;
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += *reinterpret_cast<const f32x4*>(b3l + nt * 16 + 4 * kq);
-      yl_epi_decode<NT3, 1, true>(p, acc3, pxd, 0, kq, lane);
-    }
+    for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += *reinterpret_cast<const f32x4*>(b3l + nt * 16 + 4 * kq);
+    yl_epi_decode<NT3, 1, true>(p, acc3, pxd, 0, kq, lane);
     tile = next;
   }
 }
@@ -556,8 +536,7 @@ bool yl_s2c_supported(int cin, int cout, int c3, int oh, int ow) {
 
 // dense 3x3 stride-2 conv (16 -> 48) + chained 1x1 (-> 32).  hipErrorNotSupported: other shapes (yl_conv_mfma_kernel)
 hipError_t yl_launch_conv_s2c(const YlConvP& p, hipStream_t st) {
-  static const int off = getenv("YL_S2C") ? atoi(getenv("YL_S2C")) == 0 : 0;   // developer A/B: YL_S2C=0
-  if (off || !p.w3p || p.k != 3 || p.stride != 2 || p.dw_k || p.C1 > 0 || p.res || p.up || p.in_shift || p.dec_boxes ||
+  if ((p.dev & YL_DEV_S2C_OFF) || !p.w3p || p.k != 3 || p.stride != 2 || p.dw_k || p.C1 > 0 || p.res || p.up || p.in_shift || p.dec_boxes ||
       p.act == YL_ACT_SILU || p.act3 == YL_ACT_SILU || !yl_s2c_supported(p.Cin, p.N, p.C3, p.OH, p.OW) ||
       p.OH != (p.H + 2 * p.pad_t - 3) / 2 + 1 || p.OW != (p.W + 2 * p.pad_l - 3) / 2 + 1)
     return hipErrorNotSupported;

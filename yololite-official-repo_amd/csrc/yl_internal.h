@@ -106,7 +106,36 @@ struct YlConvP {
   // Winograd F(2x2,3x3) image of a dense 3x3 stride-1 conv (yl_conv_wino_kernel, option "winograd"), or nullptr:
   // U = G g G^T per (cout, cin), packed [n-group of 32 couts][k-block][xi 0..15][2 n-tiles][64 lanes][4]
   const float* wino;
+  // squeeze-excite gate (YL_OP_SE output, [B][Cin]) multiplying the 1x1 conv's input per image and channel, or nullptr
+  const float* scale;
+  // developer kernel-selection word of the context (yl_set_option "dev_select"; 0 in production): YL_DEV_*
+  unsigned dev;
 };
+
+// YlConvP::dev -- developer kernel-selection switches (A/B runs, bitwise kernel-equivalence tests); per context, never
+// process-wide (the launchers used to read getenv switches)
+#define YL_DEV_DW_TILE_OFF (1u << 0)   // stand-alone depthwise: yl_dw_kernel instead of yl_dw_tile_kernel
+#define YL_DEV_PWS_OFF (1u << 1)       // wide 1x1 layers: yl_conv_pwt_kernel instead of yl_conv_pws_kernel
+#define YL_DEV_S2C_OFF (1u << 2)       // 3x3 s2 + chained 1x1: yl_conv_mfma_kernel instead of yl_conv_s2c_kernel
+#define YL_DEV_DWC_ALL (1u << 3)       // yl_conv_dwc_kernel (tile_m 7) on every shape it supports
+#define YL_DEV_DWT_OFF (1u << 4)       // depthwise -> 1x1: yl_conv_dwh_kernel instead of yl_conv_dwt_kernel
+#define YL_DEV_DWK(d) (((d) >> 5) & 3u)   // yl_conv_dwk_kernel: 0 default (a wave holds every n-group), 1 one n-group per item, 2 off
+#define YL_DEV_KXK_NW(d) (((d) >> 7) & 3u) // yl_conv_kxk_kernel waves per workgroup: 0 auto, 1 four, 2 eight, 3 off (4-n-tile layers)
+#define YL_DEV_KXK_MT2 (1u << 9)       // ... two m-tiles per wave in the 4-wave form
+
+// squeeze-excite gate (yl_se.hip): fixed-order two-pass spatial mean + the two FCs + sigmoid
+struct YlSeP {
+  const float* x;        // [B][HW][C]
+  float* partial;        // [B][P][C] scratch
+  const float* w1;       // [RD][C]
+  const float* b1;       // [RD]
+  const float* w2;       // [C][RD]
+  const float* b2;       // [C]
+  float* gate;           // [B][C]
+  int B, HW, C, RD, P, act;
+};
+hipError_t yl_launch_se(const YlSeP& p, hipStream_t st);
+int yl_se_parts(int HW, int C);            // partial sums per image the pool pass produces for this shape
 
 // Up to 4 independent convolutions of identical kernel configuration in ONE launch (the FPN smooth blocks,
 // head trunks and head outputs of all pyramid levels): every block serves one problem, the grid is split in

@@ -991,6 +991,10 @@ extern "C" int yl_debug_mi_blocks(unsigned long long* host) {
 #else
 #define YL_MIS(i) do { } while (0)
 #endif
+// level tables of yl_masks_image_kernel in LDS: lptr[YL_MAX_LEVELS] (pointers), lnl[YL_MAX_LEVELS], loff[YL_MAX_LEVELS + 1];
+// ONE definition for the kernel's carve-up and the launcher's dynamic-LDS request (a hand-counted
+// "YL_MAX_LEVELS * 12 + 8" was 28 bytes short and pre[B-6..B] lay past the request)
+#define YL_MI_LEVEL_TABLE_BYTES (YL_MAX_LEVELS * (sizeof(const float*) + sizeof(int)) + (YL_MAX_LEVELS + 1) * sizeof(int))
 template <bool BOXES>
 __global__ __launch_bounds__(256, BOXES ? 5 : 8) void yl_masks_image_kernel(YlLevels lv, YlMaskImgP p) {
 #pragma clang fp contract(off)
@@ -1004,7 +1008,7 @@ __global__ __launch_bounds__(256, BOXES ? 5 : 8) void yl_masks_image_kernel(YlLe
   const float** lptr = reinterpret_cast<const float**>(tile + p.tile + 32);      // [YL_MAX_LEVELS]
   int* lnl = reinterpret_cast<int*>(lptr + YL_MAX_LEVELS);                       // [YL_MAX_LEVELS] A * S * S
   int* loff = lnl + YL_MAX_LEVELS;                                               // [YL_MAX_LEVELS + 1]
-  int* pre = loff + YL_MAX_LEVELS + 1;                                           // [B + 1] first item of every image
+  int* pre = reinterpret_cast<int*>(tile + p.tile + 32 + YL_MI_LEVEL_TABLE_BYTES); // [B + 1] first item of every image
   if (BOXES && threadIdx.x == 0) {
 #pragma unroll
     for (int l = 0; l < YL_MAX_LEVELS; ++l) {
@@ -1254,18 +1258,14 @@ hipError_t yl_launch_masks_image(const YlLevels& lv, int B, const float* proto, 
   // small batches: cut every detection's rows into parts so that a handful of detections still spreads over the chip
   p.parts = B >= 16 ? 1 : min(max(32 / B, 1), min(16, max_h));
   p.B = B;
-  static int blocks_fill = 0, blocks_box = 0;
-  if (!blocks_fill) {
-    const char* e = getenv("YL_MI_BLOCKS");             // tuning aid: "fill:box" workgroups
-    if (!e || sscanf(e, "%d:%d", &blocks_fill, &blocks_box) != 2 || blocks_fill < 1 || blocks_box < 1) {
-      blocks_fill = 2048; blocks_box = 2048;            // 8 x 256 CUs
-    }
-  }
+  const int blocks_fill = 2048, blocks_box = 2048;      // 8 x 256 CUs each (tuned: tools/masks_ab.py)
   const long long most = (long long)B * max_out * p.parts;
   const unsigned gfill = (unsigned)min((long long)blocks_fill, most), gbox = (unsigned)min((long long)blocks_box, most);
   // bit-packed rows are short (80 B at 640 px): 4 KB tiles hold ~50 rows and keep 8 workgroups per CU; uint8 rows get 16 KB
   p.tile = packed ? 4096 : 16384;
-  const size_t lds = (size_t)(64 + YL_MI_PCAP + 4 * YL_MI_ROWS) * sizeof(float) + p.tile + 32 + YL_MAX_LEVELS * 12 + 8 + (size_t)(B + 1) * sizeof(int);
+  // the kernel's carve-up (mi_smem): coef[64] pbuf[PCAP] rtab[ROWS][4] | tile[tile + 32] | lptr[L] lnl[L] loff[L + 1] | pre[B + 1]
+  const size_t lds = (size_t)(64 + YL_MI_PCAP + 4 * YL_MI_ROWS) * sizeof(float) + p.tile + 32 + YL_MI_LEVEL_TABLE_BYTES +
+                     (size_t)(B + 1) * sizeof(int);
   hipLaunchKernelGGL(yl_masks_image_kernel<true>, dim3(gbox), dim3(256), lds, st, lv, p);
   hipLaunchKernelGGL(yl_masks_image_kernel<false>, dim3(gfill), dim3(256), lds, st, lv, p);
   return hipGetLastError();

@@ -27,9 +27,6 @@
 #include "yl_dev.h"
 #include <type_traits>
 
-#ifndef SB_EXP
-#define SB_EXP 0                    // timing experiments (variant builds only): 2 no stem MFMAs, 3 no 3x3 MFMAs,
-#endif                              // 4 no stores, 5 no gathers, 6 no LDS patch traffic -- results are WRONG when set
 #define SB_TR 2                     // wave tile: 2 rows x 8 columns of the second conv's output grid
 #define SB_TC 8
 #define SB_PR (2 * SB_TR + 1)       // stem patch: 5 rows x 17 columns
@@ -291,8 +288,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
       for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
-          if (SB_EXP != 2) a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], s == 6 ? x6 : xs[s], a1[nt], 0, 0, 0);
-          else a1[nt][0] += wa[s][nt] * xs[s];
+          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], s == 6 ? x6 : xs[s], a1[nt], 0, 0, 0);
 #endif
       bool inside = true;
       if (!INTERIOR) inside = sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;   // else: zero padding of the second conv
@@ -353,7 +349,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
           const f32x4 w = wq[i & 1][nt], x = xq[i & 1];
-          if (SB_EXP == 3) { a2[nt][0] += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3]; continue; }
 #if YL_BF16
           if (i & 1) a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2b[nt], 0, 0, 0);
           else a2[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2[nt], 0, 0, 0);

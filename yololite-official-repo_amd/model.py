@@ -75,6 +75,7 @@ class HipContext:
                 y.w, y.b, y.dw_w, y.dw_b = fp(l.w), fp(l.b), fp(l.dw_w), fp(l.dw_b)
                 y.c2, y.act2, y.c3, y.act3 = l.c2, l.act2, l.c3, l.act3
                 y.w2, y.b2, y.w3, y.b3 = fp(l.w2), fp(l.b2), fp(l.w3), fp(l.b3)
+                y.scale_slot, y.reserved0 = l.scale_slot, 0
             d.num_layers = len(program.layers)
             d.layers = arr
             keep.append(arr)
@@ -124,15 +125,20 @@ class HipContext:
     def set_option(self, name: str, value: int):
         """yl_set_option.  A value that is already set is not sent again: the library drops its cached hipGraphs on
         every option write."""
-        opts = self.__dict__.setdefault("_opts", {})
-        if opts.get(name) == int(value):
+        if self.get_option(name) == int(value):
             return
         _lib.check(self.lib.yl_set_option(self.handle, name.encode(), int(value)), self.handle, "yl_set_option")
-        opts[name] = int(value)
 
-    def get_option(self, name: str, default: int = 0) -> int:
-        """the value last written through set_option (the library's defaults are 0 for the measurement aids)"""
-        return self.__dict__.get("_opts", {}).get(name, default)
+    def get_option(self, name: str, default: Optional[int] = None) -> int:
+        """yl_get_option: the library's CURRENT value (its default when never written, clamped to the option's range).
+        `default` is returned for a name the library does not know (else that raises)."""
+        v = C.c_int32()
+        st = self.lib.yl_get_option(self.handle, name.encode(), C.byref(v))
+        if st != _lib.YL_OK:
+            if default is not None:
+                return default
+            _lib.check(st, self.handle, f"yl_get_option({name})")
+        return int(v.value)
 
     # ---- forward
     def forward(self, x: torch.Tensor, timed: bool = False):
@@ -177,6 +183,19 @@ class HipContext:
         _lib.check(self.lib.yl_decode(self.handle, self._ptr_array(lv), B, _lib.CENTER[center_mode], _lib.WH[wh_mode],
                                       box.data_ptr(), obj.data_ptr(), cls.data_ptr() if self.C else None,
                                       _stream_ptr(self.device)), self.handle, "yl_decode")
+        return {"box": box, "obj": obj, "cls": cls}
+
+    def forward_decoded(self, x: torch.Tensor, center_mode="v8", wh_mode="softplus"):
+        """yl_forward_decoded: network input -> the decoded triple {"box" [B,N,4], "obj" [B,N,1], "cls" [B,N,C]} in one
+        call (the reference's exported wire format, export/export_onnx.py:283-296)."""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        B = x.shape[0]
+        box = torch.empty((B, self.N, 4), device=self.device, dtype=torch.float32)
+        obj = torch.empty((B, self.N, 1), device=self.device, dtype=torch.float32)
+        cls = torch.empty((B, self.N, self.C), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.yl_forward_decoded(self.handle, x.data_ptr(), B, _lib.CENTER[center_mode], _lib.WH[wh_mode],
+                                               box.data_ptr(), obj.data_ptr(), cls.data_ptr() if self.C else None,
+                                               _stream_ptr(self.device)), self.handle, "yl_forward_decoded")
         return {"box": box, "obj": obj, "cls": cls}
 
     def make_cfg(self, mode, conf, iou, per_class_cap, topk, max_out, center_mode="v8", wh_mode="softplus",
@@ -341,9 +360,13 @@ class YOLOLiteHIP:
     checkpoint's meta, weights attached with load_state_dict(), moved with .to(device), called with
     a [B,3,S,S] float tensor, returns the list of level tensors."""
 
-    def __init__(self, meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False, fuse_ir=None):
+    def __init__(self, meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False, fuse_ir=None,
+                 fuse_uir: bool = True, fuse_lat: bool = True, fuse_chain: bool = True):
         self.meta = meta
         self.fuse_dw, self.fuse_stem, self.fuse_uib, self.fuse_ir = fuse_dw, fuse_stem, fuse_uib, fuse_ir
+        # every fusion policy of the host compiler is resolved HERE, once per model (no process environment)
+        self._fuse_kw = dict(fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib, fuse_ir=fuse_ir, fuse_uir=fuse_uir,
+                             fuse_lat=fuse_lat, fuse_chain=fuse_chain)
         self.export_concat = False
         self.program: Optional[Program] = None
         self.ctx: Optional[HipContext] = None
@@ -361,8 +384,7 @@ class YOLOLiteHIP:
         Unlike the reference, a key the forward pass needs cannot be left at its random init:
         missing weights raise."""
         try:
-            self.program = build_program(self.meta, state_dict, fuse_dw=self.fuse_dw, fuse_stem=self.fuse_stem,
-                                         fuse_uib=self.fuse_uib, fuse_ir=self.fuse_ir)
+            self.program = build_program(self.meta, state_dict, **self._fuse_kw)
         except KeyError as e:
             raise RuntimeError(f"checkpoint lacks a weight the forward pass needs: {e.args[0]}") from None
         self._sd = state_dict
@@ -388,8 +410,7 @@ class YOLOLiteHIP:
         planned per size, so contexts are cached by input size."""
         if img_size not in self._ctxs:
             p = self.program if img_size == self.program.img_size else \
-                build_program(self.meta, self._sd, fuse_dw=self.fuse_dw, img_size=img_size, fuse_stem=self.fuse_stem,
-                              fuse_uib=self.fuse_uib, fuse_ir=self.fuse_ir)
+                build_program(self.meta, self._sd, img_size=img_size, **self._fuse_kw)
             self._ctxs[img_size] = (p, HipContext(p.img_size, p.num_classes, p.level_size, p.level_anchors, p,
                                                   self._device_index))
         return self._ctxs[img_size][1]
@@ -421,11 +442,17 @@ class YOLOLiteHIP:
 
     forward = __call__
 
+    def forward_decoded(self, x: torch.Tensor, center_mode="v8", wh_mode="softplus"):
+        """The reference's exported "decoded" outputs (export/export_onnx.py:283-296) straight from the input."""
+        if self.ctx is None:
+            raise RuntimeError("model.to('cuda') first")
+        return self._ctx_for(int(x.shape[-1])).forward_decoded(x, center_mode, wh_mode)
+
 
 def build_model_from_meta(meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False,
-                          fuse_ir=None) -> YOLOLiteHIP:
-    """tools/infer.py:34-77."""
-    return YOLOLiteHIP(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib, fuse_ir=fuse_ir)
+                          fuse_ir=None, **fuse_kw) -> YOLOLiteHIP:
+    """tools/infer.py:34-77.  (fuse_*: launch-fusion policies of the host compiler, see program.build_program)"""
+    return YOLOLiteHIP(meta, fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib, fuse_ir=fuse_ir, **fuse_kw)
 
 
 def load_model_names_imgsize_from_ckpt(weights: str, device):

@@ -17,7 +17,6 @@ nearest-upsample-add / activation epilogues, one GEMM for the three head output 
 from __future__ import annotations
 
 import math
-import os
 import zlib
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -46,6 +45,20 @@ BACKBONES: Dict[str, dict] = {
               ["uir_r1_a3_k3_s2_e4_c24", "uir_r1_a0_k5_s1_e2_c24"], ["cn_r1_k1_s1_e1_c32"]],
         cmult=1.0, dmult=1.0, act="relu", eps=1e-5, same=False, fix_first_last=False, stem=16),
 }
+# timm _gen_efficientnetv2_base (tf_ variants: TF-SAME padding, BN eps 1e-3; SiLU; channel rounding with round_limit 0):
+# ConvBnAct stage with residual, fused-MBConv `er` (EdgeResidual), MBConv `ir` with SqueezeExcite (se0.25 of the block
+# input).  configs/v2_models/yololite_{n,s,m}.yaml; published checksums BENCHMARK.md:356-357.
+BACKBONES["tf_efficientnetv2_b0"] = dict(
+    arch=[["cn_r1_k3_s1_e1_c16_skip"], ["er_r2_k3_s2_e4_c32"], ["er_r2_k3_s2_e4_c48"], ["ir_r3_k3_s2_e4_c96_se0.25"],
+          ["ir_r5_k3_s1_e6_c112_se0.25"], ["ir_r8_k3_s2_e6_c192_se0.25"]],
+    cmult=1.0, dmult=1.0, act="silu", eps=1e-3, same=True, fix_first_last=False, stem=32, round_limit=0.0)
+for _n, _c, _d in (("1", 1.0, 1.1), ("2", 1.1, 1.2), ("3", 1.2, 1.4)):
+    BACKBONES["tf_efficientnetv2_b" + _n] = dict(BACKBONES["tf_efficientnetv2_b0"], cmult=_c, dmult=_d)
+# tiny efficientnetv2-style test vehicle (not a timm model; oracle/backbones.py: ORACLE_TINY_V2)
+BACKBONES["oracle_tiny_v2"] = dict(
+    arch=[["cn_r2_k3_s1_e1_c8_skip"], ["er_r2_k3_s2_e2_c12"], ["er_r1_k3_s2_e4_c16"], ["ir_r2_k3_s2_e4_c24_se0.25"],
+          ["ir_r2_k3_s1_e3_c24_se0.25"], ["ir_r2_k3_s2_e4_c32_se0.25"]],
+    cmult=1.0, dmult=1.0, act="silu", eps=1e-3, same=True, fix_first_last=False, stem=16, round_limit=0.0)
 BACKBONES["mobilenetv4_conv_small_050"] = dict(BACKBONES["mobilenetv4_conv_small"], cmult=0.5)
 BACKBONES["oracle_tiny_tf"] = dict(BACKBONES["oracle_tiny"], act="relu6", eps=1e-3, same=True)
 for _n, _c, _d in (("1", 1.0, 1.1), ("2", 1.1, 1.2), ("3", 1.2, 1.4), ("4", 1.4, 1.8)):
@@ -61,9 +74,14 @@ def _make_divisible(v, divisor=8, round_limit=0.9):
 
 def _parse(s: str) -> dict:
     parts = s.split("_")
-    d = {"type": parts[0], "r": 1, "e": 1.0, "a": 0}
+    d = {"type": parts[0], "r": 1, "e": 1.0, "a": 0, "skip": False, "se": 0.0}
     for p in parts[1:]:
-        d[p[0]] = float(p[1:]) if p[0] == "e" else int(p[1:])
+        if p == "skip":
+            d["skip"] = True
+        elif p.startswith("se"):
+            d["se"] = float(p[2:])
+        else:
+            d[p[0]] = float(p[1:]) if p[0] == "e" else int(p[1:])
     return d
 
 
@@ -86,6 +104,7 @@ class Layer:
     res_slot: int = -1
     up_slot: int = -1
     head_level: int = -1
+    scale_slot: int = -1        # squeeze-excite gate [1,1,cin] multiplying this 1x1 conv's input (an OP_SE output)
     dw_k: int = 0
     dw_stride: int = 1
     dw_pad_t: int = 0
@@ -150,6 +169,8 @@ class SynthStateDict(dict):
             else:
                 base = {"obj": -math.log(99.0), "cls": (-math.log(self.C) if self.C > 1 else 0.0), "box": 0.0, "mc": 0.0}
                 v = base[key.split(".")[-2]] + r.randn(*shape) * self.head_noise
+        elif key.endswith("se.conv_expand.bias"):
+            v = 1.5 + r.randn(*shape) * 0.5             # gates around 0.8: activations keep their scale through 20 SE blocks
         elif key.endswith("running_var"):
             v = r.rand(*shape) + 0.5
         elif key.endswith("running_mean") or key.endswith(".bias"):
@@ -242,6 +263,14 @@ MODEL_ZOO = {
                    width_multiple=1.00, fpn_channels=320, head_depth=3),
     "yololite_m": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite2", depth_multiple=1.0,
                        width_multiple=1.0, fpn_channels=328, head_depth=2),
+    # /root/reference/configs/v2_models/*.yaml (the yololite_n / yololite_m whose parameters and MACs BENCHMARK.md:356-357
+    # publishes: 8.923 M / 11.473 G and 17.916 M / 27.239 G)
+    "yololite_n_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b0", depth_multiple=1.0,
+                          width_multiple=1.0, fpn_channels=196, head_depth=1),
+    "yololite_s_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b1", depth_multiple=1.0,
+                          width_multiple=1.0, fpn_channels=256, head_depth=2),
+    "yololite_m_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b2", depth_multiple=1.0,
+                          width_multiple=1.0, fpn_channels=328, head_depth=2),
 }
 
 
@@ -251,14 +280,23 @@ def zoo_meta(name: str, num_classes: int = 80, img_size: int = 640, **kw) -> dic
 
 
 _ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
-_OP_STEM, _OP_CONV, _OP_DW, _OP_STEMBLOCK = 0, 1, 2, 3
+_OP_STEM, _OP_CONV, _OP_DW, _OP_STEMBLOCK, _OP_SE = 0, 1, 2, 3, 4
 DW_PROLOGUE_LDS_MAX = 32 * 1024      # bytes; mirrors YL_DW_LDS_MAX in csrc/yl_api.hip
 
 
+def _query_fused_block(c_in, c_mid, c_out, dk, ds, oh, ow) -> int:
+    """yl_query_fused_block: the LIBRARY says whether a fused inverted-residual block of this shape is instantiated
+    (1 = yl_ir_kernel, 2 = yl_uib_kernel, 0 = no) -- host-side code of the .so, no device needed.  (the
+    hand-copied mirrors of the kernels' shape tables that used to live here are gone.)"""
+    from . import _lib
+    return int(_lib.load().yl_query_fused_block(int(c_in), int(c_mid), int(c_out), int(dk), int(ds), int(oh), int(ow)))
+
+
 class _Builder:
-    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw, fuse_stem=True, fuse_uib=True, fuse_ir=True):
+    def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw, fuse_stem=True, fuse_uib=True, fuse_ir=True,
+                 fuse_uir=True, fuse_lat=True, fuse_chain=True):
         self.sd, self.p, self.fuse_dw, self.fuse_stem, self.fuse_uib = sd, prog, fuse_dw, fuse_stem, fuse_uib
-        self.fuse_ir = fuse_ir
+        self.fuse_ir, self.fuse_uir, self.fuse_lat, self.fuse_chain = fuse_ir, fuse_uir, fuse_lat, fuse_chain
 
     # ---- state-dict access
     def get(self, key: str, shape: Tuple[int, ...]) -> np.ndarray:
@@ -334,42 +372,19 @@ class _Builder:
                                    bytes_out=4 * oh * oh * cout))
         return o
 
-    # shapes instantiated by yl_uib_dispatch (csrc/yl_conv.hip): (projection n-tiles, dw k, input k-blocks)
-    _UIB_SHAPES = {(1, 3, 1), (2, 3, 1), (1, 5, 1), (2, 5, 2), (3, 3, 3), (4, 3, 4), (4, 5, 4), (3, 5, 3),
-                   (6, 3, 6), (8, 3, 8), (8, 5, 8), (6, 5, 6), (2, 3, 2), (2, 5, 1)}
-
     def uib_fusable(self, x, cmid, cout, dk):
+        """per-wave fused block (yl_uib_kernel; option fuse_uib): stride 1, grids multiples of 4"""
         h, w, c1 = self.dims(x)
-        if not self.fuse_uib or (h & 3) or (w & 3) or dk not in (3, 5):
+        if not self.fuse_uib or (h & 3) or (w & 3):
             return False
-        ntt = -(-cout // 16)
-        nt = next((v for v in (1, 2, 3, 4, 6, 8) if v >= ntt), 0)
-        if (nt, dk, -(-c1 // 16)) not in self._UIB_SHAPES:
-            return False
-        kb, hp = -(-cmid // 16), 3 + dk
-        pitch = hp if hp % 4 in (1, 3) else hp + 1
-        lds = kb * nt * 1024 + (dk * dk + 1) * cmid * 4 + kb * 64 + 4 * hp * pitch * 64
-        return lds <= 144 * 1024
-
-    # shapes instantiated by yl_launch_conv_ir (csrc/yl_convc.hip: YL_IR_SHAPES): (input k-blocks, projection n-tile
-    # bucket, dw k, dw stride, m-tiles per wave) -- the workgroup-level-halo kernel for EfficientNet-style blocks
-    _IR_SHAPES = ((1, 2, 3, 2, 1, 2, 2), (2, 2, 3, 1, 2, 2, 2), (2, 3, 5, 2, 1, 2, 2), (3, 3, 5, 1, 2, 2, 2), (3, 6, 3, 2, 1, 2, 2),
-                  (3, 3, 3, 1, 1, 2, 2), (2, 6, 3, 1, 2, 2, 2), (3, 6, 3, 1, 1, 2, 2))
+        return _query_fused_block(c1, cmid, cout, dk, 1, h, w) in (1, 2)
 
     def ir_fusable(self, x, cmid, cout, dk, ds, oh, ow):
-        """mirror of yl_ir_supported (csrc/yl_convc.hip)"""
-        if not self.fuse_ir:
+        """workgroup-level-halo fused block (yl_ir_kernel).  fuse_dw == "dw3": only 3x3 depthwise convs are fused
+        anywhere in the program, this kernel included."""
+        if not self.fuse_ir or (self.fuse_dw == "dw3" and dk != 3):
             return False
-        c1 = self.dims(x)[2]
-        kbi, nt = -(-c1 // 16), -(-cout // 16)
-        for (a, bk, c, d, e, r, cb) in self._IR_SHAPES:
-            lo = {2: 0, 3: 2, 4: 3}.get(bk, 4)
-            if kbi == a and lo < nt <= bk and dk == c and ds == d and oh % (4 * r) == 0 and ow % (4 * e * cb) == 0:
-                hh, hw = (4 * r - 1) * d + c, (4 * e * cb - 1) * d + c
-                pitch = ((hw * 16 + 7) // 64) * 64 + 56
-                lds = (2 * hh * pitch + 2 * bk * 256 + (((c * c + 1) * cmid + 3) & ~3) + -(-cmid // 16) * 16) * 4
-                return lds <= 150 * 1024
-        return False
+        return _query_fused_block(self.dims(x)[2], cmid, cout, dk, ds, oh, ow) == 1
 
     def uib(self, x, pre, eps, act, cmid, cout, dk, res,
             keys=("pw_exp.conv", "pw_exp.bn", "dw_mid.conv", "dw_mid.bn", "pw_proj.conv", "pw_proj.bn"), ds=1, same=False):
@@ -407,8 +422,30 @@ class _Builder:
         self.p.layers.append(L)
         return o
 
+    def dw(self, x, conv, bn, eps, act, k, s, same):
+        """stand-alone depthwise conv (+BN+act) as its own layer"""
+        h, wd, c = self.dims(x)
+        w, b = self.fold(conv, bn, eps, False, (c, 1, k, k))
+        oh, pad = self.geom(h, k, s, same)
+        ow, _ = self.geom(wd, k, s, same)
+        y = self.slot(oh, ow, c)
+        self.p.layers.append(Layer(_OP_DW, x, y, c, c, k, s, pad, pad, _ACT[act], w, b, name=conv, macs=oh * ow * c * k * k,
+                                   bytes_in=4 * h * wd * c, bytes_out=4 * oh * ow * c))
+        return y
+
+    def se(self, x, pre, rd, act):
+        """timm SqueezeExcite gate of tensor x: [1,1,C] slot = sigmoid(conv_expand(act(conv_reduce(mean_hw(x)))))"""
+        h, wd, c = self.dims(x)
+        w1, b1 = self.get(pre + "conv_reduce.weight", (rd, c, 1, 1)), self.get(pre + "conv_reduce.bias", (rd,))
+        w2, b2 = self.get(pre + "conv_expand.weight", (c, rd, 1, 1)), self.get(pre + "conv_expand.bias", (c,))
+        g = self.slot(1, 1, c)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        self.p.layers.append(Layer(_OP_SE, x, g, c, rd, 1, 1, 0, 0, _ACT[act], f32(w1), f32(b1), c2=c, w2=f32(w2), b2=f32(b2),
+                                   name=pre + "gate", macs=2 * c * rd, bytes_in=4 * h * wd * c, bytes_out=4 * c))
+        return g
+
     def conv(self, x, conv, bn, eps, act, cout, k=1, s=1, same=False, bias=False, res=-1, up=-1, head_level=-1,
-             dw=None, out_hw=None, wb=None, name=None, in_shift=0, chain=None):
+             dw=None, out_hw=None, wb=None, name=None, in_shift=0, chain=None, scale=-1):
         """dense conv; dw = dict(conv=..., bn=..., eps=..., act=..., k=..., s=..., bias=False) is a depthwise
         conv applied to x first (fused as a prologue when enabled, otherwise emitted as its own layer)."""
         h, wd, cin = self.dims(x)
@@ -447,7 +484,7 @@ class _Builder:
         else:
             o = self.slot(oh, ow, chain["cout"] if chain else cout)
         L = Layer(_OP_CONV, x, o, cin, cout, k, s, pad, pad, _ACT[act], w, b, in_shift=in_shift, res_slot=res, up_slot=up,
-                  head_level=head_level, name=name or conv, macs=oh * ow * cout * cin * k * k,
+                  head_level=head_level, scale_slot=scale, name=name or conv, macs=oh * ow * cout * cin * k * k,
                   bytes_in=4 * h * wd * cin, bytes_out=4 * oh * ow * cout)
         if chain:           # a 1x1 conv (+BN+act) chained in the same launch: chain = dict(conv, bn, eps, act, cout)
             w3, b3 = self.fold(chain["conv"], chain["bn"], chain["eps"], False, (chain["cout"], cout, 1, 1))
@@ -473,7 +510,8 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
     arch, act, eps, same = spec["arch"], spec["act"], spec["eps"], spec["same"]
     ns = len(arch)
     s0 = [_parse(t) for t in arch[0]]
-    c_s0 = [_make_divisible(d["c"] * spec["cmult"], 8) for d in s0]
+    rlim = spec.get("round_limit", 0.9)          # channel rounding of the OUTPUT widths (expansions always use 0.9)
+    c_s0 = [_make_divisible(d["c"] * spec["cmult"], 8, rlim) for d in s0]
     fused_entry = (b.fuse_stem and not same and act in ("relu", "relu6") and spec["stem"] in (16, 32) and len(s0) in (1, 2)
                    and s0[0]["type"] == "cn" and s0[0]["k"] == 3 and s0[0]["s"] == 2 and s0[0]["r"] == 1
                    and (len(s0) == 1 or (s0[1]["type"] == "cn" and s0[1]["k"] == 1 and s0[1]["s"] == 1 and s0[1]["r"] == 1))
@@ -504,7 +542,7 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
             rep = d["r"]
             if spec["dmult"] != 1.0 and not (spec["fix_first_last"] and si in (0, ns - 1)):
                 rep = int(math.ceil(rep * spec["dmult"]))
-            cout = _make_divisible(d["c"] * spec["cmult"], 8)
+            cout = _make_divisible(d["c"] * spec["cmult"], 8, rlim)
             for r in range(rep):
                 s = d["s"] if r == 0 else 1
                 pre = f"{prefix}blocks.{si}.{bi}."
@@ -512,20 +550,34 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
                 if d["type"] == "cn":
                     chain = None
                     if (d["k"] > 1 and rep == 1 and sidx + 1 < len(stage) and b.fuse_dw is not False and act in ("relu", "relu6")
-                            and os.environ.get("YL_FUSE_CHAIN", "1") != "0"):
+                            and b.fuse_chain):
                         d2 = _parse(stage[sidx + 1])
-                        c2o = _make_divisible(d2["c"] * spec["cmult"], 8)
+                        c2o = _make_divisible(d2["c"] * spec["cmult"], 8, rlim)
                         if (d2["type"] == "cn" and d2["k"] == 1 and d2["s"] == 1 and d2["r"] == 1 and cout <= 96 and cout % 4 == 0
                                 and c2o <= 32 and c2o % 4 == 0):
                             # dense k x k conv followed by a 1x1 conv (blocks.1.0 / blocks.1.1 of mobilenetv4_conv_small):
                             # the 1x1 is chained in the epilogue of the k x k launch (yl_conv_mfma_kernel)
                             chain = dict(conv=f"{prefix}blocks.{si}.{bi + 1}.conv", bn=f"{prefix}blocks.{si}.{bi + 1}.bn1",
                                          eps=eps, act=act, cout=c2o)
-                    x = b.conv(x, pre + "conv", pre + "bn1", eps, act, cout, d["k"], s, same, chain=chain)
+                    x = b.conv(x, pre + "conv", pre + "bn1", eps, act, cout, d["k"], s, same, chain=chain,
+                               res=(x if (d["skip"] and skip) else -1))
                     if chain:
                         skip_next = True
                         cout = chain["cout"]
-                elif d["type"] == "uir" and not d["a"] and d["k"] and not same and os.environ.get("YL_FUSE_UIR", "1") != "0" and \
+                elif d["type"] == "er":
+                    # fused MBConv (timm EdgeResidual): k x k expansion conv (strided, +BN+act) -> 1x1 projection (+BN) (+res)
+                    mid = _make_divisible(cin * d["e"], 8)
+                    y = b.conv(x, pre + "conv_exp", pre + "bn1", eps, act, mid, d["k"], s, same)
+                    x = b.conv(y, pre + "conv_pwl", pre + "bn2", eps, "none", cout, res=(x if skip else -1))
+                elif d["type"] == "ir" and d["se"]:
+                    # MBConv with squeeze-excite: 1x1 expand -> depthwise (own launch: the gate needs its whole output) ->
+                    # gate (fixed-order mean + 2 FCs) -> 1x1 projection reading the depthwise output times the gate
+                    mid = _make_divisible(cin * d["e"], 8)
+                    y = b.conv(x, pre + "conv_pw", pre + "bn1", eps, act, mid, same=same)
+                    z = b.dw(y, pre + "conv_dw", pre + "bn2", eps, act, d["k"], s, same)
+                    g = b.se(z, pre + "se.", int(round(mid * (d["se"] / d["e"]))), act)
+                    x = b.conv(z, pre + "conv_pwl", pre + "bn3", eps, "none", cout, res=(x if skip else -1), scale=g)
+                elif d["type"] == "uir" and not d["a"] and d["k"] and not same and b.fuse_uir and \
                         b.ir_fusable(x, _make_divisible(cin * d["e"], 8), cout, d["k"], s,
                                      b.geom(b.dims(x)[0], d["k"], s, same)[0], b.geom(b.dims(x)[1], d["k"], s, same)[0]):
                     # MobileNetV4 UIB blocks without a start depthwise, at the shapes yl_ir_kernel is instantiated for
@@ -581,15 +633,19 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
 
 def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto",
                   img_size: Optional[int] = None, fuse_stem: bool = True, fuse_uib: bool = False,
-                  fuse_ir: Optional[bool] = None) -> Program:
+                  fuse_ir: Optional[bool] = None, fuse_uir: bool = True, fuse_lat: bool = True,
+                  fuse_chain: bool = True) -> Program:
     """meta: the checkpoint's `meta` dict (tools/train.py:62-75); reads the keys
     build_model_from_meta reads (tools/infer.py:35-50).
     fuse_dw: True = every depthwise conv becomes the prologue of the following 1x1 conv, False = none,
     "dw3" = only 3x3; "auto" = measured best policy (currently: all, LDS-halo kernel).
     fuse_ir: EfficientNet-style inverted-residual blocks of the shapes yl_ir_kernel is instantiated for as ONE launch
-    (default on; None reads YL_FUSE_IR, "0" = off for A/B runs)."""
+    (None = on); fuse_uir: likewise the MobileNetV4 UIB blocks without a start depthwise; fuse_lat: FPN lateral + first
+    depthwise smooth block as one launch; fuse_chain: a 1x1 conv chained in the epilogue of the dense k x k conv before
+    it.  All of them are arguments (resolved once per model: YOLOLiteHIP.__init__), never process environment: two
+    programs built in one process cannot silently differ."""
     if fuse_ir is None:
-        fuse_ir = os.environ.get("YL_FUSE_IR", "1") != "0"
+        fuse_ir = True
     cfg = meta.get("config", {}) or {}
     mcfg = cfg.get("model", {}) or {}
     tcfg = cfg.get("training", {}) or {}
@@ -617,8 +673,9 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     else:
         sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
     prog = Program(img_size=S, num_classes=C, level_size=[], level_anchors=[], strides=[])
-    b = _Builder(sd, prog, fuse_dw, fuse_stem, bool(fuse_uib) and fuse_dw is not False,
-                 bool(fuse_ir) and fuse_dw is not False)
+    on = fuse_dw is not False
+    b = _Builder(sd, prog, fuse_dw, fuse_stem, bool(fuse_uib) and on, bool(fuse_ir) and on, bool(fuse_uir) and on,
+                 bool(fuse_lat) and on, bool(fuse_chain) and on)
 
     feats = _backbone(b, backbone)
     take = 4 if use_p2 else 3
@@ -661,7 +718,7 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
         k = n_[1]
         cslot = prog.feature_slots["c" + k]
         ch, cw = b.dims(cslot)[0], b.dims(cslot)[1]
-        if cpu_arch and os.environ.get("YL_FUSE_LAT", "1") != "0" and b.ir_fusable(cslot, F_, F_, 3, 1, ch, cw):
+        if cpu_arch and b.fuse_lat and b.ir_fusable(cslot, F_, F_, 3, 1, ch, cw):
             # lateral 1x1 (+bias, + upsample-add of the smoothed coarser level) and the first depthwise smooth block as
             # ONE launch (yl_ir_kernel: the lateral is the "expansion", its output -- which has no other consumer --
             # lives only as 16-channel slabs of a workgroup's halo region in LDS)
