@@ -55,11 +55,34 @@ def _assert_boxes_equal_after_rounding(got, exp):
     np.testing.assert_allclose(got, exp, rtol=0, atol=1e-3)
 
 
+def _align_score_ties(gb, eb, es, ec, band=1e-5):
+    """Order inside a class is score-descending; two detections of one class whose ORACLE scores lie within `band`
+    (the fp32 drift of the forward pass) may legitimately come out in the other order.  Returns the permutation of the
+    oracle rows that undoes such swaps -- only rows of the same class within the band are ever exchanged; everything
+    else stays where it is (and fails the comparison that follows if it differs)."""
+    n = len(ec)
+    perm = np.arange(n)
+    close = lambda j, k: np.abs(np.asarray(gb[j], np.float64) - np.asarray(eb[k], np.float64)).max() < 0.5
+    taken = set()
+    for j in range(n):
+        if close(j, j) and j not in taken:
+            taken.add(j)
+            continue
+        cands = [k for k in range(max(0, j - 8), min(n, j + 9)) if k not in taken and ec[k] == ec[j] and
+                 abs(float(es[k]) - float(es[j])) <= band and close(j, k)]
+        if cands:
+            perm[j] = cands[0]
+            taken.add(cands[0])
+    return perm if len(set(perm.tolist())) == n else np.arange(n)
+
+
 def _assert_north_star(got, exp, b):
     gb, gs, gc = got
     assert gc.tolist() == exp["classes"][b].tolist(), "class ids / order differ"
-    np.testing.assert_allclose(gs, exp["scores"][b], rtol=0, atol=1e-4)
-    _assert_boxes_equal_after_rounding(gb, exp["boxes"][b])
+    perm = _align_score_ties(gb, exp["boxes"][b], exp["scores"][b], exp["classes"][b])
+    np.testing.assert_allclose(gs, exp["scores"][b][perm], rtol=0, atol=1e-4)
+    _assert_boxes_equal_after_rounding(gb, exp["boxes"][b][perm])
+    return int((perm != np.arange(len(perm))).sum())
 
 
 def _score_tensor(levels, C=80):
@@ -91,8 +114,8 @@ def _assert_first_divergence_is_a_threshold_flip(got, exp_b, exp_s, exp_c, iou_t
     <= thr inside the fp32 drift).  Anything else is a real disagreement."""
     gb, gs, gc = got
     n = min(len(gc), len(exp_c))
-    same = lambda j: int(gc[j]) == int(exp_c[j]) and abs(float(gs[j]) - float(exp_s[j])) <= 1e-4 and \
-        np.abs(gb[j] - exp_b[j]).max() <= 1e-3
+    # (boxes are not compared here: two near-tied scores of one class may swap places, see _align_score_ties)
+    same = lambda j: int(gc[j]) == int(exp_c[j]) and abs(float(gs[j]) - float(exp_s[j])) <= 1e-4
     j = next((k for k in range(n) if not same(k)), n)
     assert j < max(len(gc), len(exp_c)), "lists are equal"
     cand = []                                       # (class, -score, box) of the entries at position j of both lists
@@ -111,16 +134,21 @@ def _assert_first_divergence_is_a_threshold_flip(got, exp_b, exp_s, exp_c, iou_t
 
 
 def _assert_all_safe_images(dets, counts, exp, ref_scores, conf, images, min_safe_frac=0.9, exp_index=None, iou_thr=0.5,
-                            what=""):
+                            what="", got_scores=None):
     """north_star on EVERY threshold-safe image of `images` (exp lists are indexed by position unless exp_index maps
-    image -> position).  Safe = every candidate score keeps > 2e-5 from `conf` (no threshold decision inside the fp32
-    drift of the forward pass); at least `min_safe_frac` of the images must be safe.  Every safe image is held to class
+    image -> position).  Safe = every candidate score of the oracle keeps clear of `conf` by more than the image's MEASURED
+    score drift (1.5 x max |hip score - oracle score| over all its candidates when got_scores is given -- itself asserted
+    <= 1e-4 by the callers -- and never less than 2e-5): no threshold decision can flip; at least `min_safe_frac` of the
+    images must be safe.  Every safe image is held to class
     ids, 1e-4 scores and rounded boxes -- except that at most ONE image may differ in its detection list, and only if
     the first differing detection is PROVEN to be an NMS decision on the threshold (its deciding IoU within 1e-5 of
     iou_thr, _assert_first_divergence_is_a_threshold_flip) with the counts within +-2.  Prints how many images were
     held to the bar."""
     images = list(images)
-    safe = [b for b in images if float((ref_scores[b if exp_index is None else exp_index[b]] - conf).abs().min()) > 2e-5]
+    ix = lambda b: b if exp_index is None else exp_index[b]
+    band = {b: 2e-5 if got_scores is None else max(2e-5, 1.5 * float((got_scores[ix(b)] - ref_scores[ix(b)]).abs().max()))
+            for b in images}
+    safe = [b for b in images if float((ref_scores[ix(b)] - conf).abs().min()) > band[b]]
     odd = []
     for b in safe:
         i = b if exp_index is None else exp_index[b]
@@ -133,7 +161,8 @@ def _assert_all_safe_images(dets, counts, exp, ref_scores, conf, images, min_saf
             continue
         _assert_north_star((gb, gs, gc), exp, i)
     print(f"[parity {what}] images held to class ids / 1e-4 scores / rounded boxes: {len(safe) - len(odd)} of {len(images)} "
-          f"(threshold-safe {len(safe)}, list differs by a proven IoU-threshold flip: {odd})")
+          f"(threshold-safe {len(safe)}, largest safety band {max(band.values()):.2e}, list differs by a proven "
+          f"IoU-threshold flip: {odd})")
     assert len(safe) >= min_safe_frac * len(images), (len(safe), len(images))
     assert len(odd) <= 1, odd
     return [b for b in safe if b not in [o[0] for o in odd]]
@@ -176,11 +205,11 @@ def test_bench_configuration_edge_n_b64_parity(seed):
         ref_lv = orc(x.cpu())
     ref_s = _score_tensor(ref_lv)
     exp = opost.pipeline_main(ref_lv, 640, 0.4, 0.5, 300)
-    _assert_all_safe_images(d1, c1, exp, ref_s, 0.4, range(64), what=f"edge_n B=64 seed {seed}")
     # raw head tensors: decoded scores within the 1e-4 bar everywhere (not only on survivors), all 64 images
     lv = wl["model"](x)
     got_s = _score_tensor([t.cpu() for t in lv])
     assert float((got_s - ref_s).abs().max()) <= 1e-4
+    _assert_all_safe_images(d1, c1, exp, ref_s, 0.4, range(64), what=f"edge_n B=64 seed {seed}", got_scores=got_s)
 
 
 @pytest.mark.parametrize("name,seg,seed", [("yololite_m", False, 1), ("edge_m", True, 1), ("yololite_m", False, 2),
@@ -229,11 +258,13 @@ def test_full_size_configs_3_and_4(name, seg, seed):
     det_lv = [t[..., :85] for t in ref_lv]
     exp = opost.pipeline_main(det_lv, 640, 0.4, 0.5, 300)
     pos = {b: i for i, b in enumerate(cand)}
-    safe = _assert_all_safe_images(d1, c1, exp, _score_tensor(det_lv), 0.4, cand, exp_index=pos,
-                                   what=f"{name}{'+seg' if seg else ''} B=32 seed {seed}")
-    sel = [pos[b] for b in safe][:2]
     got_s = _score_tensor([t[cand].cpu() for t in la])
+    print(f"[parity {name} seed {seed}] max |score - oracle score| over all candidates: "
+          f"{float((got_s - _score_tensor(det_lv)).abs().max()):.3e}")
     assert float((got_s - _score_tensor(det_lv)).abs().max()) <= 1e-4
+    safe = _assert_all_safe_images(d1, c1, exp, _score_tensor(det_lv), 0.4, cand, exp_index=pos,
+                                   what=f"{name}{'+seg' if seg else ''} B=32 seed {seed}", got_scores=got_s)
+    sel = [pos[b] for b in safe][:2]
     # option "winograd" (dense 3x3 stride-1 convs with >= 64 channels as Winograd F(2x2,3x3): yololite_m's six FPN
     # convs, the seg prototype branch): another rounding of the same sums, held to the SAME north_star bounds at
     # full size -- all candidate scores within 1e-4 of the oracle, sampled detections equal after rounding

@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void yl_se_pool_kernel(YlSeP p) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (pl < PL && cg < C4)
       for (int i = pix0 + pl; i < pix1; i += PL) s += yl_ld4(xb + (size_t)i * p.C + 4 * cg);
-    if (PL == 1) {
-      if (cg < C4) *reinterpret_cast<f32x4*>(out + 4 * cg) = s;
+    if (PL == 1) {                                 // (threads beyond G have pl == 1: they hold zeros and must not store)
+      if (pl == 0 && cg < C4) *reinterpret_cast<f32x4*>(out + 4 * cg) = s;
       continue;
     }
     __syncthreads();
