@@ -161,6 +161,14 @@ def test_squeeze_excite_gate_is_deterministic_and_batch_invariant():
     ref = torch.sigmoid(r @ torch.from_numpy(L.w2.reshape(L.cin, L.cout)).double().T + torch.from_numpy(L.b2).double())
     assert float((g - ref).abs().max()) < 2e-6
     ctx.set_option("reuse_slots", 1)
+    # the partial sums normally come out of the depthwise launch itself (yl_dw_tile_kernel<.., POOL>); with the tiled
+    # depthwise kernel switched off the stand-alone pool pass runs: another partition of the same sum
+    ctx.set_option("dev_select", _lib.DEV_DW_TILE_OFF)
+    for u, v in zip(a, m(x)):
+        assert float((u - v).abs().max()) <= 2e-5 and not torch.equal(u, v)
+    ctx.set_option("dev_select", 0)
+    for u, v in zip(a, m(x)):
+        assert torch.equal(u, v)
 
 
 def test_forward_decoded_is_forward_plus_decode():
@@ -268,7 +276,7 @@ def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_n", 3, 320), ("edge_n", 2, 640), ("edge_n", 3, 384), ("edge_n", 5, 128),
-                                      ("edge_m", 2, 320), ("yololite_m", 1, 256)])
+                                      ("edge_m", 2, 320), ("yololite_m", 1, 256), ("yololite_m_v2", 2, 256)])
 def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
     """Alternative kernels of yl_convc.hip sum every output's k blocks in the same order as the kernels they replace
     -> identical bits.  "tile_m" 6: wave-autonomous 1x1 / depthwise kernels and the streamed dense 3x3 kernel OFF; 7:
@@ -290,7 +298,7 @@ def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
         ctx.set_option("tile_m", 0)
         ctx.set_option("dev_select", 0)
         for u, v in zip(a, b):
-            if name == "yololite_m" and hint == 6:
+            if name.startswith("yololite_m") and hint == 6:
                 assert torch.allclose(u, v, atol=2e-5, rtol=1e-5), (hint, float((u - v).abs().max()))
             else:
                 assert torch.equal(u, v), hint

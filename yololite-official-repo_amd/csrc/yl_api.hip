@@ -608,6 +608,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
   }
   std::vector<unsigned char> prod(c->slots.size(), 0);     // lane that produced each slot
   bool side_used = false;
+  int pooled_slot = -1, pooled_P = 0;                      // slot whose partial channel sums the last depthwise launch left
   auto params = [&](size_t i, YlConvP& p) {
     layer_params(c, c->layers[i], b0, B, x, level_out, p);
     const yl_layer& d = c->layers[i].d;
@@ -718,11 +719,29 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         sp.x = p.x; sp.gate = p.out;
         sp.w1 = L.wp; sp.b1 = L.bias; sp.w2 = L.w2p; sp.b2 = L.b2;
         sp.B = B; sp.HW = L.in_h * L.in_w; sp.C = d.cin; sp.RD = d.cout; sp.act = d.act;
-        sp.P = yl_se_parts(sp.HW, sp.C);
+        const bool pooled = pooled_slot == d.in_slot;        // the depthwise launch in front left the partial sums
+        sp.P = pooled ? pooled_P : yl_se_parts(sp.HW, sp.C);
         int ch = 0;                                          // the chunk arena these images live in
         while (ch + 1 < c->plan_n && b0 >= c->plan_b0[ch + 1]) ++ch;
         sp.partial = c->se_scratch[ch] + (size_t)(b0 - c->plan_b0[ch]) * c->se_unit;
-        e = yl_launch_se(sp, ls);
+        e = yl_launch_se(sp, pooled, ls);
+        break;
+      }
+      case YL_OP_DW: {
+        // feeding a squeeze-excite gate next (efficientnetv2 MBConv): pool in the same launch
+        pooled_slot = -1;
+        if (i + 1 < lend && c->layers[i + 1].d.op == YL_OP_SE && c->layers[i + 1].d.in_slot == d.out_slot && d.res_slot < 0 &&
+            !c->opt_bf16 && !(c->opt_dev & YL_DEV_DW_TILE_OFF)) {
+          const int wpi = yl_dw_pool_wpi(d.k, d.stride, d.cin, d.cout, c->layers[i].out_h, c->layers[i].out_w);
+          if (wpi > 0 && c->se_unit >= (size_t)wpi * d.cin) {
+            int ch = 0;
+            while (ch + 1 < c->plan_n && b0 >= c->plan_b0[ch + 1]) ++ch;
+            p.pool = c->se_scratch[ch] + (size_t)(b0 - c->plan_b0[ch]) * c->se_unit;
+            p.pool_wpi = wpi;
+            pooled_slot = d.out_slot; pooled_P = wpi;
+          }
+        }
+        e = yl_launch_dw(p, ls);
         break;
       }
       case YL_OP_STEM: e = yl_launch_stem(p, ls); break;
@@ -1133,12 +1152,15 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
         return bad("squeeze-excite: plain layer fields only");
       L.in_h = si.h; L.in_w = si.w; L.out_h = L.out_w = 1;
       std::vector<float> w1(l.w, l.w + (size_t)l.cout * l.cin), b1(l.b, l.b + l.cout);
-      std::vector<float> w2(l.w2, l.w2 + (size_t)l.cin * l.cout), b2(l.b2, l.b2 + l.cin);
+      std::vector<float> w2((size_t)l.cin * l.cout), b2(l.b2, l.b2 + l.cin);
+      for (int cc = 0; cc < l.cin; ++cc)                       // conv_expand [cin][cout] -> [cout][cin]
+        for (int j = 0; j < l.cout; ++j) w2[(size_t)j * l.cin + cc] = l.w2[(size_t)cc * l.cout + j];
       yl_status s2;
       if ((s2 = upload(c, w1, &L.wp)) != YL_OK || (s2 = upload(c, b1, &L.bias)) != YL_OK ||
           (s2 = upload(c, w2, &L.w2p)) != YL_OK || (s2 = upload(c, b2, &L.b2)) != YL_OK)
         return s2;
-      const size_t unit = (size_t)yl_se_parts(si.h * si.w, l.cin) * l.cin;
+      // scratch: partial sums of the stand-alone pool pass, or of the depthwise launch that produces the tensor (<= 64 each)
+      const size_t unit = (size_t)64 * l.cin;
       if (unit > c->se_unit) c->se_unit = unit;
       L.d.w = L.d.b = L.d.dw_w = L.d.dw_b = nullptr;
       L.d.w2 = L.d.b2 = L.d.w3 = L.d.b3 = nullptr;

@@ -932,7 +932,10 @@ __global__ __launch_bounds__(256) void yl_dw_kernel(YlConvP p) {
 // pixels (coalesced 16-byte loads); a workgroup = 64 channel quads x 4 pixel blocks, persistent over the pixel
 // blocks with its K*K x 256 tap weights (+ bias) in LDS.  Taps outside the image read the zero buffer and are
 // accumulated in the same (dy, dx) order as yl_dw_kernel: bit-identical.
-template <int K, int S>
+// POOL (squeeze-excite producer): waves are dealt to IMAGES -- wave gw = (b, r) walks the blocks r, r + WPI, ... of image
+// b only -- and each lane also sums its 4 channels of the activated outputs it stores, in block / row / column order;
+// the per-wave sums go to pool[b][r][C].  Same arithmetic per output: the tensor is bit-identical to the plain launch.
+template <int K, int S, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
   constexpr int TX = 4, TY = 2;
   constexpr int COLS = (TX - 1) * S + K, ROWS = (TY - 1) * S + K;
@@ -956,7 +959,16 @@ __global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
   const long zdelta = p.zeros - p.x;
   const float* wq = wl + lane * 4;
   const f32x4 bias = *reinterpret_cast<const f32x4*>(wq + K * K * 256);
-  for (long blk = (long)blockIdx.y * 4 + wave; blk < nblk; blk += (long)gridDim.y * 4) {
+  // plain: blocks of the whole batch dealt round-robin to the waves; POOL: wave (pb, pr) of image pb takes every
+  // pool_wpi-th block of that image
+  const int pgw = (int)blockIdx.y * 4 + wave;
+  const int pb = POOL ? pgw / p.pool_wpi : 0, pr = POOL ? pgw - pb * p.pool_wpi : 0;
+  if (POOL && pb >= p.B) return;
+  const long blk_lo = POOL ? (long)pb * byn * bxn + pr : (long)blockIdx.y * 4 + wave;
+  const long blk_hi = POOL ? (long)(pb + 1) * byn * bxn : nblk;
+  const long blk_step = POOL ? (long)p.pool_wpi : (long)gridDim.y * 4;
+  f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+  for (long blk = blk_lo; blk < blk_hi; blk += blk_step) {
     const int b = (int)(blk / (byn * bxn));
     const int r0 = (int)(blk - (long)b * byn * bxn);
     const int by = r0 / bxn, bx = r0 - by * bxn;
@@ -1032,10 +1044,12 @@ __global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
         f32x4 s4 = yl_act4(acc[t][j], p.act);
         const size_t o = (((size_t)b * OH + oy) * OW + ox) * p.N + c;
         if (p.res) s4 += yl_ld4(p.res + o);
+        if (POOL) psum += s4;
         *reinterpret_cast<f32x4*>(p.out + o) = s4;
       }
     }
   }
+  if (POOL) *reinterpret_cast<f32x4*>(p.pool + ((size_t)pb * p.pool_wpi + pr) * C + c) = psum;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1429,9 +1443,26 @@ hipError_t yl_launch_stem(const YlConvP& p0, hipStream_t st) {
   return hipGetLastError();
 }
 
+// waves per image of the pooling launch: ~4 blocks of 4x2 pixels per wave, at most 64 (the gate sums them serially)
+#if !YL_BF16
+int yl_dw_pool_wpi(int k, int stride, int cin, int n, int oh, int ow) {
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2) || (cin & 3) || n != cin || oh < 1 || ow < 1) return 0;
+  const long per = (long)((oh + 1) / 2) * ((ow + 3) / 4);
+  long w = (per + 3) / 4;
+  if (w > 64) w = 64;
+  if (w < 1) w = 1;
+  return (int)w;
+}
+#endif
+
 template <int K, int S>
 static hipError_t yl_launch_dw_tile(const YlConvP& p, hipStream_t st) {
   const int gx = (p.Cin + 255) / 256;
+  if (p.pool) {
+    const long waves = (long)p.B * p.pool_wpi;
+    hipLaunchKernelGGL((yl_dw_tile_kernel<K, S, true>), dim3((unsigned)gx, (unsigned)((waves + 3) / 4)), dim3(256), 0, st, p);
+    return hipGetLastError();
+  }
   const long nblk = (long)p.B * ((p.OH + 1) / 2) * ((p.OW + 3) / 4);
   long gy = (long)8 * YL_NUM_CU / gx;                         // ~8 workgroups per CU in flight, persistent over the rest
   if (gy > (nblk + 3) / 4) gy = (nblk + 3) / 4;
@@ -1441,7 +1472,8 @@ static hipError_t yl_launch_dw_tile(const YlConvP& p, hipStream_t st) {
 }
 
 hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st) {
-  const bool tile_off = (p.dev & YL_DEV_DW_TILE_OFF) != 0;       // developer A/B (yl_set_option "dev_select")
+  const bool tile_off = (p.dev & YL_DEV_DW_TILE_OFF) != 0 && !p.pool;   // developer A/B (yl_set_option "dev_select")
+  if (p.pool && (p.res || p.pool_wpi != yl_dw_pool_wpi(p.k, p.stride, p.Cin, p.N, p.OH, p.OW) || p.pool_wpi < 1)) return hipErrorInvalidValue;
   if (!tile_off && (p.Cin & 3) == 0 && p.N == p.Cin) {
     if (p.k == 3 && p.stride == 1) return yl_launch_dw_tile<3, 1>(p, st);
     if (p.k == 3 && p.stride == 2) return yl_launch_dw_tile<3, 2>(p, st);

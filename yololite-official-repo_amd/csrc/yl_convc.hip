@@ -388,7 +388,9 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwc_kernel(YlConvMulti mp) {
 // weights), ~70 VGPRs, so 6-8 waves per SIMD cover each other's load latency and MFMA dependency chains, and the
 // launch has thousands of waves instead of a few hundred.  Same k order, same epilogues as yl_conv_mfma_kernel:
 // bit-identical results.
-template <int NTW, int MT, bool DEC>
+// SC: the input is multiplied by a squeeze-excite gate [B][Cin] (YlConvP::scale) in the B-operand path -- x * gate in one
+// fp32 rounding, then the GEMM (timm: `x * gate` feeds conv_pwl).
+template <int NTW, int MT, bool DEC, bool SC = false>
 __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nchunk) {
   YL_SELECT_PROBLEM_C(mp)                                   // level-batched launches: block ranges per problem
   (void)gx;
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
   const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wp);
   YlPix px[MT];
   const float* xrow[MT];
+  const float* srow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     size_t lin = (size_t)mg * (MT * 16) + mt * 16 + pl;
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
     if (!px[mt].valid) lin = (size_t)M - 1;
     px[mt].lin = lin;
     px[mt].b = 0; px[mt].oy = 0; px[mt].ox = 0;
-    if (DEC || p.up) {                                      // only the upsample-add / decode epilogues need coordinates
+    if (DEC || SC || p.up) {                                // only the upsample-add / decode epilogues / the gate need coordinates
       const int ohw = p.OH * p.OW;
       const int b = (int)(lin / ohw);
       const int rem = (int)(lin - (size_t)b * ohw);
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
       px[mt].ox = rem - px[mt].oy * p.OW;
     }
     xrow[mt] = xin + lin * Cin + 4 * kq;
+    srow[mt] = SC ? p.scale + (size_t)px[mt].b * Cin + 4 * kq : nullptr;
   }
   // n-tiles beyond the layer's last one (partial last chunk): read the last tile's weights, never stored
   int wofs[NTW];
@@ -463,7 +467,10 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) a[u][nt] = wg[(size_t)kb * NTtot * 64 + wofs[nt]];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) bq[u][mt] = yl_ld4(cok ? xrow[mt] + kb * 16 : p.zeros);
+      for (int mt = 0; mt < MT; ++mt) {
+        bq[u][mt] = yl_ld4(cok ? xrow[mt] + kb * 16 : p.zeros);
+        if (SC) bq[u][mt] *= yl_ld4(cok ? srow[mt] + kb * 16 : p.zeros);
+      }
     }
     (void)cin4;
 #pragma unroll
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
   else yl_epi_fast<NTW, MT>(p, acc, px, nt0, kq, lo, hi, true);
 }
 
-template <int NTW, int MT, bool DEC = false>
+template <int NTW, int MT, bool DEC = false, bool SC = false>
 static hipError_t pwt_go(YlConvMulti& m, int nchunk, hipStream_t st) {
   int at = 0;
   for (int k = 0; k < m.n; ++k) {
@@ -488,7 +495,7 @@ static hipError_t pwt_go(YlConvMulti& m, int nchunk, hipStream_t st) {
     at += m.p[k].nblk;
   }
   if (m.n == 1) m.p[0].nblk = 0;                                 // single problem: the whole grid (YL_SELECT_PROBLEM_C)
-  hipLaunchKernelGGL((yl_conv_pwt_kernel<NTW, MT, DEC>), dim3((unsigned)at), dim3(256), 0, st, m, nchunk);
+  hipLaunchKernelGGL((yl_conv_pwt_kernel<NTW, MT, DEC, SC>), dim3((unsigned)at), dim3(256), 0, st, m, nchunk);
   return hipGetLastError();
 }
 
@@ -502,7 +509,8 @@ hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st) {
   long Mtot = 0;
   for (int k = 0; k < n; ++k) {
     const YlConvP& p = ps[k];
-    if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || p.scale) return hipErrorNotSupported;
+    if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift) return hipErrorNotSupported;
+    if (p.scale && (n != 1 || p.dec_boxes)) return hipErrorNotSupported;      // gated input: single plain layer
     const bool dec = p.dec_boxes && !p.dec_raw;
     if ((p.N & 3) && !dec) return hipErrorNotSupported;
     if (p.dec_boxes && !dec) return hipErrorNotSupported;
@@ -525,6 +533,14 @@ hipError_t yl_launch_conv_pwt_multi(const YlConvP* ps, int n, hipStream_t st) {
       case 3: return pwt_go<3, 1, true>(m, nchunk, st);
       case 4: return pwt_go<4, 1, true>(m, nchunk, st);
       default: return two ? pwt_go<6, 2, true>(m, nchunk, st) : pwt_go<6, 1, true>(m, nchunk, st);
+    }
+  }
+  if (p.scale) {
+    switch (ntw) {
+      case 1: return pwt_go<1, 1, false, true>(m, nchunk, st);
+      case 2: return pwt_go<2, 1, false, true>(m, nchunk, st);
+      case 3: return pwt_go<3, 1, false, true>(m, nchunk, st);
+      default: return pwt_go<4, 1, false, true>(m, nchunk, st);
     }
   }
   switch (ntw) {
@@ -1069,7 +1085,7 @@ hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
 // activation fragment of the next k-step requested before the MFMAs of this one; a wave reads its A fragments from
 // LDS in groups of <= 7 (28 VGPRs).  Per 16 pixels and k-step: one L1/L2 load + NT LDS reads for 4 NT MFMAs.  Same k
 // order (channel blocks ascending, four sub-steps each) and epilogues as yl_conv_pwt_kernel: bit-identical results.
-template <int NT, int NW>
+template <int NT, int NW, bool SC = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(YlConvP p) {
   constexpr int CH = 2;                                      // k-steps per weight chunk
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
@@ -1124,7 +1140,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
       if (!px[0].valid) lin = (size_t)M - 1;
       px[0].lin = lin;
       px[0].b = 0; px[0].oy = 0; px[0].ox = 0;
-      if (p.up) {                                            // only the upsample-add epilogue needs coordinates
+      if (SC || p.up) {                                      // only the upsample-add epilogue / the gate need coordinates
         const int b = (int)(lin / ohw);
         const int rem = (int)(lin - (size_t)b * ohw);
         px[0].b = b;
@@ -1133,6 +1149,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
       }
     }
     const float* xrow = xin + px[0].lin * Cin + 4 * kq;
+    const float* srow = SC ? p.scale + (size_t)px[0].b * Cin + 4 * kq : nullptr;    // squeeze-excite gate of the pixel's image
     f32x4 acc[1][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1154,7 +1171,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
     }
     auto fetch = [&](int kb) {
       const bool ok = kb * 16 + 4 * kq < Cin;                 // channel tail of the last block: zeros
-      return yl_ld4(ok ? xrow + kb * 16 : p.zeros);
+      f32x4 v = yl_ld4(ok ? xrow + kb * 16 : p.zeros);
+      if (SC) v *= yl_ld4(ok ? srow + kb * 16 : p.zeros);     // x * gate (one rounding), then the GEMM
+      return v;
     };
     f32x4 xq = fetch(0);
     for (int c = 0; c < NC; ++c, ++gchunk) {
@@ -1202,15 +1221,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
 
 template <int NT, int NW>
 static hipError_t pws_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
-  if (attr_only)
+  if (attr_only) {
+    const hipError_t e = hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  }
   YlConvP p = p0;
   p.ntiles = (int)(((long)p.M + 16 * NW - 1) / (16 * NW));
   const size_t lds = (size_t)2 * 2 * NT * 1024;
   int gx = yl_resident_blocks_n(yl_conv_pws_kernel<NT, NW>, NW * 64, lds) & ~7;
   const int gy = (p.NTtot + NT - 1) / NT;
   while (gx > 8 && gx - 8 >= p.ntiles * gy) gx -= 8;
-  hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
+  if (p.scale) hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW, true>), dim3(gx), dim3(NW * 64), lds, st, p);
+  else hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
   return hipGetLastError();
 }
 
@@ -1226,7 +1249,7 @@ static hipError_t pws_nw(const YlConvP& p, hipStream_t st, bool eight, bool attr
 // plain 1x1 stride-1 layers (N % 4 == 0, no decode epilogue) with enough channels on both sides that the weight
 // stream pays: K >= 80 and >= 6 n-tiles.  hipErrorNotSupported otherwise (yl_conv_pwt_kernel runs the layer).
 hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
-  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || (p.N & 3) || p.dec_boxes || p.scale) return hipErrorNotSupported;
+  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || (p.N & 3) || p.dec_boxes) return hipErrorNotSupported;
   if ((p.dev & YL_DEV_PWS_OFF) || p.KB < 5 || p.NTtot < 6) return hipErrorNotSupported;     // (dev: A/B runs)
   // n-tiles per item, from {6..13}: the makespan of the launch in MFMA units -- (16-pixel x n-group) wave items dealt
   // to 1024 SIMDs, each NT x KB x 4 MFMAs long -- with a penalty when fewer than 1.5 waves per SIMD exist (one wave

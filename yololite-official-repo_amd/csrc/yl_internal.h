@@ -110,6 +110,11 @@ struct YlConvP {
   const float* scale;
   // developer kernel-selection word of the context (yl_set_option "dev_select"; 0 in production): YL_DEV_*
   unsigned dev;
+  // stand-alone depthwise conv feeding a squeeze-excite gate: the launch also leaves per-image partial channel sums of its
+  // (activated) output, pool[b][r][C] for r < pool_wpi -- wave (b, r) owns every pool_wpi-th 4x2 pixel block of image b, so
+  // the partials are a fixed function of the shape (deterministic) and the gate needs no pass over the tensor.  nullptr = off
+  float* pool;
+  int pool_wpi;
 };
 
 // YlConvP::dev -- developer kernel-selection switches (A/B runs, bitwise kernel-equivalence tests); per context, never
@@ -129,13 +134,14 @@ struct YlSeP {
   float* partial;        // [B][P][C] scratch
   const float* w1;       // [RD][C]
   const float* b1;       // [RD]
-  const float* w2;       // [C][RD]
+  const float* w2;       // [RD][C] (transposed at upload: coalesced reads in the expand FC)
   const float* b2;       // [C]
   float* gate;           // [B][C]
   int B, HW, C, RD, P, act;
 };
-hipError_t yl_launch_se(const YlSeP& p, hipStream_t st);
+hipError_t yl_launch_se(const YlSeP& p, bool pooled, hipStream_t st);   // pooled: p.partial already holds P partials per image
 int yl_se_parts(int HW, int C);            // partial sums per image the pool pass produces for this shape
+int yl_dw_pool_wpi(int k, int stride, int cin, int n, int oh, int ow);   // > 0: yl_launch_dw can pool (waves per image), else 0
 
 // Up to 4 independent convolutions of identical kernel configuration in ONE launch (the FPN smooth blocks,
 // head trunks and head outputs of all pyramid levels): every block serves one problem, the grid is split in

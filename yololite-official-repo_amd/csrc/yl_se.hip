@@ -12,7 +12,9 @@
 //   yl_se_pool_kernel   grid (P, B) x 256 threads: workgroup (p, b) sums pixels [p*HW/P, (p+1)*HW/P) of image b for all C
 //                       channels; thread = (pixel lane, float4 channel group), coalesced 16-byte loads along C, the
 //                       pixel lanes reduced through LDS in lane order.  HBM-bound: one read of the tensor.
-//   yl_se_gate_kernel   grid (B) x 256 threads: mean = (sum of the P partials) / HW; reduce FC (one wave per output,
+//                       Only a fallback: when the tensor comes from a stand-alone depthwise launch (always, in the
+//                       efficientnetv2 blocks) that launch leaves the partial sums itself (yl_dw_tile_kernel<.., POOL>).
+//   yl_se_gate_kernel   grid (B) x 1024 threads: mean = (sum of the P partials) / HW; reduce FC (one wave per output,
 //                       lanes across C, butterfly sum) + activation; expand FC (thread per channel, RD <= 256 terms) +
 //                       sigmoid.  Latency-bound, a few KB per image.
 #include "yl_internal.h"
@@ -63,20 +65,23 @@ __global__ __launch_bounds__(256) void yl_se_pool_kernel(YlSeP p) {
   }
 }
 
-__global__ __launch_bounds__(256) void yl_se_gate_kernel(YlSeP p) {
+// 1024 threads per image: the mean (P partials in index order), the reduce FC (one wave per output row at a time, lanes
+// across C, butterfly sum: a fixed order) and the expand FC (thread per channel; w2 is stored TRANSPOSED [RD][C] so the RD
+// reads of a wave are coalesced rows).
+__global__ __launch_bounds__(1024) void yl_se_gate_kernel(YlSeP p) {
   __shared__ float mean[YL_SE_MAXC];
   __shared__ float rd[YL_SE_MAXRD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const float* part = p.partial + (size_t)b * p.P * p.C;
   const float hw = (float)p.HW;
-  for (int c = tid; c < p.C; c += 256) {
+  for (int c = tid; c < p.C; c += 1024) {
     float s = part[c];
     for (int q = 1; q < p.P; ++q) s += part[(size_t)q * p.C + c];
     mean[c] = s / hw;
   }
   __syncthreads();
-  for (int j = wave; j < p.RD; j += 4) {
+  for (int j = wave; j < p.RD; j += 16) {
     const float* w = p.w1 + (size_t)j * p.C;
     float s = 0.0f;
     for (int c = lane; c < p.C; c += 64) s = fmaf(w[c], mean[c], s);
@@ -84,18 +89,17 @@ __global__ __launch_bounds__(256) void yl_se_gate_kernel(YlSeP p) {
     if (lane == 0) rd[j] = yl_act1(s + p.b1[j], p.act);
   }
   __syncthreads();
-  for (int c = tid; c < p.C; c += 256) {
-    const float* w = p.w2 + (size_t)c * p.RD;
+  for (int c = tid; c < p.C; c += 1024) {
     float s = 0.0f;
-    for (int j = 0; j < p.RD; ++j) s = fmaf(w[j], rd[j], s);
+    for (int j = 0; j < p.RD; ++j) s = fmaf(p.w2[(size_t)j * p.C + c], rd[j], s);
     p.gate[(size_t)b * p.C + c] = yl_sigmoid(s + p.b2[c]);
   }
 }
 
-hipError_t yl_launch_se(const YlSeP& p, hipStream_t st) {
+hipError_t yl_launch_se(const YlSeP& p, bool pooled, hipStream_t st) {
   if (p.C < 4 || (p.C & 3) || p.C > YL_SE_MAXC || p.RD < 1 || p.RD > YL_SE_MAXRD || p.HW < 1 || p.P < 1 || p.B < 1)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(yl_se_pool_kernel, dim3(p.P, p.B), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(yl_se_gate_kernel, dim3(p.B), dim3(256), 0, st, p);
+  if (!pooled) hipLaunchKernelGGL(yl_se_pool_kernel, dim3(p.P, p.B), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(yl_se_gate_kernel, dim3(p.B), dim3(1024), 0, st, p);
   return hipGetLastError();
 }
