@@ -269,18 +269,38 @@ def bench_tracker(args):
     print(json.dumps(out))
 
 
+def wino_eligible(L):
+    """the predicate of yl_create (yl_api.hip: the layers that get a Winograd weight image)"""
+    return (L.op == 1 and L.k == 3 and L.stride == 1 and L.dw_k == 0 and L.c2 == 0 and L.c3 == 0 and L.pad_t == 1 and L.pad_l == 1
+            and L.in_shift == 0 and L.cin >= 64 and L.cout >= 64 and L.cout % 4 == 0
+            and L.head_level < 0 and L.res_slot < 0 and L.up_slot < 0)
+
+
+def wino_layers(prog, mode):
+    """indices of the layers option "winograd" = mode runs as Winograd F(2x2,3x3): 1 = every eligible layer, 2 (the
+    library default) = the eligible layers on the largest grid they occur on"""
+    el = [i for i, L in enumerate(prog.layers) if wino_eligible(L)]
+    if mode == 1 or not el:
+        return set(el) if mode else set()
+    if mode != 2:
+        return set()
+    hw = lambda i: prog.slots[prog.layers[i].out_slot][0] * prog.slots[prog.layers[i].out_slot][1]
+    top = max(hw(i) for i in el)
+    return {i for i in el if hw(i) >= top}
+
+
 def kernel_family(L, winograd=False):
     """Kernel the dispatcher (yl_launch_conv_multi, yl_conv.hip / yl_convc.hip) picks for a fused layer of the program:
-    a label for the roofline object, the rocprofv3 summaries under profiles/ carry the exact instantiation."""
+    a label for the roofline object, the rocprofv3 summaries under profiles/ carry the exact instantiation.
+    winograd: this layer runs as Winograd (see wino_layers)."""
     if L.op == 3:
         return "yl_stemblock_kernel"
+    if L.op == 4:
+        return "yl_se_gate_kernel"
     if L.op != 1:
-        return "yl_stem_mfma_kernel" if L.op == 0 else "yl_dw_kernel"
+        return "yl_stem_mfma_kernel" if L.op == 0 else "yl_dw_tile_kernel"
     nt, kb = -(-L.cout // 16), -(-L.cin // 16)
-    # the predicate of yl_create (yl_api.hip: the layers that get a Winograd weight image)
-    if (winograd and L.k == 3 and L.stride == 1 and L.dw_k == 0 and L.c2 == 0 and L.pad_t == 1 and L.pad_l == 1
-            and L.in_shift == 0 and L.cin >= 64 and L.cout >= 64 and L.cout % 4 == 0
-            and L.head_level < 0 and L.res_slot < 0 and L.up_slot < 0):
+    if winograd and wino_eligible(L):
         return "yl_conv_wino_kernel"
     if L.dw_k == 0:
         if L.k == 1:
@@ -496,7 +516,8 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     k = int(np.argmax(lay))
     L = prog.layers[k]
     flops = 2.0 * L.macs * B
-    fam = kernel_family(L, bool(args.winograd))
+    wl_set = wino_layers(prog, args.winograd)
+    fam = kernel_family(L, k in wl_set)
     wino = "yl_conv_wino_kernel" in fam
     flops_direct = flops
     if wino:                      # Winograd F(2x2,3x3) executes 16 multiplications where the direct conv has 36
@@ -517,8 +538,7 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     roof["algorithmic_flops_per_launch"] = flops
     roof["algorithmic_bytes_per_launch"] = byts
     # executed multiplications of the whole forward: Winograd layers count 16/36 of their direct-conv MACs
-    net_macs = sum(l.macs * (16.0 / 36.0 if "yl_conv_wino_kernel" in kernel_family(l, bool(args.winograd)) else 1.0)
-                   for l in prog.layers)
+    net_macs = sum(l.macs * (16.0 / 36.0 if i in wl_set else 1.0) for i, l in enumerate(prog.layers))
     net_flops = 2.0 * net_macs * B
     fwd_ms = float(lay.sum())
     out = {
@@ -531,7 +551,8 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
                    "images_per_sec_max": round(float(rates.max()), 1), "images_per_sec_first": round(float(rates[0]), 1)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 operands / f32 accumulate and storage (reduced-precision mode, not the headline)" if args.bf16 else "f32",
-        "options": {"winograd": int(args.winograd)},
+        "options": {"winograd": int(args.winograd),
+                    "winograd_layers": [prog.layers[i].name for i in sorted(wl_set)]},
         "data": "synthetic",
         "config": {"workload": f"{model_name} {'detector+instance-seg head' if seg else 'detector'} {S}x{S} C=80 batch={B}/GPU, forward+decode+per-class NMS{'+masks' if seg else ''} "
                                f"(conf {args.conf}, iou {args.iou}), input resident in HBM"
@@ -593,8 +614,10 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="extra context option name=value (developer A/B), repeatable")
     ap.add_argument("--lanes", type=int, default=0, help="side-stream lane for the coarse-level neck/head layers")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16-MFMA compute mode (f4; NOT the headline: reduced precision)")
-    ap.add_argument("--winograd", type=int, default=0, help="1: dense 3x3 stride-1 convs (>= 64 channels) as Winograd F(2x2,3x3): "
-                    "2.25x fewer MACs, results within 1e-4 of the direct convolution but not bit-identical")
+    ap.add_argument("--winograd", type=int, default=2, help="dense 3x3 stride-1 convs (>= 64 channels) as Winograd F(2x2,3x3), 2.25x "
+                    "fewer MACs: 2 (library default) = only those on the largest grid (the finest level's smooth block), 1 = all, "
+                    "0 = direct convolution everywhere.  Score error vs the oracle measured equal for all three "
+                    "(profiles/r04_winograd_margin.json)")
     ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3) | track (tracker bank, f4)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the block of --steps timed steps until this much "
                     "step time has been measured (value = the median block)")
@@ -622,15 +645,17 @@ def main():
 
     out = measure_predict(args, args.model, args.batch, args.seg, dev, rank, world, gather=(world > 1 or force_coll),
                           min_seconds=args.min_seconds)
-    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and not args.winograd
+    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and args.winograd == 2
                 and not args.stress and args.img == 640)
     want_other = args.other_configs == 1 or (args.other_configs == -1 and headline and world == 1 and not force_coll)
     if rank == 0:
         meta, sd = out.pop("_cpu")
         if want_other:
-            # BASELINE configs 3 and 4 through the same harness (parity path: winograd 0), each a few seconds
+            # BASELINE configs 3 and 4 (and the published efficientnetv2 yololite_m) through the same harness, library
+            # defaults, each a few seconds
             others = {}
-            for name, (m, b, sg) in {"yololite_m_b32": ("yololite_m", 32, 0), "edge_m_seg_b32": ("edge_m", 32, 1)}.items():
+            for name, (m, b, sg) in {"yololite_m_b32": ("yololite_m", 32, 0), "edge_m_seg_b32": ("edge_m", 32, 1),
+                                     "yololite_m_v2_b32": ("yololite_m_v2", 32, 0)}.items():
                 o = measure_predict(args, m, b, sg, dev, 0, 1, gather=False, min_seconds=min(args.min_seconds, 0.5), max_blocks=8)
                 o.pop("_cpu")
                 others[name] = {k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "p50_ms_per_frame", "blocks", "dtype",

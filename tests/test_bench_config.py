@@ -265,23 +265,31 @@ def test_full_size_configs_3_and_4(name, seg, seed):
     safe = _assert_all_safe_images(d1, c1, exp, _score_tensor(det_lv), 0.4, cand, exp_index=pos,
                                    what=f"{name}{'+seg' if seg else ''} B=32 seed {seed}", got_scores=got_s)
     sel = [pos[b] for b in safe][:2]
-    # option "winograd" (dense 3x3 stride-1 convs with >= 64 channels as Winograd F(2x2,3x3): yololite_m's six FPN
-    # convs, the seg prototype branch): another rounding of the same sums, held to the SAME north_star bounds at
-    # full size -- all candidate scores within 1e-4 of the oracle, sampled detections equal after rounding
-    ctx.set_option("winograd", 1)
+    # Winograd F(2x2,3x3): everything above ran the library default ("winograd" 2: the dense 3x3 layers of the finest
+    # level only).  The other two settings are held to the SAME north_star bounds at full size -- all candidate scores
+    # within 1e-4 of the oracle, sampled detections equal after rounding: 0 = direct convolution everywhere, 1 = all
+    # eligible layers (yololite_m's six FPN convs; for edge_m + seg the prototype branch's first conv is the only one)
     ctx.set_option("graph", 1); ctx.set_option("streams", 2)
-    w = model(x)
-    lw = w[0] if seg else w
-    if seg:                                                        # edge_m: only the prototype branch has eligible convs
-        assert not torch.equal(a[1], w[1]) and float((a[1] - w[1]).abs().max()) <= 1e-4
-    else:
-        assert any(not torch.equal(u, v) for u, v in zip(la, lw))  # the option really selects the other kernel
-    assert float((_score_tensor([t[cand].cpu() for t in lw]) - _score_tensor(det_lv)).abs().max()) <= 1e-4
-    dw_, cw_ = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
-    selw = _safe_images(_score_tensor(det_lv), None, 0.4, range(len(cand)), need=2)
-    for i in selw:
-        _assert_north_star(_rows(dw_, cw_, cand[i]), exp, i)
-    ctx.set_option("winograd", 0)
+    outs = {}
+    for mode in (0, 1):
+        ctx.set_option("winograd", mode)
+        w = model(x)
+        lw = w[0] if seg else w
+        outs[mode] = (w[1].clone() if seg else None, [t.clone() for t in lw])
+        err = float((_score_tensor([t[cand].cpu() for t in lw]) - _score_tensor(det_lv)).abs().max())
+        print(f"[parity {name} seed {seed}] winograd {mode}: max |score - oracle score| {err:.3e}")
+        assert err <= 1e-4
+        dw_, cw_ = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
+        selw = _safe_images(_score_tensor(det_lv), None, 0.4, range(len(cand)), need=2)
+        for i in selw:
+            _assert_north_star(_rows(dw_, cw_, cand[i]), exp, i)
+    if seg:                                                        # edge_m: only the prototype branch has an eligible conv
+        assert not torch.equal(outs[0][0], a[1]) and float((outs[0][0] - a[1]).abs().max()) <= 1e-4
+        assert torch.equal(outs[1][0], a[1])                       # ... which the default already runs as Winograd
+    else:                                                          # the options really select other kernels
+        assert any(not torch.equal(u, v) for u, v in zip(la, outs[0][1]))
+        assert any(not torch.equal(u, v) for u, v in zip(la, outs[1][1]))
+    ctx.set_option("winograd", 2)
     if seg:
         # config 4: image-resolution masks (640 x 640 input grid, no back-map) of the sampled images vs the oracle's
         # restatement on the ORACLE's own levels / prototypes, mask IoU >= 0.999 (north_star); packed == unpacked
