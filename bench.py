@@ -155,6 +155,41 @@ def cpu_baseline(meta, sd, S, conf, iou, budget_s=20.0, B=64):
             "cpu_model": _cpu_model_string(), "logical_cpus": os.cpu_count(), "batch1_infer_flow": b1}
 
 
+def gpu_batch1_flow(meta, sd, S, conf, iou, dev, budget_s=4.0):
+    """The GPU side of the reference's only published protocol (export/infer_onnx.py:136-296, BENCHMARK.md:336-339):
+    batch 1 through the pip API -- YoloLite(checkpoint).predict(frame) on the SAME 480x640 BGR uint8 frame the CPU
+    baseline's batch-1 flow uses: host packing + H2D + letterbox/normalise kernel (pre), forward (infer), decode + NMS +
+    back-map (post), detections copied to the host.  10 warm-up runs, then up to 200 runs / budget_s seconds; pre_ms is wall
+    clock around a stream sync, infer_ms / post_ms are HIP-event intervals (yl_last_timing), total = their sum as in the
+    reference's harness; wall_ms is perf_counter around the whole predict() call (includes the D2H copy of the rows)."""
+    import tempfile
+    from yololite_amd.api import YoloLite
+    m = dict(meta)
+    m["names"] = [f"c{i}" for i in range(int(meta.get("num_classes") or 80))]
+    with tempfile.TemporaryDirectory() as td:
+        ck = os.path.join(td, "bench_model.pt")
+        torch.save({"state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, "meta": m}, ck)
+        yl = YoloLite(ck, device=str(dev))
+    img = np.random.RandomState(7).randint(0, 256, size=(480, 640, 3)).astype(np.uint8)
+    for _ in range(10):
+        r = yl.predict(img, conf=conf, iou=iou)
+    rows = {k: [] for k in ("pre_ms", "infer_ms", "post_ms", "total_ms", "wall_ms")}
+    t_start = time.perf_counter()
+    while len(rows["wall_ms"]) < 200 and (time.perf_counter() - t_start < budget_s or len(rows["wall_ms"]) < 20):
+        t0 = time.perf_counter()
+        r = yl.predict(img, conf=conf, iou=iou)
+        rows["wall_ms"].append((time.perf_counter() - t0) * 1e3)
+        for k in ("pre_ms", "infer_ms", "post_ms", "total_ms"):
+            rows[k].append(r[0]["speed"][k])
+    out = {k: _ms_stats(v) for k, v in rows.items()}
+    out.update(images_per_sec=round(1000.0 / float(np.mean(rows["total_ms"])), 1),
+               images_per_sec_wall=round(1000.0 / float(np.mean(rows["wall_ms"])), 1), runs=len(rows["wall_ms"]), warmup=10,
+               detections=int(len(r[0]["scores"])),
+               flow="480x640 BGR u8 on the host -> YoloLite.predict (pack + H2D + letterbox/normalise kernel -> forward -> "
+                    "decode + per-class NMS + back-map -> rows on the host), batch 1, one chunk, eager launches")
+    return out
+
+
 def synth_coco(n_img, n_cls=80, gt_per_img=8, det_per_img=100, seed=5):
     """COCO-style annotation / detection lists of an evaluation pass (conf 0.001 keeps ~100 dets/img)."""
     r = np.random.RandomState(seed)
@@ -329,7 +364,7 @@ def csrc_digest():
 
 
 PMC_FILES = {("edge_n", 0, 64): "pmc_traffic.json", ("yololite_m", 0, 32): "pmc_traffic_yololite_m_b32.json",
-             ("edge_m", 1, 32): "pmc_traffic_edge_m_seg_b32.json"}
+             ("edge_m", 1, 32): "pmc_traffic_edge_m_seg_b32.json", ("yololite_m_v2", 0, 32): "pmc_traffic_yololite_m_v2_b32.json"}
 
 
 def pmc_traffic(model_name, seg, B, kname, stem_pattern):
@@ -367,6 +402,37 @@ def pmc_traffic(model_name, seg, B, kname, stem_pattern):
     return None, f"no PMC pass under profiles/ was taken on these kernel sources (csrc_sha256 {csrc_digest()})"
 
 
+def traffic_per_step(model_name, seg, B, prog, S, max_out):
+    """HBM-side bytes of ONE yl_predict step from the committed counter passes of exactly these kernel sources
+    (profiles/rNN_pmc_traffic*.json: `per_step` = sum over the step's dispatches of FETCH_SIZE and WRITE_SIZE, taken on
+    predict-only runs: tools/profile_round.sh) against the compulsory bytes of the step: the fp32 input batch, the packed
+    detections and the weights once.  null when no pass matches the sources."""
+    tail = PMC_FILES.get((model_name, int(seg), B))
+    comp = 4.0 * 3 * S * S * B + B * (max_out * 6 * 4 + 4) + 4.0 * sum(
+        sum(int(np.asarray(a).size) for a in (l.w, l.b, l.dw_w, l.dw_b, l.w2, l.b2, l.w3, l.b3) if a is not None) for l in prog.layers)
+    out = {"compulsory_bytes": round(comp), "hbm_bytes": None, "ratio": None, "source": None}
+    if not tail:
+        out["source"] = "no committed PMC pass for this configuration"
+        return out
+    for f in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_" + tail)), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", f)) as fh:
+                j = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        ps = j.get("per_step")
+        if j.get("csrc_sha256") != csrc_digest() or not ps:
+            continue
+        ffac = 0.5
+        t = ps["fetch_kb"] * 1024.0 / ffac + ps["write_kb"] * 1024.0
+        out.update(hbm_bytes=round(t), ratio=round(t / comp, 2),
+                   source=f"profiles/{f} (csrc_sha256 {j['csrc_sha256']}): sum over the {ps['dispatches_per_step']} dispatches of a "
+                          f"step (mean of {ps['steps']} eager one-stream steps) of FETCH_SIZE / {ffac} + WRITE_SIZE")
+        return out
+    out["source"] = f"no PMC pass under profiles/ was taken on these kernel sources (csrc_sha256 {csrc_digest()})"
+    return out
+
+
 def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seconds, max_blocks=60):
     """One configuration of the hot path: build the workload, time per-layer durations eagerly (HIP events around every
     launch), then time BLOCKS of exactly args.steps steps each -- every block bracketed by barrier +
@@ -386,6 +452,8 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     ctx.set_option("streams", args.streams)
     if args.bf16:
         ctx.set_option("mfma_bf16", 1)
+    if args.f16:
+        ctx.set_option("mfma_f16", 1)
     ctx.set_option("lanes", args.lanes)
     ctx.set_option("fuse_decode", args.fuse_decode)
     ctx.set_option("batch_levels", args.batch_levels)
@@ -426,11 +494,14 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    for _ in range(3):                                       # the eager timed path itself, untimed: clocks / caches settle
-        ctx.forward(x, timed=True)
-    reps = 15
-    lay = np.median(np.stack([np.asarray(ctx.forward(x, timed=True)[1]) for _ in range(reps)]), axis=0)   # median: a
-    # host hiccup between two eager launches must not crown a 30 us layer "dominant kernel"
+    reps = args.layer_reps
+    if reps > 0:
+        for _ in range(3):                                   # the eager timed path itself, untimed: clocks / caches settle
+            ctx.forward(x, timed=True)
+        lay = np.median(np.stack([np.asarray(ctx.forward(x, timed=True)[1]) for _ in range(reps)]), axis=0)   # median: a
+        # host hiccup between two eager launches must not crown a 30 us layer "dominant kernel"
+    else:                                                    # counter passes (tools/profile_round.sh): predict steps only
+        lay = np.full(len(prog.layers), 1e-3)
 
     ctx.set_option("graph", args.graph)
     for _ in range(max(args.warmup, 1)):
@@ -512,31 +583,43 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     if rank != 0:
         return None
 
-    # dominant kernel = the fused layer with the largest median duration
+    wl_set = wino_layers(prog, args.winograd)
+
+    def roofline_of(k):
+        """roofline object of fused layer k: executed FLOPs (Winograd layers: 16/36 of the direct MACs) or algorithmic
+        bytes per launch / median eager launch duration against the roof its arithmetic intensity puts it under"""
+        L = prog.layers[k]
+        flops = 2.0 * L.macs * B
+        fam = kernel_family(L, k in wl_set)
+        wino = "yl_conv_wino_kernel" in fam
+        flops_direct = flops
+        if wino:                  # Winograd F(2x2,3x3) executes 16 multiplications where the direct conv has 36
+            flops = flops * 16.0 / 36.0
+        byts = float(L.bytes_in + L.bytes_out) * B
+        ai = flops / byts
+        dur = lay[k] * 1e-3
+        if ai >= RIDGE:
+            roof = {"bound": "mfma", "achieved": round(flops / dur / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": round(byts / dur / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(model_name, seg, B, fam, L.op == 3)
+        roof["kernel"] = f"layer {k} {L.name} ({fam}, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})"
+        if wino:
+            roof["direct_conv_equivalent_tflops"] = round(flops_direct / dur / 1e12, 3)
+        roof["avg_launch_ms"] = round(float(lay[k]), 4)
+        roof["share_of_forward"] = round(float(lay[k] / lay.sum()), 4)
+        roof["algorithmic_flops_per_launch"] = flops
+        roof["algorithmic_bytes_per_launch"] = byts
+        return roof
+
+    # dominant kernel = the fused layer with the largest median duration; worst = the layer furthest below its roof among
+    # those that take >= 3 % of the forward pass (VERDICT r03 item 4)
     k = int(np.argmax(lay))
     L = prog.layers[k]
-    flops = 2.0 * L.macs * B
-    wl_set = wino_layers(prog, args.winograd)
-    fam = kernel_family(L, k in wl_set)
-    wino = "yl_conv_wino_kernel" in fam
-    flops_direct = flops
-    if wino:                      # Winograd F(2x2,3x3) executes 16 multiplications where the direct conv has 36
-        flops = flops * 16.0 / 36.0
-    byts = float(L.bytes_in + L.bytes_out) * B
-    ai = flops / byts
-    dur = lay[k] * 1e-3
-    if ai >= RIDGE:
-        roof = {"bound": "mfma", "achieved": round(flops / dur / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s"}
-    else:
-        roof = {"bound": "hbm", "achieved": round(byts / dur / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
-    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    roof["traffic"], roof["traffic_source"] = pmc_traffic(model_name, seg, B, fam, L.op == 3)
-    roof["kernel"] = f"layer {k} {L.name} ({fam}, cin={L.cin} cout={L.cout} k={L.k} dw={L.dw_k})"
-    if wino:
-        roof["direct_conv_equivalent_tflops"] = round(flops_direct / dur / 1e12, 3)
-    roof["avg_launch_ms"] = round(float(lay[k]), 4)
-    roof["algorithmic_flops_per_launch"] = flops
-    roof["algorithmic_bytes_per_launch"] = byts
+    roof = roofline_of(k)
+    heavy = [i for i in range(len(lay)) if lay[i] >= 0.03 * lay.sum() and prog.layers[i].macs > 0]
+    roof_worst = min((roofline_of(i) for i in heavy), key=lambda r: r["frac"]) if heavy else None
     # executed multiplications of the whole forward: Winograd layers count 16/36 of their direct-conv MACs
     net_macs = sum(l.macs * (16.0 / 36.0 if i in wl_set else 1.0) for i, l in enumerate(prog.layers))
     net_flops = 2.0 * net_macs * B
@@ -550,7 +633,8 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
                    "images_per_sec_min": round(float(rates.min()), 1), "images_per_sec_median": round(float(rates[k_med]), 1),
                    "images_per_sec_max": round(float(rates.max()), 1), "images_per_sec_first": round(float(rates[0]), 1)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 operands / f32 accumulate and storage (reduced-precision mode, not the headline)" if args.bf16 else "f32",
+        "dtype": ("bf16" if args.bf16 else "f16") + " operands / f32 accumulate and storage (reduced-precision mode, not the headline)"
+                 if (args.bf16 or args.f16) else "f32",
         "options": {"winograd": int(args.winograd),
                     "winograd_layers": [prog.layers[i].name for i in sorted(wl_set)]},
         "data": "synthetic",
@@ -564,6 +648,8 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
                    "mean_dets_per_image": round(ndet, 1), "mean_classes_per_image": round(ncls, 1),
                    "max_out": max_out, "dets_dropped": dropped},
         "roofline": roof,
+        "roofline_worst": roof_worst,
+        "traffic_per_step": traffic_per_step(model_name, seg, B, prog, S, max_out),
         "network": {"conv_gflop_per_image": round(2.0 * prog.macs / 1e9, 4), "launches": len(prog.layers),
                     "activation_mb": round(ctx.activation_bytes() / 1e6, 1),
                     "forward_ms_sum_of_layers": round(fwd_ms, 4),
@@ -614,6 +700,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="extra context option name=value (developer A/B), repeatable")
     ap.add_argument("--lanes", type=int, default=0, help="side-stream lane for the coarse-level neck/head layers")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16-MFMA compute mode (f4; NOT the headline: reduced precision)")
+    ap.add_argument("--f16", type=int, default=0, help="1: fp16-MFMA compute mode (the reference's fp16 autocast; NOT the headline)")
     ap.add_argument("--winograd", type=int, default=2, help="dense 3x3 stride-1 convs (>= 64 channels) as Winograd F(2x2,3x3), 2.25x "
                     "fewer MACs: 2 (library default) = only those on the largest grid (the finest level's smooth block), 1 = all, "
                     "0 = direct convolution everywhere.  Score error vs the oracle measured equal for all three "
@@ -621,6 +708,8 @@ def main():
     ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3) | track (tracker bank, f4)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the block of --steps timed steps until this much "
                     "step time has been measured (value = the median block)")
+    ap.add_argument("--layer-reps", type=int, default=15, help="eager per-layer timing passes (HIP events around every launch); 0 = "
+                    "none (counter passes: only yl_predict steps dispatch kernels; roofline fields are then meaningless)")
     ap.add_argument("--other-configs", type=int, default=-1, help="append BASELINE configs 3 and 4 (yololite_m B=32, edge_m+seg "
                     "B=32) as `other_configs`; -1 = only for the default single-GPU headline run")
     args = ap.parse_args()
@@ -645,7 +734,7 @@ def main():
 
     out = measure_predict(args, args.model, args.batch, args.seg, dev, rank, world, gather=(world > 1 or force_coll),
                           min_seconds=args.min_seconds)
-    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and args.winograd == 2
+    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and not args.f16 and args.winograd == 2
                 and not args.stress and args.img == 640)
     want_other = args.other_configs == 1 or (args.other_configs == -1 and headline and world == 1 and not force_coll)
     if rank == 0:
@@ -659,10 +748,13 @@ def main():
                 o = measure_predict(args, m, b, sg, dev, 0, 1, gather=False, min_seconds=min(args.min_seconds, 0.5), max_blocks=8)
                 o.pop("_cpu")
                 others[name] = {k: o[k] for k in ("value", "unit", "steps", "ms_per_step", "p50_ms_per_frame", "blocks", "dtype",
-                                                  "options", "config", "roofline", "network")}
+                                                  "options", "config", "roofline", "roofline_worst", "traffic_per_step", "network")}
                 torch.cuda.empty_cache()
             out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
+            # the reference's published protocol is batch 1 (export/infer_onnx.py, BENCHMARK.md:336-339): GPU side first,
+            # then the CPU baseline (which carries the same flow as batch1_infer_flow)
+            out["gpu_batch1_flow"] = gpu_batch1_flow(meta, sd, args.img, args.conf, args.iou, dev)
             out["cpu_baseline"] = cpu_baseline(meta, sd, args.img, args.conf, args.iou)
     if world > 1 or force_coll or init_only:
         dist.destroy_process_group()

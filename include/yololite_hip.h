@@ -180,7 +180,8 @@ yl_status yl_forward(yl_ctx* ctx, const float* x_dev, int32_t batch, float* cons
  * per-layer durations (ms) in layer_ms[num_layers].  Measurement aid for bench.py (roofline).      */
 yl_status yl_forward_timed(yl_ctx* ctx, const float* x_dev, int32_t batch, float* const* level_out_dev,
                            void* stream, float* layer_ms);
-/* With option "time_split" 1, yl_predict runs as ONE chunk on the caller's stream (no hipGraph) with a HIP event
+/* With option "time_split" 1, yl_predict runs as ONE chunk on the caller's stream (eagerly, or with option "graph" as two
+ * replayed hipGraphs: conv layers | post-processing) with a HIP event
  * before the conv layers, between the last conv layer and the NMS, and after the NMS; this call waits for the last
  * event and returns the two intervals: infer_ms (backbone + neck + heads, decode fused into the head epilogues) and
  * post_ms (per-class NMS + back-map) -- the pre / infer / post split of the reference's timing harness
@@ -222,7 +223,9 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * to bf16 in registers and multiplied on v_mfma_f32_16x16x16_bf16 with fp32 accumulation; tensors stay
  * fp32 in memory.  The reference's counterpart is fp16 autocast in evaluate_model
  * (scripts/helpers/evaluate.py:399,415).  NOT the parity path: results differ from fp32 at the 1e-2
- * relative level.) */
+ * relative level.),
+ * "mfma_f16" (0/1, default 0: the same with fp16 operands on v_mfma_f32_16x16x16_f16 -- 11 mantissa bits instead of 8:
+ * raw logits within 4e-3 of the level maximum; exclusive with "mfma_bf16"). */
 yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
 /* Current value of an option (the library's default if it was never written; values are stored clamped to the
  * option's range, e.g. "streams" 1..4).  YL_ERR_INVALID for an unknown name.  Also "dev_select" (default 0): a word of

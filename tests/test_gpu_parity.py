@@ -213,11 +213,14 @@ def test_option_defaults_and_arena_growth():
     assert ctx.activation_bytes() == one                # capacity only grows, nothing re-allocated on the way back
 
 
+@pytest.mark.parametrize("mode,bound", [("mfma_bf16", 3e-2), ("mfma_f16", 4e-3)])
 @pytest.mark.parametrize("name,B,S", [("edge_n", 2, 320), ("yololite_m", 1, 256)])
-def test_bf16_mfma_mode(name, B, S):
-    """optional reduced-precision mode (operands rounded to bf16, fp32 accumulate, fp32
-    tensors).  Not the parity path: the bound is 3e-2 of the level's largest logit (bf16 has 8 mantissa
-    bits; ~60 layers) and the detections of the fp32 run are reproduced to within a few percent."""
+def test_reduced_precision_mfma_modes(name, B, S, mode, bound):
+    """optional reduced-precision modes (operands rounded to bf16 / fp16 in registers, fp32 accumulate,
+    fp32 tensors).  "mfma_f16" is the counterpart of the reference's fp16 autocast in evaluate_model
+    (scripts/helpers/evaluate.py:399,415).  Not the parity path: the bound is 3e-2 (bf16: 8 mantissa bits; ~60 layers) /
+    4e-3 (fp16: 11 bits) of the level's largest logit, and the detections of the fp32 run are reproduced to within a few
+    percent.  The two modes are exclusive; switching back restores the fp32 bits."""
     meta = zoo_meta(name, 80, S)
     sd = synth_state_dict(meta, seed={"edge_n": 2, "yololite_m": 10}[name], head_noise=2.0)
     x = _x(B, S)
@@ -227,17 +230,22 @@ def test_bf16_mfma_mode(name, B, S):
     ctx = m._ctx_for(S)
     f32 = [o.clone() for o in m(x.to(DEV))]
     _cmp_levels(f32, ref)
-    ctx.set_option("mfma_bf16", 1)
+    ctx.set_option(mode, 1)
+    other = "mfma_f16" if mode == "mfma_bf16" else "mfma_bf16"
+    assert ctx.get_option(mode) == 1 and ctx.get_option(other) == 0
     b16 = m(x.to(DEV))
     differs = False
+    worst = 0.0
     for o, q, r in zip(b16, f32, ref):
         err = (o.cpu() - r).abs().max().item()
-        assert err <= 3e-2 * r.abs().max().item() + 1e-3, (name, err, r.abs().max().item())
+        worst = max(worst, err / r.abs().max().item())
+        assert err <= bound * r.abs().max().item() + 1e-3, (name, err, r.abs().max().item())
         differs |= not torch.equal(o, q)
+    print(f"[{mode} {name}] max logit error / level max: {worst:.2e}")
     assert differs                                              # the mode really switched kernels
     d16, c16 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.1, 0.5, per_class_cap=300, max_out=300)
     c16 = c16.cpu().numpy().copy()
-    ctx.set_option("mfma_bf16", 0)
+    ctx.set_option(mode, 0)
     d32, c32 = ctx.predict(x.to(DEV), _lib.POST_MAIN, 0.1, 0.5, per_class_cap=300, max_out=300)
     c32 = c32.cpu().numpy()
     assert c32.sum() > 50

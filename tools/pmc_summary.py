@@ -28,9 +28,37 @@ if len(sys.argv) > 1 and sys.argv[1] == "--json":
         sha = csrc_digest()
     except Exception:
         sha = None
-    print(json.dumps({"note": "rocprofv3 --pmc, separate passes, eager launches (--graph 0 --streams 1), " + label + "; "
+    # traffic of ONE step: the passes run predict steps only (bench.py --layer-reps 0), so every full-batch dispatch of a
+    # yl_* kernel belongs to a step; dispatches on the 8-image head-calibration batch (< half the kernel's median) are
+    # dropped; steps = the full-batch dispatches of the network's entry kernel (one per step)
+    per_step = None
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    ndisp, steps = 0, 0
+    for path in argv:
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, d in acc.items():
+            if "yl_" not in k:
+                continue
+            for c, v in d.items():
+                if c not in tot:
+                    continue
+                med = statistics.median(v)
+                full = [x for x in v if x >= 0.5 * med]
+                tot[c] += sum(full)
+                if c == "WRITE_SIZE":
+                    ndisp += len(full)
+                    if "yl_stemblock_kernel" in k or "yl_stem_mfma_kernel" in k:
+                        steps = max(steps, len(full))
+    if steps:
+        per_step = {"fetch_kb": tot["FETCH_SIZE"] / steps, "write_kb": tot["WRITE_SIZE"] / steps, "steps": steps,
+                    "dispatches_per_step": round(ndisp / steps, 1)}
+    print(json.dumps({"note": "rocprofv3 --pmc, separate passes, eager launches (--graph 0 --streams 1 --layer-reps 0: predict "
+                              "steps only), " + label + "; "
                               "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 of their bytes (MI355X_MICROARCH.md HBM section)",
-                      "csrc_sha256": sha, "kernels": out}, indent=1))
+                      "csrc_sha256": sha, "per_step": per_step, "kernels": out}, indent=1))
     sys.exit(0)
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(sys.argv[1]) as f:

@@ -23,6 +23,9 @@ class YoloLite:
         dev = torch.device(device if isinstance(device, str) else f"cuda:{device}")
         self.model, self.names, self.img_size = load_model_names_imgsize_from_ckpt(weights, dev)
         self.device = dev
+        # serving loop: the launches of a call are replayed from cached hipGraphs (keyed on the buffers of the call; a
+        # batch-1 forward is 30-odd launches of a few microseconds each -- eager launch overhead would dominate it)
+        self.model._ctx_for(self.img_size).set_option("graph", 1)
 
     @torch.no_grad()
     def predict(self, source: Union[np.ndarray, Sequence[np.ndarray]], device=None, draw: bool = False,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build libyololite_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
-nine translation units (three of them compiled twice: fp32 and bf16-MFMA builds), one shared library with a plain C ABI (include/yololite_hip.h).
+nine translation units (three of them compiled three times: fp32, bf16-MFMA and fp16-MFMA builds), one shared library with a plain C ABI (include/yololite_hip.h).
 
     python yololite-official-repo_amd/csrc/build.py [--force | --asan]
 """
@@ -24,6 +24,10 @@ UNITS = [   # (source, extra flags, object name)
     # bf16-MFMA inference mode: the same two units compiled again under distinct symbol names (yl_dev.h)
     ("yl_conv.hip", ["-DYL_BF16=1"], "yl_conv_bf16.o"),
     ("yl_stemblock.hip", ["-DYL_BF16=1"], "yl_stemblock_bf16.o"),
+    # fp16-MFMA inference mode (the reference's fp16 autocast, scripts/helpers/evaluate.py:399,415): a third compilation
+    ("yl_convc.hip", ["-DYL_BF16=1", "-DYL_F16=1"], "yl_convc_f16.o"),
+    ("yl_conv.hip", ["-DYL_BF16=1", "-DYL_F16=1"], "yl_conv_f16.o"),
+    ("yl_stemblock.hip", ["-DYL_BF16=1", "-DYL_F16=1"], "yl_stemblock_f16.o"),
     # reference-exact fp32 arithmetic in decode/NMS: no fused multiply-add contraction
     ("yl_post.hip", ["-ffp-contract=off"], "yl_post.o"),
     ("yl_pre.hip", ["-ffp-contract=off"], "yl_pre.o"),
@@ -32,7 +36,7 @@ UNITS = [   # (source, extra flags, object name)
     # tracker: float32 scalar arithmetic of the reference's bbox conversions / IoU, op by op
     ("yl_track.hip", ["-ffp-contract=off"], "yl_track.o"),
 ]
-DEPS = ["yl_internal.h", "yl_dev.h", "yl_epi.h", "yl_decode.h", os.path.join("..", "..", "include", "yololite_hip.h")]
+DEPS = ["yl_internal.h", "yl_dev.h", "yl_lp.h", "yl_epi.h", "yl_decode.h", os.path.join("..", "..", "include", "yololite_hip.h")]
 
 
 def _hipcc():

@@ -67,7 +67,7 @@ struct yl_ctx {
   size_t arena_unit = 0;                   // arena bytes per image of a chunk (peak of the live set)
   bool plan_reuse = false;
   int opt_reuse = 1;
-  int opt_time_split = 0;    // yl_predict records HIP events around the conv layers and the NMS (one chunk, eager)
+  int opt_time_split = 0;    // yl_predict records HIP events around the conv layers and the NMS (one chunk; eager or two hipGraphs)
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};
   bool timing_valid = false;
   int opt_pre_norm = 0;      // yl_preprocess: 0 = tools/infer.py arithmetic, 1 = the evaluate path's A.Normalize
@@ -107,7 +107,8 @@ struct yl_ctx {
   int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
   int opt_fuse_head = 1;     // ... and the head trunk (depthwise 3x3 -> 1x1) in the same launch (yl_conv_dpp_kernel)
   int opt_dev = 0;    // developer kernel-selection word (YL_DEV_*, "dev_select"); rides in every YlConvP
-  int opt_bf16 = 0;   // 1: conv / stem-block launches use the bf16-MFMA builds (fp32 storage, fp32 accumulate)
+  int opt_bf16 = 0;   // reduced-precision MFMA mode: 1 = conv / stem-block launches use the bf16-MFMA builds, 2 = the fp16-MFMA
+                      // builds (fp32 storage, fp32 accumulate either way); 0 = fp32 (the parity path)
   // batch chunks run on `opt_streams` internal streams (fork/join around every call): the
   // latency-bound low-resolution layers of one chunk overlap the bandwidth-bound layers of another
   hipStream_t work[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -698,8 +699,9 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
     if (gend - i > 1) {
       YlConvP ps[4];
       for (size_t q = i; q < gend; ++q) params(q, ps[q - i]);
-      const hipError_t e = c->opt_bf16 ? yl_launch_conv_multi_bf16(ps, (int)(gend - i), c->opt_tile_m, st)
-                                       : yl_launch_conv_multi(ps, (int)(gend - i), c->opt_tile_m, st);
+      const hipError_t e = c->opt_bf16 == 1 ? yl_launch_conv_multi_bf16(ps, (int)(gend - i), c->opt_tile_m, st)
+                           : c->opt_bf16 == 2 ? yl_launch_conv_multi_f16(ps, (int)(gend - i), c->opt_tile_m, st)
+                                              : yl_launch_conv_multi(ps, (int)(gend - i), c->opt_tile_m, st);
       if (e != hipSuccess) {
         char b[256];
         snprintf(b, sizeof(b), "layers %zu..%zu batched launch failed: %s", i, gend - 1, hipGetErrorString(e));
@@ -760,8 +762,13 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         break;
       }
       case YL_OP_STEM: e = yl_launch_stem(p, ls); break;
-      case YL_OP_CONV: e = c->opt_bf16 ? yl_launch_conv_bf16(p, c->opt_tile_m, ls) : yl_launch_conv(p, c->opt_tile_m, ls); break;
-      case YL_OP_STEMBLOCK: e = c->opt_bf16 ? yl_launch_stemblock_bf16(p, ls) : yl_launch_stemblock(p, ls); break;
+      case YL_OP_CONV:
+        e = c->opt_bf16 == 1 ? yl_launch_conv_bf16(p, c->opt_tile_m, ls)
+            : c->opt_bf16 == 2 ? yl_launch_conv_f16(p, c->opt_tile_m, ls) : yl_launch_conv(p, c->opt_tile_m, ls);
+        break;
+      case YL_OP_STEMBLOCK:
+        e = c->opt_bf16 == 1 ? yl_launch_stemblock_bf16(p, ls) : c->opt_bf16 == 2 ? yl_launch_stemblock_f16(p, ls) : yl_launch_stemblock(p, ls);
+        break;
       default: e = yl_launch_dw(p, ls); break;
     }
     if (e != hipSuccess) {
@@ -914,6 +921,11 @@ struct Seg { int lo, hi; bool chunked, post; };
 int plan_segments(const yl_ctx* c, const Job& j, int n, Seg* segs) {
   const int L = (int)c->layers.size();
   if (!j.x) { segs[0] = {0, 0, n > 1, true}; return 1; }
+  if (c->opt_time_split && j.cfg) {          // one chunk (chunks_for): conv layers | post-processing, an event between them
+    segs[0] = {0, L, false, false};
+    segs[1] = {L, L, false, true};
+    return 2;
+  }
   if (n > 1 && c->opt_hybrid == 2 && !c->opt_lanes && c->tiny_hi - c->tiny_lo >= 6) {
     int k = 0;
     if (c->tiny_lo > 0) segs[k++] = {0, c->tiny_lo, true, false};
@@ -936,12 +948,10 @@ int plan_segments(const yl_ctx* c, const Job& j, int n, Seg* segs) {
 yl_status run_piece(yl_ctx* c, const Job& j, const Seg& sg, int b0, int bn, hipStream_t st, int chunk) {
   yl_status s = YL_OK;
   const bool fused = j.x && j.cfg && can_fuse_decode(c);
-  const bool timed = c->opt_time_split && j.x && j.cfg && chunk == 0 && bn == j.B && c->ev_t[0];
-  if (timed) hipEventRecord(c->ev_t[0], st);
+  // ("time_split": the events are recorded by walk_plan AROUND the pieces -- conv layers | post-processing -- so that a
+  // piece can also be a replayed hipGraph)
   if (j.x && sg.hi > sg.lo) s = run_layers(c, j.x, b0, bn, j.outs, st, nullptr, chunk, fused ? j.cfg : nullptr, sg.lo, sg.hi);
-  if (timed) hipEventRecord(c->ev_t[1], st);
   if (s == YL_OK && sg.post && j.cfg) s = do_post(c, j.outs, b0, bn, j.cfg, j.dets, j.counts, j.keep_idx, st, fused);
-  if (timed) { hipEventRecord(c->ev_t[2], st); c->timing_valid = true; }
   return s;
 }
 
@@ -962,10 +972,13 @@ yl_status ensure_streams(yl_ctx* c) {
 template <typename F>
 yl_status walk_plan(yl_ctx* c, const Job& j, hipStream_t st, int n, const Seg* segs, int nseg, F&& piece) {
   const int base = j.B / n, rem = j.B % n;
+  const bool timed = c->opt_time_split && j.x && j.cfg && nseg == 2 && c->ev_t[0];
   for (int g = 0; g < nseg; ++g) {
     if (!segs[g].chunked || n == 1) {
+      if (timed) HIPCHK(c, hipEventRecord(c->ev_t[g], st));       // before the conv layers / between them and the NMS
       yl_status s = piece(g, 0, 0, j.B, st);
       if (s != YL_OK) return s;
+      if (timed && g == 1) { HIPCHK(c, hipEventRecord(c->ev_t[2], st)); c->timing_valid = true; }
       continue;
     }
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
@@ -994,17 +1007,17 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = tru
   const int nseg = plan_segments(c, j, n, segs);
   yl_status s = ensure_streams(c);
   if (s != YL_OK) return s;
-  if (!c->opt_graph || !allow_graph || c->opt_time_split)
+  if (!c->opt_graph || !allow_graph)
     return walk_plan(c, j, st, n, segs, nseg, [&](int g, int i, int b0, int bn, hipStream_t ws) -> yl_status {
       return run_piece(c, j, segs[g], b0, bn, ws, i);
     });
   std::vector<unsigned char> key(sizeof(Job) + sizeof(yl_post_cfg) + 3 * sizeof(int), 0);
   memcpy(key.data(), &j, sizeof(Job));
   if (j.cfg) memcpy(key.data() + sizeof(Job), j.cfg, sizeof(yl_post_cfg));
-  const int optkey = c->opt_streams | (c->opt_lanes << 8) | (c->opt_bf16 << 9) | (c->opt_fuse_decode << 10) |
+  const int optkey = c->opt_streams | (c->opt_lanes << 8) | ((c->opt_bf16 & 1) << 9) | ((c->opt_bf16 >> 1) << 25) | (c->opt_fuse_decode << 10) |
                      (c->opt_batch_levels << 11) | ((c->opt_hybrid & 1) << 12) | (c->opt_nms_groups << 13) | ((c->opt_hybrid >> 1) << 24) |
                      (c->opt_winograd << 17) | (c->opt_fuse_head << 19);
-  const int devkey = c->opt_dev;
+  const int devkey = c->opt_dev | (c->opt_time_split << 16);
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), &devkey, sizeof(int));
@@ -1127,7 +1140,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   if (!g_inited[device_id]) {
     if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess || yl_stemblock_init() != hipSuccess ||
         yl_conv_init_bf16() != hipSuccess || yl_stemblock_init_bf16() != hipSuccess || yl_convc_init() != hipSuccess ||
-        yl_convc_init_bf16() != hipSuccess || yl_dpp_init() != hipSuccess)
+        yl_convc_init_bf16() != hipSuccess || yl_dpp_init() != hipSuccess || yl_conv_init_f16() != hipSuccess ||
+        yl_stemblock_init_f16() != hipSuccess || yl_convc_init_f16() != hipSuccess)
       return YL_ERR_HIP;
     g_inited[device_id] = true;
   }
@@ -1378,14 +1392,15 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
 yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
-  if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : (c->opt_bf16 == 1 ? 0 : c->opt_bf16); drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "mfma_f16")) { c->opt_bf16 = value ? 2 : (c->opt_bf16 == 2 ? 0 : c->opt_bf16); drop_graph(c); return YL_OK; }
   if (!strcmp(name, "nms_groups")) { c->opt_nms_groups = value < 0 ? 0 : (value > YL_NMS_GROUPS ? YL_NMS_GROUPS : value); drop_graph(c); return YL_OK; }
   if (!strcmp(name, "time_split")) {
+    // (no drop_graph: the setting is part of the graph key -- a serving loop toggles it per call, api.YoloLite.predict)
     c->opt_time_split = value ? 1 : 0;
     for (int i = 0; i < 3 && value; ++i)
       if (!c->ev_t[i]) HIPCHK(c, hipEventCreate(&c->ev_t[i]));
     c->timing_valid = false;
-    drop_graph(c);
     return YL_OK;
   }
   if (!strcmp(name, "pre_norm")) { c->opt_pre_norm = value ? 1 : 0; return YL_OK; }
@@ -1405,7 +1420,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
 yl_status yl_get_option(const yl_ctx* c, const char* name, int32_t* value) {
   if (!c || !name || !value) return YL_ERR_INVALID;
   const struct { const char* n; int v; } tab[] = {
-      {"graph", c->opt_graph}, {"mfma_bf16", c->opt_bf16}, {"nms_groups", c->opt_nms_groups}, {"time_split", c->opt_time_split},
+      {"graph", c->opt_graph}, {"mfma_bf16", c->opt_bf16 == 1}, {"mfma_f16", c->opt_bf16 == 2}, {"nms_groups", c->opt_nms_groups}, {"time_split", c->opt_time_split},
       {"pre_norm", c->opt_pre_norm}, {"reuse_slots", c->opt_reuse}, {"hybrid", c->opt_hybrid}, {"batch_levels", c->opt_batch_levels},
       {"fuse_decode", c->opt_fuse_decode}, {"fuse_head", c->opt_fuse_head}, {"winograd", c->opt_winograd}, {"lanes", c->opt_lanes},
       {"tile_m", c->opt_tile_m}, {"streams", c->opt_streams}, {"dev_select", c->opt_dev}};

@@ -22,29 +22,30 @@
 // the timm backbones it wraps (model_v2.py:94-100,266-272).
 // Second compilation with -DYL_BF16=1 (csrc/build.py) produces the bf16-MFMA variant of this translation unit
 // under distinct symbol names; yl_api.hip picks one per context (yl_set_option "mfma_bf16").
+#include "yl_lp.h"
 #if defined(YL_BF16) && YL_BF16
-#define yl_conv_mfma_kernel yl_conv_mfma_kernel_bf16
-#define yl_conv_dwh_kernel yl_conv_dwh_kernel_bf16
-#define yl_uib_kernel yl_uib_kernel_bf16
-#define yl_stem_mfma_kernel yl_stem_mfma_kernel_bf16
-#define yl_dw_kernel yl_dw_kernel_bf16
-#define yl_dw_tile_kernel yl_dw_tile_kernel_bf16
-#define yl_launch_conv yl_launch_conv_bf16
-#define yl_launch_conv_multi yl_launch_conv_multi_bf16
-#define yl_launch_stem yl_launch_stem_bf16
-#define yl_launch_dw yl_launch_dw_bf16
-#define yl_conv_init yl_conv_init_bf16
-#define yl_uib_supported yl_uib_supported_bf16
-#define yl_uib_lds_bytes yl_uib_lds_bytes_bf16
-#define yl_launch_conv_dwc yl_launch_conv_dwc_bf16
-#define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
-#define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
-#define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
-#define yl_launch_conv_pws yl_launch_conv_pws_bf16
-#define yl_launch_conv_ir yl_launch_conv_ir_bf16
-#define yl_launch_conv_wino yl_launch_conv_wino_bf16
-#define yl_launch_conv_dwk yl_launch_conv_dwk_bf16
-#define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
+#define yl_conv_mfma_kernel YL_LP_NAME(yl_conv_mfma_kernel)
+#define yl_conv_dwh_kernel YL_LP_NAME(yl_conv_dwh_kernel)
+#define yl_uib_kernel YL_LP_NAME(yl_uib_kernel)
+#define yl_stem_mfma_kernel YL_LP_NAME(yl_stem_mfma_kernel)
+#define yl_dw_kernel YL_LP_NAME(yl_dw_kernel)
+#define yl_dw_tile_kernel YL_LP_NAME(yl_dw_tile_kernel)
+#define yl_launch_conv YL_LP_NAME(yl_launch_conv)
+#define yl_launch_conv_multi YL_LP_NAME(yl_launch_conv_multi)
+#define yl_launch_stem YL_LP_NAME(yl_launch_stem)
+#define yl_launch_dw YL_LP_NAME(yl_launch_dw)
+#define yl_conv_init YL_LP_NAME(yl_conv_init)
+#define yl_uib_supported YL_LP_NAME(yl_uib_supported)
+#define yl_uib_lds_bytes YL_LP_NAME(yl_uib_lds_bytes)
+#define yl_launch_conv_dwc YL_LP_NAME(yl_launch_conv_dwc)
+#define yl_launch_conv_pwt YL_LP_NAME(yl_launch_conv_pwt)
+#define yl_launch_conv_pwt_multi YL_LP_NAME(yl_launch_conv_pwt_multi)
+#define yl_launch_conv_kxk YL_LP_NAME(yl_launch_conv_kxk)
+#define yl_launch_conv_pws YL_LP_NAME(yl_launch_conv_pws)
+#define yl_launch_conv_ir YL_LP_NAME(yl_launch_conv_ir)
+#define yl_launch_conv_wino YL_LP_NAME(yl_launch_conv_wino)
+#define yl_launch_conv_dwk YL_LP_NAME(yl_launch_conv_dwk)
+#define yl_launch_conv_dwt YL_LP_NAME(yl_launch_conv_dwt)
 #endif
 #include <stdio.h>
 #include <stdlib.h>

@@ -24,26 +24,27 @@
 //
 // Limits (launcher falls back to yl_conv_dwh_kernel otherwise): OH, OW multiples of 4, N % 4 == 0,
 // NTW = ceil(ceil(N/16)/4) <= 5 and ceil(Cin/16) <= KBMAX(NTW) (the register budget of the resident weights).
+#include "yl_lp.h"
 #if defined(YL_BF16) && YL_BF16
-#define yl_conv_dwc_kernel yl_conv_dwc_kernel_bf16
-#define yl_launch_conv_dwc yl_launch_conv_dwc_bf16
-#define yl_convc_init yl_convc_init_bf16
-#define yl_conv_pwt_kernel yl_conv_pwt_kernel_bf16
-#define yl_launch_conv_pwt yl_launch_conv_pwt_bf16
-#define yl_launch_conv_pwt_multi yl_launch_conv_pwt_multi_bf16
-#define yl_conv_dwt_kernel yl_conv_dwt_kernel_bf16
-#define yl_launch_conv_dwt yl_launch_conv_dwt_bf16
-#define yl_conv_dwk_kernel yl_conv_dwk_kernel_bf16
-#define yl_launch_conv_dwk yl_launch_conv_dwk_bf16
-#define yl_conv_wino_kernel yl_conv_wino_kernel_bf16
-#define yl_launch_conv_wino yl_launch_conv_wino_bf16
-#define yl_conv_kxk_kernel yl_conv_kxk_kernel_bf16
-#define yl_launch_conv_kxk yl_launch_conv_kxk_bf16
-#define yl_conv_pws_kernel yl_conv_pws_kernel_bf16
-#define yl_launch_conv_pws yl_launch_conv_pws_bf16
-#define yl_ir_kernel yl_ir_kernel_bf16
-#define yl_launch_conv_ir yl_launch_conv_ir_bf16
-#define yl_ir_supported yl_ir_supported_bf16
+#define yl_conv_dwc_kernel YL_LP_NAME(yl_conv_dwc_kernel)
+#define yl_launch_conv_dwc YL_LP_NAME(yl_launch_conv_dwc)
+#define yl_convc_init YL_LP_NAME(yl_convc_init)
+#define yl_conv_pwt_kernel YL_LP_NAME(yl_conv_pwt_kernel)
+#define yl_launch_conv_pwt YL_LP_NAME(yl_launch_conv_pwt)
+#define yl_launch_conv_pwt_multi YL_LP_NAME(yl_launch_conv_pwt_multi)
+#define yl_conv_dwt_kernel YL_LP_NAME(yl_conv_dwt_kernel)
+#define yl_launch_conv_dwt YL_LP_NAME(yl_launch_conv_dwt)
+#define yl_conv_dwk_kernel YL_LP_NAME(yl_conv_dwk_kernel)
+#define yl_launch_conv_dwk YL_LP_NAME(yl_launch_conv_dwk)
+#define yl_conv_wino_kernel YL_LP_NAME(yl_conv_wino_kernel)
+#define yl_launch_conv_wino YL_LP_NAME(yl_launch_conv_wino)
+#define yl_conv_kxk_kernel YL_LP_NAME(yl_conv_kxk_kernel)
+#define yl_launch_conv_kxk YL_LP_NAME(yl_launch_conv_kxk)
+#define yl_conv_pws_kernel YL_LP_NAME(yl_conv_pws_kernel)
+#define yl_launch_conv_pws YL_LP_NAME(yl_launch_conv_pws)
+#define yl_ir_kernel YL_LP_NAME(yl_ir_kernel)
+#define yl_launch_conv_ir YL_LP_NAME(yl_launch_conv_ir)
+#define yl_ir_supported YL_LP_NAME(yl_ir_supported)
 #endif
 #include <stdlib.h>
 #include <map>

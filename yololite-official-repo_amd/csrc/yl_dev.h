@@ -50,22 +50,43 @@ __device__ __forceinline__ f32x4 yl_clamp4(f32x4 v, float lo, float hi) {
 //   mode"): operands rounded to bf16 in registers (v_cvt_pk_bf16_f32, RNE), ONE v_mfma_f32_16x16x16_bf16 per
 //   (nt, mt), fp32 accumulate; activations and weights stay fp32 in HBM / LDS, so layouts, loads and epilogues
 //   are shared with the fp32 build.  Selected per context with yl_set_option("mfma_bf16", 1).
+//   YL_F16 (third compilation, -DYL_BF16=1 -DYL_F16=1: everything the reduced-precision build shares, plus): operands rounded to
+//   fp16 (RNE) and multiplied on v_mfma_f32_16x16x16_f16 -- the counterpart of the reference's fp16 autocast in evaluate_model
+//   (scripts/helpers/evaluate.py:399,415).  Selected with yl_set_option("mfma_f16", 1).  Symbols carry _f16 (yl_lp.h).
 #ifndef YL_BF16
 #define YL_BF16 0
 #endif
+#ifndef YL_F16
+#define YL_F16 0
+#endif
+#include "yl_lp.h"
 typedef short yl_s16x4 __attribute__((ext_vector_type(4)));
+// the lane's four consecutive channels packed to the 16-bit operand type of the reduced-precision build (bf16 or fp16, RNE)
 __device__ __forceinline__ yl_s16x4 yl_pk_bf16(f32x4 v) {
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
   typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
   u32x2_ r;
+#if YL_F16
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  r.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v.x, v.y}, f16x2_));
+  r.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v.z, v.w}, f16x2_));
+#else
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
   r.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v.x, v.y}, bf16x2_));
   r.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v.z, v.w}, bf16x2_));
+#endif
   return __builtin_bit_cast(yl_s16x4, r);
 }
+// one 16x16x16 MFMA on the packed operands, fp32 accumulate
+#if YL_F16
+typedef _Float16 yl_f16x4 __attribute__((ext_vector_type(4)));
+#define YL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(yl_f16x4, a), __builtin_bit_cast(yl_f16x4, b), c, 0, 0, 0)
+#else
+#define YL_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+#endif
 #if YL_BF16
 #define YL_MFMA_PER_BLOCK 1
-#define yl_mma_step yl_mma_step_bf16
+#define yl_mma_step YL_LP_NAME(yl_mma_step)
 #else
 #define YL_MFMA_PER_BLOCK 4
 #endif
@@ -80,7 +101,7 @@ __device__ __forceinline__ void yl_mma_step(const f32x4 (&wq)[NT], const f32x4 (
     const yl_s16x4 wb = yl_pk_bf16(wq[nt]);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wb, xb[mt], acc[mt][nt], 0, 0, 0);
+      acc[mt][nt] = YL_MFMA16(wb, xb[mt], acc[mt][nt]);
   }
 #else
 #pragma unroll

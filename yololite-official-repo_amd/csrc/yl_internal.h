@@ -221,3 +221,10 @@ hipError_t yl_launch_conv_multi_bf16(const YlConvP* ps, int n, int tile_hint, hi
 hipError_t yl_conv_init_bf16();
 hipError_t yl_launch_stemblock_bf16(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init_bf16();
+// fp16-MFMA builds (third compilation, -DYL_BF16=1 -DYL_F16=1: option "mfma_f16")
+hipError_t yl_launch_conv_f16(const YlConvP& p, int tile_hint, hipStream_t st);
+hipError_t yl_launch_conv_multi_f16(const YlConvP* ps, int n, int tile_hint, hipStream_t st);
+hipError_t yl_conv_init_f16();
+hipError_t yl_convc_init_f16();
+hipError_t yl_launch_stemblock_f16(const YlConvP& p, hipStream_t st);
+hipError_t yl_stemblock_init_f16();

@@ -17,11 +17,12 @@
 // Replaces timm conv_stem+bn1 and blocks.0.{0,1} (ConvBnAct) of mobilenetv4_conv_small*, i.e. the
 // first three conv/BN/ReLU triples behind model_v2.py:94-100,266-272.
 // bf16-MFMA variant: second compilation with -DYL_BF16=1 under distinct symbol names (see yl_dev.h: yl_mma_step)
+#include "yl_lp.h"
 #if defined(YL_BF16) && YL_BF16
-#define yl_stemblock_kernel yl_stemblock_kernel_bf16
-#define yl_launch_stemblock yl_launch_stemblock_bf16
-#define yl_stemblock_init yl_stemblock_init_bf16
-#define yl_stemblock_supported yl_stemblock_supported_bf16
+#define yl_stemblock_kernel YL_LP_NAME(yl_stemblock_kernel)
+#define yl_launch_stemblock YL_LP_NAME(yl_launch_stemblock)
+#define yl_stemblock_init YL_LP_NAME(yl_stemblock_init)
+#define yl_stemblock_supported YL_LP_NAME(yl_stemblock_supported)
 #endif
 #include "yl_internal.h"
 #include "yl_dev.h"
@@ -277,8 +278,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
         const yl_s16x4 x1 = yl_pk_bf16((f32x4){xs[4], xs[5], xs[6], 0.0f});
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) {
-          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wab[0][nt], x0, a1[nt], 0, 0, 0);
-          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wab[1][nt], x1, a1[nt], 0, 0, 0);
+          a1[nt] = YL_MFMA16(wab[0][nt], x0, a1[nt]);
+          a1[nt] = YL_MFMA16(wab[1][nt], x1, a1[nt]);
         }
       }
 #else
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
         for (int nt = 0; nt < NT2; ++nt) {
           const f32x4 w = wq[i & 1][nt], x = xq[i & 1];
 #if YL_BF16
-          if (i & 1) a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2b[nt], 0, 0, 0);
-          else a2[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(w), yl_pk_bf16(x), a2[nt], 0, 0, 0);
+          if (i & 1) a2b[nt] = YL_MFMA16(yl_pk_bf16(w), yl_pk_bf16(x), a2b[nt]);
+          else a2[nt] = YL_MFMA16(yl_pk_bf16(w), yl_pk_bf16(x), a2[nt]);
 #else
           a2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], a2[nt], 0, 0, 0);
           a2b[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], a2b[nt], 0, 0, 0);
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
         for (int nt = 0; nt < NT3; ++nt) {
           const f32x4 wq3 = w3l[(kb * NT3 + nt) * 64 + lane];
 #if YL_BF16
-          a3[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yl_pk_bf16(wq3), yl_pk_bf16(a2[kb]), a3[nt], 0, 0, 0);
+          a3[nt] = YL_MFMA16(yl_pk_bf16(wq3), yl_pk_bf16(a2[kb]), a3[nt]);
 #else
 #pragma unroll
           for (int s = 0; s < 4; ++s)
