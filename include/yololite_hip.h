@@ -224,6 +224,11 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * fp32 in memory.  The reference's counterpart is fp16 autocast in evaluate_model
  * (scripts/helpers/evaluate.py:399,415).  NOT the parity path: results differ from fp32 at the 1e-2
  * relative level.),
+ * "split_k" (0/1, default 0: depthwise -> 1x1 layers with 49..64 outputs on grids of <= 20 x 20 pixels split their k-blocks
+ * over the four waves of a workgroup (one tile per workgroup, partial sums joined in LDS in a fixed order).  A latency
+ * option for small batches: edge_n batch-1 forward -9 %, batch-64 throughput -0.7 %.  Chosen per context, never by the
+ * batch size, so results stay batch-invariant and bitwise repeatable within a setting; between the settings they differ
+ * by fp32 rounding (another summation order of the same products).  The pip API (api.YoloLite) turns it on),
  * "mfma_f16" (0/1, default 0: the same with fp16 operands on v_mfma_f32_16x16x16_f16 -- 11 mantissa bits instead of 8:
  * raw logits within 4e-3 of the level maximum; exclusive with "mfma_bf16"). */
 yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
@@ -234,7 +239,8 @@ yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
  * 1: no weight-streaming 1x1 kernel, 2: no staged-patch 3x3 s2 kernel, 3: producer/consumer depthwise kernel on every
  * shape it supports (with "tile_m" 7), 4: no wave-autonomous depthwise kernel, 5-6: streamed depthwise->1x1 kernel
  * variant (0 default, 1 one n-group per item, 2 off), 7-8: streamed dense 3x3 waves per workgroup (0 auto, 1 four,
- * 2 eight, 3 off for 4-n-tile layers), 9: two m-tiles per wave in its 4-wave form).                                */
+ * 2 eight, 3 off for 4-n-tile layers), 9: two m-tiles per wave in its 4-wave form, 10: depthwise -> 1x1 layers on
+ * grids of <= 20 x 20 pixels with one wave per tile instead of the split-K form).                                  */
 yl_status yl_get_option(const yl_ctx* ctx, const char* name, int32_t* value);
 /* Host-side query, no device needed: would yl_create accept a fused inverted-residual block (yl_layer with c2 > 0:
  * 1x1 expand c_in -> c_mid, depthwise dw_k x dw_k stride dw_stride, 1x1 project c_mid -> c_out) producing an

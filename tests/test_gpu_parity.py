@@ -300,6 +300,13 @@ def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
     ctx.set_option("winograd", 0)                       # kernel-equivalence test: the direct convolution on both sides
     x = _x(B, S, seed=11).to(DEV)
     a = [t.clone() for t in m(x)]
+    ctx.set_option("split_k", 1)                        # latency option (round 4): split-K depthwise -> 1x1 on the <= 20x20 grids
+    split = [t.clone() for t in m(x)]
+    ctx.set_option("split_k", 0)
+    for u, v in zip(split, a):                          # another summation order of the same products: rounding noise only
+        assert torch.allclose(u, v, atol=2e-5, rtol=1e-5), float((u - v).abs().max())
+    if name == "edge_n":
+        assert any(not torch.equal(u, v) for u, v in zip(split, a))
     for hint in (6, 7):
         ctx.set_option("tile_m", hint)
         ctx.set_option("dev_select", _lib.DEV_DWC_ALL)   # this context only: the opt-in kernel on every shape it supports

@@ -50,6 +50,7 @@ NMS_TORCHVISION, NMS_GREEDY = 0, 1
 
 # "dev_select" bits (developer A/B, bitwise kernel-equivalence tests; see yl_get_option in the header)
 DEV_DW_TILE_OFF, DEV_PWS_OFF, DEV_S2C_OFF, DEV_DWC_ALL, DEV_DWT_OFF = 1, 2, 4, 8, 16
+DEV_DWT_NOSPLIT = 1 << 10
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)

@@ -106,6 +106,8 @@ struct yl_ctx {
   int wino_max_hw = 0;       // that grid: max out_h * out_w over the layers that carry a Winograd weight image
   int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
   int opt_fuse_head = 1;     // ... and the head trunk (depthwise 3x3 -> 1x1) in the same launch (yl_conv_dpp_kernel)
+  int opt_split_k = 0; // depthwise -> 1x1 layers on <= 20x20 grids in the split-K form (yl_conv_dwt_kernel<.., SK = 4>): -9 % batch-1
+                      // latency, -0.7 % throughput at B = 64 (measured, edge_n) -> off by default, the pip API turns it on
   int opt_dev = 0;    // developer kernel-selection word (YL_DEV_*, "dev_select"); rides in every YlConvP
   int opt_bf16 = 0;   // reduced-precision MFMA mode: 1 = conv / stem-block launches use the bf16-MFMA builds, 2 = the fp16-MFMA
                       // builds (fp32 storage, fp32 accumulate either way); 0 = fp32 (the parity path)
@@ -516,7 +518,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   }
   if (d.res_slot >= 0) p.res = slot_ptr(d.res_slot);
   if (d.scale_slot >= 0) p.scale = slot_ptr(d.scale_slot);
-  p.dev = (unsigned)c->opt_dev;
+  p.dev = (unsigned)c->opt_dev | (c->opt_split_k ? 0u : YL_DEV_DWT_NOSPLIT);
   if (d.up_slot >= 0) {
     p.up = slot_ptr(d.up_slot);
     p.UH = c->slots[d.up_slot].h; p.UW = c->slots[d.up_slot].w;
@@ -1017,7 +1019,7 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = tru
   const int optkey = c->opt_streams | (c->opt_lanes << 8) | ((c->opt_bf16 & 1) << 9) | ((c->opt_bf16 >> 1) << 25) | (c->opt_fuse_decode << 10) |
                      (c->opt_batch_levels << 11) | ((c->opt_hybrid & 1) << 12) | (c->opt_nms_groups << 13) | ((c->opt_hybrid >> 1) << 24) |
                      (c->opt_winograd << 17) | (c->opt_fuse_head << 19);
-  const int devkey = c->opt_dev | (c->opt_time_split << 16);
+  const int devkey = c->opt_dev | (c->opt_time_split << 16) | (c->opt_split_k << 17);
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg), &optkey, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + sizeof(int), &c->opt_tile_m, sizeof(int));
   memcpy(key.data() + sizeof(Job) + sizeof(yl_post_cfg) + 2 * sizeof(int), &devkey, sizeof(int));
@@ -1413,7 +1415,8 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!strcmp(name, "lanes")) { c->opt_lanes = value ? 1 : 0; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }
-  if (!strcmp(name, "dev_select")) { c->opt_dev = value & 0x3ff; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "split_k")) { c->opt_split_k = value ? 1 : 0; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "dev_select")) { c->opt_dev = value & 0x7ff; drop_graph(c); return YL_OK; }
   return fail(c, YL_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -1423,7 +1426,7 @@ yl_status yl_get_option(const yl_ctx* c, const char* name, int32_t* value) {
       {"graph", c->opt_graph}, {"mfma_bf16", c->opt_bf16 == 1}, {"mfma_f16", c->opt_bf16 == 2}, {"nms_groups", c->opt_nms_groups}, {"time_split", c->opt_time_split},
       {"pre_norm", c->opt_pre_norm}, {"reuse_slots", c->opt_reuse}, {"hybrid", c->opt_hybrid}, {"batch_levels", c->opt_batch_levels},
       {"fuse_decode", c->opt_fuse_decode}, {"fuse_head", c->opt_fuse_head}, {"winograd", c->opt_winograd}, {"lanes", c->opt_lanes},
-      {"tile_m", c->opt_tile_m}, {"streams", c->opt_streams}, {"dev_select", c->opt_dev}};
+      {"tile_m", c->opt_tile_m}, {"streams", c->opt_streams}, {"dev_select", c->opt_dev}, {"split_k", c->opt_split_k}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *value = t.v; return YL_OK; }
   return YL_ERR_INVALID;

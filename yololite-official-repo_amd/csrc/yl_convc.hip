@@ -565,7 +565,15 @@ hipError_t yl_launch_conv_pwt(const YlConvP& p, hipStream_t st) { return yl_laun
 //        the better choice when it is small (K = N = 96: 36 KB).
 //   MT   m-tiles per wave: 2 = a 4x8-pixel tile, both m-tiles share the 6x10 / 8x12 halo patch, every A fragment
 //        and every tap-weight read (LDS reads per pixel -35 %).
-template <int NT, int DK, int DS, int MT, bool WL>
+//   SK   split-K for grids of <= 20 x 20 pixels (round 4): such a layer has 25 tiles per image -- 800 wave tiles for a
+//        32-image chunk on 1024 SIMDs, one wave walking 12-18 k-blocks serially while most of the chip idles (the 20x20
+//        stage of edge_n: 4x off its byte / MFMA floor, and its launches cost their full duration in the two-stream step:
+//        profiles/r04_skip_layers_edge_n_b64.txt).  SK = 4: the four waves of a workgroup share ONE tile, wave w takes the
+//        k-blocks w, w + 4, ... (its own halo staging, no barrier in the loop); the partial accumulators meet in LDS (one
+//        barrier per tile, buffers alternate) and wave w finishes n-tile w (+4): partials added in wave order 0..3, then
+//        the usual epilogue.  Chosen by the LAYER SHAPE only (never by the batch): results stay batch-invariant and
+//        bitwise repeatable, but are another fp32 summation order of the same products than SK = 1 / yl_conv_dwh_kernel.
+template <int NT, int DK, int DS, int MT, bool WL, int SK = 1>
 __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlConvMulti mp) {
   YL_SELECT_PROBLEM_C(mp)
   constexpr int HPY = 3 * DS + DK, HPX = (4 * MT - 1) * DS + DK;     // halo patch rows / columns
@@ -582,6 +590,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);                     // WL: [KB][NTtot][64] float4
   float* dwl = yl_clds + (WL ? (size_t)KB * NTtot * 256 : 0);        // [DK*DK][Cin] taps, [Cin] bias
   float* halo = dwl + (((size_t)(DK * DK + 1) * Cin + 3) & ~(size_t)3) + wave * (HPY * PITCHF);
+  f32x4* red = reinterpret_cast<f32x4*>(dwl + (((size_t)(DK * DK + 1) * Cin + 3) & ~(size_t)3) + 4 * (HPY * PITCHF));   // SK: [2][4][NT][64]
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
   const int twn = OW / (4 * MT), thn = OH >> 2;
   const int tiles_img = twn * thn;
@@ -589,15 +598,18 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   // tile order: workgroup b runs on XCD b % 8; each XCD takes one contiguous band of tiles (halo rows of neighbouring
   // tiles then meet in the same L2), its workgroups' waves interleave inside the band
   int tile, tend, wstride;
+  constexpr int WPT = SK > 1 ? 1 : 4;                                // tiles a workgroup works on at a time
   if ((gx & 7) == 0) {
     const int tpx = (ntiles + 7) >> 3;
     const int band0 = (bx & 7) * tpx;
     tend = (band0 + tpx) < ntiles ? (band0 + tpx) : ntiles;
-    tile = band0 + (bx >> 3) * 4 + wave;
-    wstride = (gx >> 3) * 4;
+    tile = band0 + (bx >> 3) * WPT + (SK > 1 ? 0 : wave);
+    wstride = (gx >> 3) * WPT;
   } else {
-    tile = bx * 4 + wave; tend = ntiles; wstride = gx * 4;
+    tile = bx * WPT + (SK > 1 ? 0 : wave); tend = ntiles; wstride = gx * WPT;
   }
+  const int kb0 = SK > 1 ? wave : 0;                                 // SK: this wave's k-blocks kb0, kb0 + SK, ...
+  unsigned sk_par = 0;
   // staging slots of this lane: halo pixel / channel quad -> LDS offset; global offsets per tile
   int s_lo[NSLOT];
   bool s_ok[NSLOT];
@@ -647,7 +659,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   bool primed = false;
   if (tile < tend) {                       // first tile's first halo block: in flight together with the LDS fills
     tile_geom();
-    stage_load(0, stg);
+    stage_load(kb0, stg);
     primed = true;
   }
   if (WL) {
@@ -685,11 +697,11 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
       for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 16 + 4 * kq;
         acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (pre_add && n < N) acc[mt][nt] = yl_ld4(p.res + px[mt].lin * N + n);
+        if (pre_add && n < N && (SK == 1 || wave == 0)) acc[mt][nt] = yl_ld4(p.res + px[mt].lin * N + n);
       }
     if (!primed) {
       tile_geom();
-      stage_load(0, stg);
+      stage_load(kb0, stg);
     }
     primed = false;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // previous tile's tap reads are complete
@@ -700,9 +712,9 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
     // `pw_proj` -> `pw_exp` pairs of edge_n's 20x20 stage: one-stream launch times at B = 64, 45.4 us chained against
     // 29.4 + 20.2 for the 5x5 pairs, 53.6 against 23.7 + 20.2 for the 3x3 pairs (one of them feeds 64 -> 480); headline
     // unchanged at 38.8k with five launches fewer per chunk -- not kept.)
-    for (int kb = 0; kb < KB; ++kb) {
-      const bool more = kb + 1 < KB;
-      if (more) stage_load(kb + 1, stg);
+    for (int kb = kb0; kb < KB; kb += SK) {
+      const bool more = kb + SK < KB;
+      if (more) stage_load(kb + SK, stg);
       f32x4 wq[NT];
       if (!WL) {                                                     // A fragments from L1/L2: in flight under the taps
 #pragma unroll
@@ -759,8 +771,27 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
         stage_store(stg);
       }
     }
-    if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
-    else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
+    if (SK > 1) {
+      // partial accumulators -> LDS (buffer = tile parity), ONE barrier per tile, wave w finishes the n-tiles w, w + SK
+      f32x4* rb = red + (size_t)(sk_par & 1u) * (4 * NT * 64);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rb[(wave * NT + nt) * 64 + lane] = acc[0][nt];
+      __syncthreads();
+      ++sk_par;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if ((nt & (SK - 1)) != wave) continue;                       // wave-uniform
+        f32x4 one[1][1];
+        one[0][0] = ((rb[(0 * NT + nt) * 64 + lane] + rb[(1 * NT + nt) * 64 + lane]) + rb[(2 * NT + nt) * 64 + lane]) +
+                    rb[(3 * NT + nt) * 64 + lane];
+        const YlPix px1[1] = {px[0]};
+        if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<1, 1>(p, one, px1, nt, kq);
+        else yl_epi_fast<1, 1>(p, one, px1, nt, kq, lo, hi, true);
+      }
+    } else {
+      if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
+      else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
+    }
     txi += sdx;
     if (txi >= twn) { txi -= twn; ++tyi; }
     tyi += sdy;
@@ -769,20 +800,20 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   }
 }
 
-template <int NT, int DK, int DS, int MT, bool WL>
+template <int NT, int DK, int DS, int MT, bool WL, int SK = 1>
 static hipError_t dwt_go(YlConvMulti& m, hipStream_t st, bool attr_only) {
   if (attr_only)
-    return hipFuncSetAttribute((const void*)yl_conv_dwt_kernel<NT, DK, DS, MT, WL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    return hipFuncSetAttribute((const void*)yl_conv_dwt_kernel<NT, DK, DS, MT, WL, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   constexpr int HPY = 3 * DS + DK, HPX = (4 * MT - 1) * DS + DK;
   constexpr int PITCHF = ((HPX * 16 + 7) / 64) * 64 + 56;
   const YlConvP& p = m.p[0];
   const size_t lds = ((WL ? (size_t)p.KB * p.NTtot * 256 : 0) + (((size_t)(DK * DK + 1) * p.Cin + 3) & ~(size_t)3) +
-                      (size_t)4 * HPY * PITCHF) * 4;
+                      (size_t)4 * HPY * PITCHF + (SK > 1 ? (size_t)2 * 4 * NT * 256 : 0)) * 4;
   if (lds > 96 * 1024) return hipErrorNotSupported;
-  const int res = yl_resident_blocks_n(yl_conv_dwt_kernel<NT, DK, DS, MT, WL>, 256, lds);
+  const int res = yl_resident_blocks_n(yl_conv_dwt_kernel<NT, DK, DS, MT, WL, SK>, 256, lds);
   long tiles[4], total = 0;
   for (int k = 0; k < m.n; ++k) {
-    tiles[k] = (long)m.p[k].B * (m.p[k].OH >> 2) * (m.p[k].OW / (4 * MT));
+    tiles[k] = (long)m.p[k].B * (m.p[k].OH >> 2) * (m.p[k].OW / (4 * MT)) * (SK > 1 ? 4 : 1);     // SK: a workgroup per tile
     total += tiles[k];
   }
   // persistent workgroups: the co-resident count shared between the problems in proportion to their tiles, each
@@ -798,8 +829,24 @@ static hipError_t dwt_go(YlConvMulti& m, hipStream_t st, bool attr_only) {
     at += (int)g;
   }
   if (m.n == 1) m.p[0].nblk = 0;
-  hipLaunchKernelGGL((yl_conv_dwt_kernel<NT, DK, DS, MT, WL>), dim3((unsigned)at), dim3(256), lds, st, m);
+  hipLaunchKernelGGL((yl_conv_dwt_kernel<NT, DK, DS, MT, WL, SK>), dim3((unsigned)at), dim3(256), lds, st, m);
   return hipGetLastError();
+}
+
+// split-K form (see the kernel): single problem, N = 49..64 (4 n-tiles, one per wave), stride-1 3x3 / 5x5 or stride-2
+// 3x3 depthwise, weights from L1/L2, >= 8 k-blocks, a grid of at most 20 x 20 output pixels
+static hipError_t dwt_splitk(YlConvMulti& m, hipStream_t st, bool attr_only) {
+  if (attr_only) {
+    hipError_t e = dwt_go<4, 3, 1, 1, false, 4>(m, st, true);
+    if (e == hipSuccess) e = dwt_go<4, 5, 1, 1, false, 4>(m, st, true);
+    if (e == hipSuccess) e = dwt_go<4, 3, 2, 1, false, 4>(m, st, true);
+    return e;
+  }
+  const YlConvP& p = m.p[0];
+  if (p.dw_k == 3 && p.dw_stride == 1) return dwt_go<4, 3, 1, 1, false, 4>(m, st, false);
+  if (p.dw_k == 5 && p.dw_stride == 1) return dwt_go<4, 5, 1, 1, false, 4>(m, st, false);
+  if (p.dw_k == 3 && p.dw_stride == 2) return dwt_go<4, 3, 2, 1, false, 4>(m, st, false);
+  return hipErrorNotSupported;
 }
 
 template <int NT, int MT, bool WL>
@@ -865,6 +912,11 @@ hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st) {
   const int nts[5] = {1, 2, 3, 4, 6};
   int NT = 6;
   for (int i = 0; i < 5; ++i) if (nts[i] >= p.NTtot) { NT = nts[i]; break; }
+  // split-K: chosen by the layer's SHAPE only (batch-invariant results); "dev_select" bit 10 keeps the one-wave-per-tile form
+  if (m.n == 1 && NT == 4 && !wl && p.KB >= 8 && p.OH * p.OW <= 400 && !(p.dev & YL_DEV_DWT_NOSPLIT)) {
+    const hipError_t e = dwt_splitk(m, st, false);
+    if (e != hipErrorNotSupported) return e;
+  }
   return dwt_any(m, NT, st, two, wl, false);
 }
 
@@ -2020,6 +2072,7 @@ hipError_t yl_convc_init() {
   if (e == hipSuccess) e = pws_nw<11>(q, nullptr, false, true);
   if (e == hipSuccess) e = pws_nw<13>(q, nullptr, false, true);
   if (e == hipSuccess) e = dwt_any(m, 0, nullptr, false, false, true);
+  if (e == hipSuccess) e = dwt_splitk(m, nullptr, true);
   if (e == hipSuccess) e = wino_go(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<7, 1, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<7, 3, 4>(q, nullptr, true);

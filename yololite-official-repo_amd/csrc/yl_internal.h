@@ -127,6 +127,7 @@ struct YlConvP {
 #define YL_DEV_DWK(d) (((d) >> 5) & 3u)   // yl_conv_dwk_kernel: 0 default (a wave holds every n-group), 1 one n-group per item, 2 off
 #define YL_DEV_KXK_NW(d) (((d) >> 7) & 3u) // yl_conv_kxk_kernel waves per workgroup: 0 auto, 1 four, 2 eight, 3 off (4-n-tile layers)
 #define YL_DEV_KXK_MT2 (1u << 9)       // ... two m-tiles per wave in the 4-wave form
+#define YL_DEV_DWT_NOSPLIT (1u << 10)  // depthwise -> 1x1 on <= 20x20 grids: one wave per tile instead of the split-K form
 
 // squeeze-excite gate (yl_se.hip): fixed-order two-pass spatial mean + the two FCs + sigmoid
 struct YlSeP {
