@@ -421,6 +421,14 @@ static hipError_t sb_launch(const YlConvP& p0, hipStream_t st, bool attr_only, s
   const int tpr = (p.OW + SB_TC - 1) / SB_TC, tpc = (p.OH + SB_TR - 1) / SB_TR;
   int nsp = (tpr + 5) / 10;
   if (nsp < 1) nsp = 1;
+  // small batches (round 4): with ~10-tile strips one image is 160 strips = 20 workgroups walking 10 tiles each in series
+  // (99 us at B = 1); shorter strips until ~2048 waves exist (one per wave slot of the 8-wave workgroups on 256 CUs).  A
+  // tile's arithmetic does not depend on the strip it is part of: same bits.
+  {
+    const long rows = (long)p.B * tpc;
+    const long want = (2048 + rows - 1) / rows;
+    if (want > nsp) nsp = (int)(want < tpr ? want : tpr);
+  }
   p.sb_strip = (tpr + nsp - 1) / nsp;
   const long nstrips = (long)p.B * tpc * ((tpr + p.sb_strip - 1) / p.sb_strip);
   int gx = (8 / NWV) * YL_NUM_CU;
