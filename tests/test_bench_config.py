@@ -123,7 +123,14 @@ def _assert_first_divergence_is_a_threshold_flip(got, exp_b, exp_s, exp_c, iou_t
         cand.append((int(gc[j]), -float(gs[j]), gb[j], "hip"))
     if j < len(exp_c):
         cand.append((int(exp_c[j]), -float(exp_s[j]), exp_b[j], "oracle"))
-    cls, _, dbox, side = min(cand, key=lambda t: (t[0], t[1]))           # the one that sorts first is the extra detection
+    cls, nscore, dbox, side = min(cand, key=lambda t: (t[0], t[1]))      # the one that sorts first is the extra detection
+    # a third kind of decision inside the fp32 drift: the class arg-max of a candidate whose two best class logits are
+    # nearly tied -- the SAME candidate (same box, same score to 1e-4) then sits in the other list under another class
+    ob, os_, oc = (exp_b, exp_s, exp_c) if side == "hip" else (gb, gs, gc)
+    twin = [k for k in range(len(oc)) if int(oc[k]) != cls and abs(float(os_[k]) + nscore) <= 1e-4 and
+            np.abs(np.asarray(ob[k], np.float64) - np.asarray(dbox, np.float64)).max() <= 1e-2]
+    if twin:
+        return j, cls, f"class arg-max near-tie (the same candidate is class {int(oc[twin[0]])} on the other side)"
     # common kept boxes of that class in front of position j
     common = [exp_b[k] for k in range(j) if int(exp_c[k]) == cls]
     assert common, ("first divergence has no earlier kept box of its class to be suppressed by", j, cls, side)

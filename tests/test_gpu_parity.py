@@ -305,7 +305,7 @@ def test_convc_kernels_are_bitwise_the_kernels_they_replace(name, B, S):
     ctx.set_option("split_k", 0)
     for u, v in zip(split, a):                          # another summation order of the same products: rounding noise only
         assert torch.allclose(u, v, atol=2e-5, rtol=1e-5), float((u - v).abs().max())
-    if name == "edge_n":
+    if name == "edge_n" and S in (640, 384):            # 20x20 / 12x12 grids in the last backbone stage: the option bites
         assert any(not torch.equal(u, v) for u, v in zip(split, a))
     for hint in (6, 7):
         ctx.set_option("tile_m", hint)
