@@ -227,12 +227,17 @@ def bench_eval_consumers(args):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    evalops.DEVICE_MS.update(total=0.0, launches=0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / args.steps
+    dev_ms = evalops.DEVICE_MS["total"] / args.steps
     out = {"metric": "eval detections/sec (P/R/F1 sweep + confusion matrix)", "value": round(len(dets) / el, 1),
+           "device_kernels_ms_per_step": round(dev_ms, 3), "device_kernel_launches_per_step": evalops.DEVICE_MS["launches"] // args.steps,
+           "device_kernels_share_of_step": round(dev_ms / (el * 1e3), 4),
+           "detections_per_sec_device_kernels_only": round(len(dets) / (dev_ms * 1e-3), 1) if dev_ms > 0 else None,
            "unit": "detections/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(el * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64/f32", "data": "synthetic",

@@ -43,6 +43,28 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+# device time of the matching kernels (HIP events around every yl_eval_* launch), accumulated for the benchmark line:
+# bench.py --workload eval reports how much of a step is kernels and how much host list -> array conversion
+DEVICE_MS = {"total": 0.0, "launches": 0}
+
+
+class _timed_launch:
+    def __init__(self, dev):
+        self.dev = dev
+
+    def __enter__(self):
+        self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.e0.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        self.e1.record(torch.cuda.current_stream(self.dev))
+        self.e1.synchronize()
+        DEVICE_MS["total"] += self.e0.elapsed_time(self.e1)
+        DEVICE_MS["launches"] += 1
+        return False
+
+
 def _offsets(sorted_keys, num_keys):
     off = np.zeros(num_keys + 1, dtype=np.int32)
     if len(sorted_keys):
@@ -80,8 +102,9 @@ def match_per_class(det_img, det_cat, det_xywh, det_score, gt_img, gt_cat, gt_xy
     t_gt = _up(gt_xywh[gorder], dev) if ng else None
     t_tp = torch.empty(nd, dtype=torch.uint8, device=dev)
     t_gm = torch.empty(max(ng, 1), dtype=torch.uint8, device=dev)
-    _lib.check(lib.yl_eval_match(_ptr(t_det), _ptr(t_doff), _ptr(t_gt), _ptr(t_goff), nk, ng, float(iou),
-                                 _ptr(t_tp), None, _ptr(t_gm), _stream(dev)), what="yl_eval_match")
+    with _timed_launch(dev):
+        _lib.check(lib.yl_eval_match(_ptr(t_det), _ptr(t_doff), _ptr(t_gt), _ptr(t_goff), nk, ng, float(iou),
+                                     _ptr(t_tp), None, _ptr(t_gm), _stream(dev)), what="yl_eval_match")
     tp_sorted = t_tp.cpu().numpy()
     tp = np.empty(nd, np.uint8); tp[dorder] = tp_sorted
     has_gt = (gt_off[1:] - gt_off[:-1])[dkey] > 0
@@ -104,8 +127,9 @@ def sweep_counts(score, tp, counted, thresholds, device=None):
     t_s = _up(np.asarray(score, np.float64), dev) if n else None
     t_tp = _up(np.asarray(tp, np.uint8), dev) if n else None
     t_c = _up(np.asarray(counted, np.uint8), dev) if n else None
-    _lib.check(lib.yl_eval_sweep(_ptr(t_s), _ptr(t_tp), _ptr(t_c), n, _ptr(t_thr), steps, _ptr(t_tpg), _ptr(t_fpg),
-                                 _stream(dev)), what="yl_eval_sweep")
+    with _timed_launch(dev):
+        _lib.check(lib.yl_eval_sweep(_ptr(t_s), _ptr(t_tp), _ptr(t_c), n, _ptr(t_thr), steps, _ptr(t_tpg), _ptr(t_fpg),
+                                     _stream(dev)), what="yl_eval_sweep")
     return t_tpg.cpu().numpy().astype(np.int64), t_fpg.cpu().numpy().astype(np.int64)
 
 
@@ -208,9 +232,10 @@ def confusion_matrix_counts(coco_anns, coco_dets, num_classes, iou_thresh=0.5, s
     t_doff, t_goff = _up(det_off, dev), _up(gt_off, dev)
     t_cm = torch.empty(W * W, dtype=torch.int32, device=dev)
     t_gm = torch.empty(len(g_img), dtype=torch.uint8, device=dev)
-    _lib.check(lib.yl_eval_confusion(_ptr(t_det), _ptr(t_dcls), _ptr(t_doff), _ptr(t_gt), _ptr(t_gcls), _ptr(t_goff),
-                                     ni, len(g_img), C, float(np.float32(iou_thresh)), _ptr(t_cm), _ptr(t_gm),
-                                     _stream(dev)), what="yl_eval_confusion")
+    with _timed_launch(dev):
+        _lib.check(lib.yl_eval_confusion(_ptr(t_det), _ptr(t_dcls), _ptr(t_doff), _ptr(t_gt), _ptr(t_gcls), _ptr(t_goff),
+                                         ni, len(g_img), C, float(np.float32(iou_thresh)), _ptr(t_cm), _ptr(t_gm),
+                                         _stream(dev)), what="yl_eval_confusion")
     return t_cm.cpu().numpy().reshape(W, W).astype(np.int64)
 
 
