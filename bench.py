@@ -312,17 +312,20 @@ def bench_tracker(args):
 def wino_eligible(L):
     """the predicate of yl_create (yl_api.hip: the layers that get a Winograd weight image)"""
     return (L.op == 1 and L.k == 3 and L.stride == 1 and L.dw_k == 0 and L.c2 == 0 and L.c3 == 0 and L.pad_t == 1 and L.pad_l == 1
-            and L.in_shift == 0 and L.cin >= 64 and L.cout >= 64 and L.cout % 4 == 0
-            and L.head_level < 0 and L.res_slot < 0 and L.up_slot < 0)
+            and L.in_shift == 0 and L.cin >= 16 and L.cout >= 16 and L.cout % 4 == 0
+            and L.head_level < 0 and L.up_slot < 0 and L.scale_slot < 0)
 
 
 def wino_layers(prog, mode):
-    """indices of the layers option "winograd" = mode runs as Winograd F(2x2,3x3): 1 = every eligible layer, 2 (the
-    library default) = the eligible layers on the largest grid they occur on"""
+    """indices of the layers option "winograd" = mode runs as Winograd F(2x2,3x3): 1 (the library default) = every
+    eligible layer, 2 = only the >= 64-channel layers on the largest grid they occur on (the finest level's smooth block)"""
     el = [i for i, L in enumerate(prog.layers) if wino_eligible(L)]
     if mode == 1 or not el:
         return set(el) if mode else set()
     if mode != 2:
+        return set()
+    el = [i for i in el if prog.layers[i].cin >= 64 and prog.layers[i].cout >= 64]
+    if not el:
         return set()
     hw = lambda i: prog.slots[prog.layers[i].out_slot][0] * prog.slots[prog.layers[i].out_slot][1]
     top = max(hw(i) for i in el)
@@ -706,10 +709,10 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="side-stream lane for the coarse-level neck/head layers")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16-MFMA compute mode (f4; NOT the headline: reduced precision)")
     ap.add_argument("--f16", type=int, default=0, help="1: fp16-MFMA compute mode (the reference's fp16 autocast; NOT the headline)")
-    ap.add_argument("--winograd", type=int, default=2, help="dense 3x3 stride-1 convs (>= 64 channels) as Winograd F(2x2,3x3), 2.25x "
-                    "fewer MACs: 2 (library default) = only those on the largest grid (the finest level's smooth block), 1 = all, "
-                    "0 = direct convolution everywhere.  Score error vs the oracle measured equal for all three "
-                    "(profiles/r04_winograd_margin.json)")
+    ap.add_argument("--winograd", type=int, default=1, help="dense 3x3 stride-1 convs as Winograd F(2x2,3x3), 2.25x fewer MACs: "
+                    "1 (library default) = every eligible layer, 2 = only the >= 64-channel ones on the largest grid (the finest "
+                    "level's smooth block), 0 = direct convolution everywhere.  Score error vs the oracle measured equal for "
+                    "all three (profiles/r04_winograd_margin*.json)")
     ap.add_argument("--workload", default="predict", help="predict (headline) | eval (evaluate-path consumers, f3) | track (tracker bank, f4)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the block of --steps timed steps until this much "
                     "step time has been measured (value = the median block)")
@@ -739,7 +742,7 @@ def main():
 
     out = measure_predict(args, args.model, args.batch, args.seg, dev, rank, world, gather=(world > 1 or force_coll),
                           min_seconds=args.min_seconds)
-    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and not args.f16 and args.winograd == 2
+    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and not args.f16 and args.winograd == 1
                 and not args.stress and args.img == 640)
     want_other = args.other_configs == 1 or (args.other_configs == -1 and headline and world == 1 and not force_coll)
     if rank == 0:

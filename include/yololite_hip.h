@@ -212,18 +212,15 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * "time_split" (0/1, default 0: see yl_last_timing), "pre_norm" (0/1: see yl_preprocess),
  * "reuse_slots" (0/1, default 1: activation tensors share memory by liveness inside one arena per batch chunk;
  * 0 keeps every tensor of the forward pass),
- * "winograd" (0/1/2, default 2: dense 3x3 stride-1 convolutions with >= 64 input and output channels as Winograd
- * F(2x2,3x3) -- 16 instead of 36 multiplications per 2x2 output tile; fp32.  2 = only such layers on the LARGEST grid they
- * occur on (the finest pyramid level's smooth block of the YOLOLiteMS neck, model_v2.py:125-127: 41 % of yololite_m's step),
- * 1 = all of them, 0 = direct convolution everywhere.  Winograd rounds differently from the direct convolution (not
- * bit-identical to it); against the fp32 CPU oracle its score error is the SAME as the direct path's -- measured over 4
- * weight seeds x 32 images x 8400 candidates at 640x640: max |score - oracle score| 1.4-1.7e-5 (direct), 1.4-1.7e-5
- * (2), 0.9-1.6e-5 (1), i.e. >= 5.9x inside the 1e-4 bar (profiles/r04_winograd_margin.json, tools/wino_margin.py)),
- * "mfma_bf16" (0/1, default 0: SURVEY 8(f) f4 reduced-precision inference mode -- conv operands are rounded
- * to bf16 in registers and multiplied on v_mfma_f32_16x16x16_bf16 with fp32 accumulation; tensors stay
- * fp32 in memory.  The reference's counterpart is fp16 autocast in evaluate_model
- * (scripts/helpers/evaluate.py:399,415).  NOT the parity path: results differ from fp32 at the 1e-2
- * relative level.),
+ * "winograd" (0/1/2, default 1: dense 3x3 stride-1 pad-1 convolutions with >= 16 input and output channels as Winograd
+ * F(2x2,3x3) -- 16 instead of 36 multiplications per 2x2 output tile; fp32.  1 = every such layer (the dense FPN smooth
+ * blocks of the YOLOLiteMS neck, model_v2.py:125-127; the ConvBnAct / fused-MBConv expansions of the efficientnetv2
+ * backbones), 2 = only the >= 64-channel layers on the LARGEST grid they occur on (the finest pyramid level's smooth
+ * block), 0 = direct convolution everywhere.  Winograd rounds differently from the direct convolution (not bit-identical
+ * to it); against the fp32 CPU oracle its score error is no larger than the direct path's -- measured over 4 weight seeds x
+ * 32 images x 8400 candidates at 640x640 on yololite_m: max |score - oracle score| 1.4-1.7e-5 (0), 1.4-1.7e-5 (2),
+ * 0.9-1.6e-5 (1); on the efficientnetv2 yololite_m: 1.0-1.3e-5 (0), 0.7-1.2e-5 (1) -- i.e. >= 5.9x inside the 1e-4 bar
+ * (profiles/r04_winograd_margin*.json, tools/wino_margin.py)),
  * "split_k" (0/1, default 0: depthwise -> 1x1 layers with 49..64 outputs on grids of <= 20 x 20 pixels split their k-blocks
  * over the four waves of a workgroup (one tile per workgroup, partial sums joined in LDS in a fixed order).  A latency
  * option for small batches: edge_n batch-1 forward -9 %, batch-64 throughput -0.7 %.  Chosen per context, never by the

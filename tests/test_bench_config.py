@@ -272,13 +272,14 @@ def test_full_size_configs_3_and_4(name, seg, seed):
     safe = _assert_all_safe_images(d1, c1, exp, _score_tensor(det_lv), 0.4, cand, exp_index=pos,
                                    what=f"{name}{'+seg' if seg else ''} B=32 seed {seed}", got_scores=got_s)
     sel = [pos[b] for b in safe][:2]
-    # Winograd F(2x2,3x3): everything above ran the library default ("winograd" 2: the dense 3x3 layers of the finest
-    # level only).  The other two settings are held to the SAME north_star bounds at full size -- all candidate scores
-    # within 1e-4 of the oracle, sampled detections equal after rounding: 0 = direct convolution everywhere, 1 = all
-    # eligible layers (yololite_m's six FPN convs; for edge_m + seg the prototype branch's first conv is the only one)
+    # Winograd F(2x2,3x3): everything above ran the library default ("winograd" 1: every eligible dense 3x3 stride-1
+    # layer -- yololite_m's six FPN convs, the fused-MBConv expansions of the efficientnetv2 backbone, the prototype
+    # branch's first conv).  The other two settings are held to the SAME north_star bounds at full size -- all candidate
+    # scores within 1e-4 of the oracle, sampled detections equal after rounding: 0 = direct convolution everywhere, 2 = only
+    # the >= 64-channel layers of the finest level
     ctx.set_option("graph", 1); ctx.set_option("streams", 2)
     outs = {}
-    for mode in (0, 1):
+    for mode in (0, 2):
         ctx.set_option("winograd", mode)
         w = model(x)
         lw = w[0] if seg else w
@@ -292,11 +293,11 @@ def test_full_size_configs_3_and_4(name, seg, seed):
             _assert_north_star(_rows(dw_, cw_, cand[i]), exp, i)
     if seg:                                                        # edge_m: only the prototype branch has an eligible conv
         assert not torch.equal(outs[0][0], a[1]) and float((outs[0][0] - a[1]).abs().max()) <= 1e-4
-        assert torch.equal(outs[1][0], a[1])                       # ... which the default already runs as Winograd
+        assert torch.equal(outs[2][0], a[1])                       # ... the only eligible layer: modes 1 and 2 coincide
     else:                                                          # the options really select other kernels
         assert any(not torch.equal(u, v) for u, v in zip(la, outs[0][1]))
-        assert any(not torch.equal(u, v) for u, v in zip(la, outs[1][1]))
-    ctx.set_option("winograd", 2)
+        assert any(not torch.equal(u, v) for u, v in zip(la, outs[2][1]))
+    ctx.set_option("winograd", 1)
     if seg:
         # config 4: image-resolution masks (640 x 640 input grid, no back-map) of the sampled images vs the oracle's
         # restatement on the ORACLE's own levels / prototypes, mask IoU >= 0.999 (north_star); packed == unpacked

@@ -20,8 +20,9 @@ for N in yololite_m edge_m_seg yololite_m_v2; do
   cp $S/bench_$N.json $D/${TAG}_bench_${N}_b32.json
 done
 cp $S/bench_yololite_m_winograd0.json $D/${TAG}_bench_yololite_m_b32_winograd0.json
-cp $S/bench_yololite_m_winograd1.json $D/${TAG}_bench_yololite_m_b32_winograd1.json
-grep -v amdgpu.ids $S/layers_yololite_m_winograd1.txt > $D/${TAG}_layer_table_yololite_m_b32_winograd1.txt
+cp $S/bench_yololite_m_winograd2.json $D/${TAG}_bench_yololite_m_b32_winograd2.json
+cp $S/bench_yololite_m_v2_winograd0.json $D/${TAG}_bench_yololite_m_v2_b32_winograd0.json
+grep -v amdgpu.ids $S/layers_yololite_m_winograd0.txt > $D/${TAG}_layer_table_yololite_m_b32_winograd0.txt
 cp $S/bench_edge_m_seg_winograd0.json $D/${TAG}_bench_edge_m_seg_b32_winograd0.json
 cp $S/bench_eval.json $D/${TAG}_bench_eval.json
 cp $S/bench_track.json $D/${TAG}_bench_track.json

@@ -35,9 +35,11 @@ python bench.py --steps 30 --warmup 5 --stress 1 --no-cpu-baseline > $OUT/bench_
 python bench.py --model yololite_m --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --layers > $OUT/bench_yololite_m.json 2> $OUT/layers_yololite_m.txt
 python bench.py --model edge_m --seg 1 --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --layers > $OUT/bench_edge_m_seg.json 2> $OUT/layers_edge_m_seg.txt
 python bench.py --model yololite_m_v2 --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --layers > $OUT/bench_yololite_m_v2.json 2> $OUT/layers_yololite_m_v2.txt
-# option "winograd": 2 (selective) is the library default since round 4; labelled lines for 0 (direct everywhere) and 1 (all)
-python bench.py --model yololite_m --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --winograd 0 > $OUT/bench_yololite_m_winograd0.json 2> /dev/null
-python bench.py --model yololite_m --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --winograd 1 --layers > $OUT/bench_yololite_m_winograd1.json 2> $OUT/layers_yololite_m_winograd1.txt
+# option "winograd": 1 (every eligible layer) is the library default since round 4; labelled lines for 0 (direct everywhere)
+# and 2 (the finest level's >= 64-channel layers only)
+python bench.py --model yololite_m --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --winograd 0 --layers > $OUT/bench_yololite_m_winograd0.json 2> $OUT/layers_yololite_m_winograd0.txt
+python bench.py --model yololite_m --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --winograd 2 > $OUT/bench_yololite_m_winograd2.json 2> /dev/null
+python bench.py --model yololite_m_v2 --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --winograd 0 > $OUT/bench_yololite_m_v2_winograd0.json 2> /dev/null
 python bench.py --model edge_m --seg 1 --batch 32 --steps 15 --warmup 3 --no-cpu-baseline --winograd 0 > $OUT/bench_edge_m_seg_winograd0.json 2> /dev/null
 python bench.py --workload eval > $OUT/bench_eval.json 2> /dev/null
 python bench.py --workload track > $OUT/bench_track.json 2> /dev/null

@@ -98,11 +98,13 @@ struct yl_ctx {
                                     // launches between two chunked segments (half as many latency-bound launches)
   int opt_batch_levels = 1;  // runs of independent, identically shaped layers (FPN smooth / head trunk / head out of all
                              // levels) go out as ONE launch (YlConvMulti)
-  int opt_winograd = 2;      // dense 3x3 stride-1 layers with >= 64 channels through Winograd F(2x2,3x3) (2.25x fewer MACs;
+  int opt_winograd = 1;      // dense 3x3 stride-1 layers with >= 64 channels through Winograd F(2x2,3x3) (2.25x fewer MACs;
                              // NOT bit-identical to the direct convolution: fp32 rounding of the transforms); 2 = only the
-                             // eligible layers on the LARGEST grid (the finest pyramid level's smooth block: most of the time)
-                             // -- the DEFAULT since round 4: measured score error vs the oracle over 4 weight seeds x 32
-                             // images x 8400 candidates <= 1.7e-5, the same as the direct convolution's (profiles/r04_winograd_margin.json)
+                             // >= 64-channel layers on the LARGEST grid they occur on (the finest pyramid level's smooth block).
+                             // 1 = every eligible layer (>= 16 channels in and out) -- the DEFAULT since round 4: measured score
+                             // error vs the oracle over 4 weight seeds x 32 images x 8400 candidates 0.9-1.6e-5 (yololite_m) /
+                             // 0.7-1.2e-5 (yololite_m v2), no worse than the direct convolution's 1.4-1.7e-5 / 1.0-1.3e-5
+                             // (profiles/r04_winograd_margin*.json)
   int wino_max_hw = 0;       // that grid: max out_h * out_w over the layers that carry a Winograd weight image
   int opt_fuse_decode = 1;   // yl_predict: decode in the head-output conv's epilogue (no raw level tensor, no decode kernel)
   int opt_fuse_head = 1;     // ... and the head trunk (depthwise 3x3 -> 1x1) in the same launch (yl_conv_dpp_kernel)
@@ -488,7 +490,8 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   memset(&p, 0, sizeof(p));
   const yl_layer& d = L.d;
   p.wp = L.wp; p.bias = L.bias; p.dw_w = L.dw_w; p.dw_b = L.dw_b;
-  p.wino = (c->opt_winograd == 1 || (c->opt_winograd == 2 && L.out_h * L.out_w >= c->wino_max_hw)) ? L.wino : nullptr;
+  p.wino = (c->opt_winograd == 1 ||
+            (c->opt_winograd == 2 && d.cin >= 64 && d.cout >= 64 && L.out_h * L.out_w >= c->wino_max_hw)) ? L.wino : nullptr;
   p.zeros = c->zeros;
   p.B = B; p.H = L.in_h; p.W = L.in_w; p.Cin = d.cin;
   p.OH = L.out_h; p.OW = L.out_w; p.N = d.cout;
@@ -1338,11 +1341,11 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       bias.assign((size_t)cdiv(l.cout, 16) * 16 + 128, 0.0f);
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
       if (l.k == 3 && l.stride == 1 && l.dw_k == 0 && l.c2 == 0 && l.c3 == 0 && l.pad_t == 1 && l.pad_l == 1 && l.in_shift == 0 &&
-          l.cin >= 64 && l.cout >= 64 && (l.cout & 3) == 0 && l.head_level < 0 && l.res_slot < 0 && l.up_slot < 0) {
+          l.cin >= 16 && l.cout >= 16 && (l.cout & 3) == 0 && l.head_level < 0 && l.up_slot < 0) {
         std::vector<float> wn;
         pack_wino(l.w, l.cout, l.cin, wn);
         if ((s = upload(c, wn, &L.wino)) != YL_OK) return s;
-        if (L.out_h * L.out_w > c->wino_max_hw) c->wino_max_hw = L.out_h * L.out_w;
+        if (l.cin >= 64 && l.cout >= 64 && L.out_h * L.out_w > c->wino_max_hw) c->wino_max_hw = L.out_h * L.out_w;
       }
       if (l.c3 > 0) {       // chained 1x1 conv [c3][cout][1][1]: its k-blocks are this conv's 16-wide n-tiles
         if (!l.w3 || l.k < 2 || l.dw_k > 0 || l.c2 > 0 || l.head_level >= 0 || l.res_slot >= 0 || l.up_slot >= 0 || l.in_shift ||

@@ -1968,8 +1968,12 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
 #pragma unroll
           for (int c2 = 0; c2 < 2; ++c2) {
             const int oy = 2 * ty + a, ox = 2 * tx + c2;
-            if (oy < OH && ox < OW)
-              *reinterpret_cast<f32x4*>(p.out + (((size_t)b * OH + oy) * OW + ox) * N + n) = yl_actc(y[a][c2] + bias, p.act, lo, hi);
+            if (oy < OH && ox < OW) {
+              const size_t o = (((size_t)b * OH + oy) * OW + ox) * N + n;
+              f32x4 v = yl_actc(y[a][c2] + bias, p.act, lo, hi);
+              if (p.res) v += yl_ld4(p.res + o);                     // residual after the activation (yl_epi_generic's order)
+              *reinterpret_cast<f32x4*>(p.out + o) = v;
+            }
           }
       }
     }
@@ -1996,7 +2000,7 @@ static hipError_t wino_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
 // dense 3x3 stride-1 pad-1 layers that carry a Winograd image (yl_api.hip builds it for >= 64 channels, plain
 // ReLU-family epilogue; layer_params hands it over only under option "winograd").
 hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st) {
-  if (!p.wino || p.k != 3 || p.stride != 1 || p.dw_k > 0 || p.res || p.up || p.dec_boxes || p.C1 > 0 || (p.N & 3) ||
+  if (!p.wino || p.k != 3 || p.stride != 1 || p.dw_k > 0 || p.up || p.dec_boxes || p.C1 > 0 || (p.N & 3) || p.w3p || p.scale ||
       p.in_shift || (size_t)p.B * p.H * p.W * p.Cin >= ((size_t)1 << 31))
     return hipErrorNotSupported;
   return wino_go(p, st, false);
