@@ -312,7 +312,7 @@ def bench_tracker(args):
 def wino_eligible(L):
     """the predicate of yl_create (yl_api.hip: the layers that get a Winograd weight image)"""
     return (L.op == 1 and L.k == 3 and L.stride == 1 and L.dw_k == 0 and L.c2 == 0 and L.c3 == 0 and L.pad_t == 1 and L.pad_l == 1
-            and L.in_shift == 0 and L.cin >= 16 and L.cout >= 16 and L.cout % 4 == 0
+            and L.in_shift <= 1 and L.cin >= 16 and L.cout >= 16 and L.cout % 4 == 0
             and L.head_level < 0 and L.up_slot < 0 and L.scale_slot < 0)
 
 

@@ -1340,7 +1340,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       pack_conv(l.w, l.cout, l.cin, l.k, wp);
       bias.assign((size_t)cdiv(l.cout, 16) * 16 + 128, 0.0f);
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
-      if (l.k == 3 && l.stride == 1 && l.dw_k == 0 && l.c2 == 0 && l.c3 == 0 && l.pad_t == 1 && l.pad_l == 1 && l.in_shift == 0 &&
+      if (l.k == 3 && l.stride == 1 && l.dw_k == 0 && l.c2 == 0 && l.c3 == 0 && l.pad_t == 1 && l.pad_l == 1 && l.in_shift <= 1 &&
           l.cin >= 16 && l.cout >= 16 && (l.cout & 3) == 0 && l.head_level < 0 && l.up_slot < 0) {
         std::vector<float> wn;
         pack_wino(l.w, l.cout, l.cin, wn);

@@ -1805,8 +1805,9 @@ hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------
 // Dense 3x3 stride-1 convolution as Winograd F(2x2,3x3): Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A -- 16 multiplications
-// per 2x2 output tile and channel pair instead of 36 (2.25x fewer MFMAs; option "winograd", off by default: the
-// transforms round differently from the direct convolution, so the result is not bit-identical to it).
+// per 2x2 output tile and channel pair instead of 36 (2.25x fewer MFMAs; option "winograd": every eligible layer by
+// default since round 4 -- the transforms round differently from the direct convolution, so the result is not
+// bit-identical to it, but the score error against the fp32 oracle was measured equal: profiles/r04_winograd_margin*.json).
 // One wave owns 16 Winograd tiles (lane pl = tile, 4 channels 4kq..4kq+3 of a 16-channel block) and 2 n-tiles, and
 // holds ALL 16 transform positions' accumulators (16 x 2 x 4 = 128 VGPRs), so the loop is channel-block outer:
 //   per k-block:  4x4 input patch of the lane's tile (16 float4 from L1/L2, zero buffer outside the image)
@@ -1816,6 +1817,10 @@ hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
 // double-buffered, one barrier per k-block, 8 waves (128 tiles = 512 output pixels) share a chunk; (n-group, m-tile)
 // items group-major in XCD bands like yl_conv_kxk_kernel.  Output transform, bias, ReLU-family clamp and the four
 // NHWC float4 stores per n-tile in the epilogue (ReLU-family clamp or SiLU).
+// SH = 1 (round 4): the conv reads its input nearest-upsampled by 2 (yl_layer.in_shift, the prototype branch's second conv):
+// p.H / p.W are the dims of the VIRTUAL tensor; the 4x4 patch of a tile maps onto a 3x3 block of stored pixels
+// (rows / columns (2t-1+r) >> 1 = t-1, t, t, t+1).
+template <int SH>
 __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
   constexpr int NW = 8, NT = 2;
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
@@ -1886,6 +1891,15 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
     // patch offsets (floats from p.x; the launcher guarantees the tensor is < 2^31 floats): 16 pixels, rows 2ty-1 ..
     // 2ty+2, columns 2tx-1 .. 2tx+2; bit e of `inb` clear = outside the image (zero buffer)
     const int pbase = ((b * H + 2 * ty - 1) * W + 2 * tx - 1) * Cin + 4 * kq;   // patch origin (may lie outside: masked)
+    int rowoff[4], coloff[4];                                    // SH: stored-tensor offsets of the patch rows / columns
+    if (SH) {
+      const int Hs = H >> SH, Ws = W >> SH;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        rowoff[r] = ((b * Hs + ((2 * ty - 1 + r) >> SH)) * Ws) * Cin + 4 * kq;
+        coloff[r] = ((2 * tx - 1 + r) >> SH) * Cin;
+      }
+    }
     unsigned inb = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -1899,7 +1913,8 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int e = r * 4 + q;
-        const int off = pbase + (r * W + q) * Cin + kb * 16;      // (r * W + q) * Cin + kb * 16: wave-uniform
+        const int off = SH ? rowoff[r] + coloff[q] + kb * 16
+                           : pbase + (r * W + q) * Cin + kb * 16;  // (r * W + q) * Cin + kb * 16: wave-uniform
         dst[e] = yl_ld4((((inb >> e) & 1u) && !tail) ? xin + off : xin + zdelta);
       }
     };
@@ -1983,17 +1998,21 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
 }
 
 static hipError_t wino_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
-  if (attr_only)
-    return hipFuncSetAttribute((const void*)yl_conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  if (attr_only) {
+    const hipError_t e = hipFuncSetAttribute((const void*)yl_conv_wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)yl_conv_wino_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  }
   YlConvP p = p0;
   const long T = (long)p.B * ((p.OH + 1) >> 1) * ((p.OW + 1) >> 1);
   p.ntiles = (int)((T + 127) / 128);
   const size_t lds = (size_t)2 * 16 * 2 * 1024;
-  const int res = yl_resident_blocks_n(yl_conv_wino_kernel, 512, lds);
+  const int res = yl_resident_blocks_n(yl_conv_wino_kernel<0>, 512, lds);
   const int G = (p.NTtot + 1) / 2;
   int gx = res & ~7;
   while (gx > 8 && gx - 8 >= p.ntiles * G) gx -= 8;
-  hipLaunchKernelGGL(yl_conv_wino_kernel, dim3(gx), dim3(512), lds, st, p);
+  if (p.in_shift) hipLaunchKernelGGL(yl_conv_wino_kernel<1>, dim3(gx), dim3(512), lds, st, p);
+  else hipLaunchKernelGGL(yl_conv_wino_kernel<0>, dim3(gx), dim3(512), lds, st, p);
   return hipGetLastError();
 }
 
@@ -2001,7 +2020,7 @@ static hipError_t wino_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
 // ReLU-family epilogue; layer_params hands it over only under option "winograd").
 hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st) {
   if (!p.wino || p.k != 3 || p.stride != 1 || p.dw_k > 0 || p.up || p.dec_boxes || p.C1 > 0 || (p.N & 3) || p.w3p || p.scale ||
-      p.in_shift || (size_t)p.B * p.H * p.W * p.Cin >= ((size_t)1 << 31))
+      p.in_shift > 1 || (size_t)p.B * (p.H >> p.in_shift) * (p.W >> p.in_shift) * p.Cin >= ((size_t)1 << 31))
     return hipErrorNotSupported;
   return wino_go(p, st, false);
 }
