@@ -203,7 +203,9 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * layers is split into batch chunks over the internal streams), "batch_levels" (0/1, default 1: head trunks /
  * head outputs of all pyramid levels in one launch each),
  * "fuse_decode" (0/1, default 1: yl_predict decodes inside the head-output convs; the raw level tensors are
- * then NOT materialised unless the model has mask coefficients),
+ * then NOT materialised; a model with mask coefficients gets ONLY the coefficient columns of its level rows written --
+ * what yl_masks / yl_masks_image read -- by a second plain 1x1 launch per head ("fuse_head" 1, single-anchor levels,
+ * 5+C <= 96; otherwise the whole raw rows as before)),
  * "fuse_head" (0/1, default 1: run-time launch fusion of layer pairs whose shapes are instantiated.  With "fuse_decode"
  * and "batch_levels", a head branch -- depthwise 3x3 -> 1x1 trunk of 96 or 64 channels feeding the 1x1 head output --
  * runs trunk, output conv and decode as ONE launch for all levels; a depthwise 3x3 -> 1x1 expand layer followed by the

@@ -291,9 +291,10 @@ def test_full_size_configs_3_and_4(name, seg, seed):
         selw = _safe_images(_score_tensor(det_lv), None, 0.4, range(len(cand)), need=2)
         for i in selw:
             _assert_north_star(_rows(dw_, cw_, cand[i]), exp, i)
-    if seg:                                                        # edge_m: only the prototype branch has an eligible conv
+    if seg:                                                        # edge_m: only the prototype branch has eligible convs
         assert not torch.equal(outs[0][0], a[1]) and float((outs[0][0] - a[1]).abs().max()) <= 1e-4
-        assert torch.equal(outs[2][0], a[1])                       # ... the only eligible layer: modes 1 and 2 coincide
+        # (mode 2 = the >= 64-channel layer on the largest grid: the second prototype conv at 160x160 only)
+        assert not torch.equal(outs[2][0], outs[0][0]) and float((outs[2][0] - a[1]).abs().max()) <= 1e-4
     else:                                                          # the options really select other kernels
         assert any(not torch.equal(u, v) for u, v in zip(la, outs[0][1]))
         assert any(not torch.equal(u, v) for u, v in zip(la, outs[2][1]))

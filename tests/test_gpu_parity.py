@@ -889,6 +889,38 @@ def test_batch_size_changes_keep_buffers_graphs_and_mask_inputs():
     ctx.set_option("graph", 0)
 
 
+def test_split_head_output_of_a_seg_model_is_bitwise_the_combined_launch():
+    """Round 4: under yl_predict a seg model's head-output conv (5+C+NM = 117 columns: no float4 epilogue, raw rows needed for
+    the mask coefficients -> the generic kernel's scalar epilogue at 40 TFLOP/s) runs as TWO launches of the same 1x1 conv --
+    rows [0, 85) with the decode in the epilogue and no raw rows (the detector's fast path), rows [85, 117) as a plain 1x1
+    storing into the level rows' coefficient columns.  Same k order per output: detections AND masks are bit-identical to
+    the combined launch ("fuse_head" 0)."""
+    from yololite_amd.program import MODEL_ZOO
+    for name, S, B in (("edge_m", 320, 2), ("edge_n", 320, 2)):
+        meta = make_meta(num_classes=80, img_size=S, seg=True, **MODEL_ZOO[name])
+        sd = synth_state_dict(meta, seed=3, head_noise=2.0)
+        for k, v in sd.items():
+            if k.endswith(".out.box.bias"):
+                v[2::4] += 3.0
+                v[3::4] += 3.0
+        m = _hip_for(meta, sd)
+        ctx = m._ctx_for(S)
+        x = _x(B, S, seed=5).to(DEV)
+        res = {}
+        for fh in (0, 1):
+            ctx.set_option("fuse_head", fh)
+            d, c, i = ctx.predict(x, _lib.POST_MAIN, 0.02, 0.5, per_class_cap=300, max_out=128, want_idx=True)
+            mk = ctx.masks_image(d, c, i, packed=True)
+            res[fh] = (d.clone(), c.clone(), [t.clone() for t in mk])
+        ctx.set_option("fuse_head", 1)
+        assert int(res[0][1].min()) > 0 and torch.equal(res[0][1], res[1][1])
+        for b in range(B):
+            n = min(int(res[0][1][b]), 128)
+            assert torch.equal(res[0][0][b, :n], res[1][0][b, :n]), (name, b)
+            assert torch.equal(res[0][2][b], res[1][2][b]), (name, b)
+        assert sum(int(t.ne(0).sum()) for t in res[1][2]) > 100
+
+
 def test_masks_image_every_batch_size_17_to_48():
     """the launcher asked for 28 bytes too little dynamic LDS (hand-counted level tables), so
     the per-image item prefix pre[B-6..B] lay past the request and -- for the B whose request ended on an allocation

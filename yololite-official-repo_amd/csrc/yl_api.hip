@@ -27,6 +27,10 @@ struct DevLayer {
   float* w3p = nullptr;
   float* b3 = nullptr;
   float* wino = nullptr; // Winograd F(2x2,3x3) weight image of a dense 3x3 stride-1 conv (pack_wino), or nullptr
+  // head-output layer of a model with mask coefficients (round 4): the same 1x1 conv as TWO weight images -- rows [0, 5+C)
+  // (decode fused in the epilogue, no raw rows: the fast wave-autonomous path) and rows [5+C, 5+C+NM) (plain 1x1 whose 32
+  // columns land in the level rows the mask kernels read)
+  float* wp_det = nullptr; float* b_det = nullptr; float* wp_mc = nullptr; float* b_mc = nullptr;
   int in_h = 0, in_w = 0, out_h = 0, out_w = 0;
   int head_anchor = -1;  // head layers: anchor index handled by this layer
 };
@@ -701,6 +705,38 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         return fail(c, YL_ERR_HIP, b);
       }
     }
+    // head-output conv(s) of a model with mask coefficients under yl_predict: det rows through the decode epilogue (no raw
+    // rows), the mask coefficients as a second plain 1x1 launch into the level rows (bit-identical values: same k order)
+    if (fuse && !evs && !lanes && d.op == YL_OP_CONV && d.head_level >= 0 && c->layers[i].wp_det && c->opt_fuse_head) {
+      bool all = true;
+      for (size_t q = i; q < gend; ++q) all = all && c->layers[q].wp_det != nullptr;
+      if (all) {
+        YlConvP pd[4], pm[4];
+        const int nd = 5 + c->C;
+        for (size_t q = i; q < gend; ++q) {
+          YlConvP o;
+          params(q, o);
+          YlConvP& a = pd[q - i]; YlConvP& m2 = pm[q - i];
+          a = o; a.wp = c->layers[q].wp_det; a.bias = c->layers[q].b_det; a.N = nd; a.NTtot = cdiv(nd, 16); a.dec_raw = 0;
+          m2 = o; m2.wp = c->layers[q].wp_mc; m2.bias = c->layers[q].b_mc; m2.N = c->NM; m2.NTtot = cdiv(c->NM, 16);
+          m2.dec_boxes = nullptr; m2.dec_scores = nullptr; m2.dec_cls = nullptr; m2.dec_raw = 0;
+          m2.out = o.out + nd; m2.ldo = c->E;
+        }
+        const int n = (int)(gend - i);
+        hipError_t e = c->opt_bf16 == 1 ? yl_launch_conv_multi_bf16(pd, n, c->opt_tile_m, st)
+                       : c->opt_bf16 == 2 ? yl_launch_conv_multi_f16(pd, n, c->opt_tile_m, st) : yl_launch_conv_multi(pd, n, c->opt_tile_m, st);
+        if (e == hipSuccess)
+          e = c->opt_bf16 == 1 ? yl_launch_conv_multi_bf16(pm, n, c->opt_tile_m, st)
+              : c->opt_bf16 == 2 ? yl_launch_conv_multi_f16(pm, n, c->opt_tile_m, st) : yl_launch_conv_multi(pm, n, c->opt_tile_m, st);
+        if (e != hipSuccess) {
+          char b[256];
+          snprintf(b, sizeof(b), "layers %zu..%zu split head launch failed: %s", i, gend - 1, hipGetErrorString(e));
+          return fail(c, YL_ERR_HIP, b);
+        }
+        i = gend;
+        continue;
+      }
+    }
     if (gend - i > 1) {
       YlConvP ps[4];
       for (size_t q = i; q < gend; ++q) params(q, ps[q - i]);
@@ -1128,6 +1164,7 @@ void yl_destroy(yl_ctx* c) {
   for (auto& L : c->layers) {
     hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b);
     hipFree(L.w2p); hipFree(L.b2); hipFree(L.w3p); hipFree(L.b3); hipFree(L.wino);
+    hipFree(L.wp_det); hipFree(L.b_det); hipFree(L.wp_mc); hipFree(L.b_mc);
   }
   delete c;
 }
@@ -1346,6 +1383,17 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
         pack_wino(l.w, l.cout, l.cin, wn);
         if ((s = upload(c, wn, &L.wino)) != YL_OK) return s;
         if (l.cin >= 64 && l.cout >= 64 && L.out_h * L.out_w > c->wino_max_hw) c->wino_max_hw = L.out_h * L.out_w;
+      }
+      if (l.head_level >= 0 && c->NM > 0 && (c->NM & 3) == 0 && l.k == 1 && l.dw_k == 0 && l.c2 == 0 && l.c3 == 0 &&
+          5 + c->C <= 96 && l.cout == c->E && c->level_A[l.head_level] == 1) {
+        const int nd = 5 + c->C;
+        std::vector<float> wd, wm, bd((size_t)cdiv(nd, 16) * 16 + 128, 0.0f), bm((size_t)cdiv(c->NM, 16) * 16 + 128, 0.0f);
+        pack_conv(l.w, nd, l.cin, 1, wd);
+        pack_conv(l.w + (size_t)nd * l.cin, c->NM, l.cin, 1, wm);
+        if (l.b) { memcpy(bd.data(), l.b, nd * sizeof(float)); memcpy(bm.data(), l.b + nd, c->NM * sizeof(float)); }
+        if ((s = upload(c, wd, &L.wp_det)) != YL_OK || (s = upload(c, bd, &L.b_det)) != YL_OK ||
+            (s = upload(c, wm, &L.wp_mc)) != YL_OK || (s = upload(c, bm, &L.b_mc)) != YL_OK)
+          return s;
       }
       if (l.c3 > 0) {       // chained 1x1 conv [c3][cout][1][1]: its k-blocks are this conv's 16-wide n-tiles
         if (!l.w3 || l.k < 2 || l.dw_k > 0 || l.c2 > 0 || l.head_level >= 0 || l.res_slot >= 0 || l.up_slot >= 0 || l.in_shift ||

@@ -33,14 +33,17 @@ __device__ __forceinline__ void yl_epi_fast(const YlConvP& p, f32x4 (&acc)[MT][N
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (!px[mt].valid) continue;
-    float* orow = p.out + px[mt].lin * p.N;
+    float* orow = p.out + px[mt].lin * (p.ldo ? p.ldo : p.N);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = (nt0 + nt) * 16 + 4 * kq;
       f32x4 v = acc[mt][nt];
       if (add_bias) v += yl_ld4(p.bias + n);
       v = yl_clamp4(v, lo, hi);
-      if (n < p.N) *reinterpret_cast<f32x4*>(orow + n) = v;
+      if (n < p.N) {
+        if (p.ldo) { orow[n] = v.x; orow[n + 1] = v.y; orow[n + 2] = v.z; orow[n + 3] = v.w; }   // rows of ldo floats: unaligned
+        else *reinterpret_cast<f32x4*>(orow + n) = v;
+      }
     }
   }
 }

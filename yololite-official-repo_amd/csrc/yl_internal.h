@@ -115,6 +115,9 @@ struct YlConvP {
   // the partials are a fixed function of the shape (deterministic) and the gate needs no pass over the tensor.  nullptr = off
   float* pool;
   int pool_wpi;
+  // output row pitch in floats when it is not N (0 = N): the mask-coefficient part of a split head-output conv stores
+  // its 32 columns into rows of 5+C+NM floats (yl_epi_fast only; scalar stores: the rows are not 16-byte aligned)
+  int ldo;
 };
 
 // YlConvP::dev -- developer kernel-selection switches (A/B runs, bitwise kernel-equivalence tests); per context, never
