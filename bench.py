@@ -186,7 +186,8 @@ def gpu_batch1_flow(meta, sd, S, conf, iou, dev, budget_s=4.0):
                images_per_sec_wall=round(1000.0 / float(np.mean(rows["wall_ms"])), 1), runs=len(rows["wall_ms"]), warmup=10,
                detections=int(len(r[0]["scores"])),
                flow="480x640 BGR u8 on the host -> YoloLite.predict (pack + H2D + letterbox/normalise kernel -> forward -> "
-                    "decode + per-class NMS + back-map -> rows on the host), batch 1, one chunk, eager launches")
+                    "decode + per-class NMS + back-map -> rows on the host), batch 1, one chunk, launches replayed from a hipGraph "
+                    "(time_split: forward and post-processing as two replays with HIP events between them), split_k 1")
     return out
 
 
@@ -725,6 +726,10 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # one rank per GPU: the rank count comes from the launcher (torch.distributed.run); a bare `python bench.py --gpus 8`
+    # would measure ONE GPU under an 8-GPU label
+    assert args.gpus == world, (f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 as `python -m torch.distributed.run "
+                                f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback exists)"
     torch.cuda.set_device(local)
     if args.workload in ("eval", "track"):

@@ -228,6 +228,9 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * option for small batches: edge_n batch-1 forward -9 %, batch-64 throughput -0.7 %.  Chosen per context, never by the
  * batch size, so results stay batch-invariant and bitwise repeatable within a setting; between the settings they differ
  * by fp32 rounding (another summation order of the same products).  The pip API (api.YoloLite) turns it on),
+ * "mfma_bf16" (0/1, default 0: reduced-precision inference mode, never the parity path -- every conv rounds the lane's
+ * operands (weights and activations) to bf16 in registers and issues v_mfma_f32_16x16x16_bf16 with fp32 accumulation;
+ * tensors stay fp32 in HBM; raw logits within 3e-2 of the level maximum),
  * "mfma_f16" (0/1, default 0: the same with fp16 operands on v_mfma_f32_16x16x16_f16 -- 11 mantissa bits instead of 8:
  * raw logits within 4e-3 of the level maximum; exclusive with "mfma_bf16"). */
 yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);

@@ -296,8 +296,12 @@ class FeatureBackbone(nn.Module):
 
     def __init__(self, name: str, out_indices: Optional[Sequence[int]] = None):
         super().__init__()
-        arch, cmult, dmult, act, eps, same, fix_fl, stem = _ZOO[name][:8]   # timm keeps the stem at 32
+        arch, cmult, dmult, act, eps, same, fix_fl, stem = _ZOO[name][:8]
         rlim = _ZOO[name][8] if len(_ZOO[name]) > 8 else 0.9
+        if arch is EFFNETV2_BASE:
+            # timm's EfficientNet rounds the stem with round_chs_fn unless fix_stem is passed; _gen_efficientnetv2_base does
+            # not pass it (b0-b2: 32, b3: 40).  _gen_efficientnet_lite passes fix_stem=True, _gen_mobilenet_v4 fixes it below 1.0x
+            stem = round_channels(stem, cmult, round_limit=rlim)
         self.conv_stem = _conv(3, stem, 3, 2, same=same)
         self.bn1 = BatchNormAct2d(stem, eps, act)
 

@@ -230,8 +230,18 @@ MODEL_ZOO = {
                    width_multiple=0.75, fpn_channels=256, head_depth=2),
     "edge_m": dict(arch="YOLOLiteMS_CPU", backbone="mobilenetv4_conv_small", depth_multiple=0.95,
                    width_multiple=0.85, fpn_channels=288, head_depth=2),
+    "edge_l": dict(arch="YOLOLiteMS_CPU", backbone="mobilenetv4_conv_small", depth_multiple=1.05,
+                   width_multiple=1.00, fpn_channels=320, head_depth=3),
+    "yololite_n": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite0", depth_multiple=1.0,
+                       width_multiple=1.0, fpn_channels=196, head_depth=1),
+    "yololite_s": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite1", depth_multiple=1.0,
+                       width_multiple=1.0, fpn_channels=256, head_depth=1),
     "yololite_m": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite2", depth_multiple=1.0,
                        width_multiple=1.0, fpn_channels=328, head_depth=2),
+    "yololite_l": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite3", depth_multiple=1.0,
+                       width_multiple=1.0, fpn_channels=512, head_depth=3),
+    "yololite_xl": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite4", depth_multiple=1.5,
+                        width_multiple=1.0, fpn_channels=512, head_depth=3),
     # /root/reference/configs/v2_models/yololite_{n,s,m}.yaml (tf_efficientnetv2_b0 / b1 / b2)
     "yololite_n_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b0", depth_multiple=1.0,
                           width_multiple=1.0, fpn_channels=196, head_depth=1),

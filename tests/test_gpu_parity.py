@@ -129,6 +129,22 @@ def test_forward_zoo_models(name, B, S, uib):
     _cmp_levels(outs, ref, C=80)
 
 
+@pytest.mark.parametrize("name", sorted(__import__("yololite_amd").program.MODEL_ZOO))
+def test_every_zoo_config_runs_on_the_gpu(name):
+    """EVERY model yaml of the reference whose backbone is restated (configs/models/*.yaml, configs/v2_models/*.yaml ->
+    program.MODEL_ZOO) through the HIP path against the oracle: batch 1 at 320 and at 640, C = 80, raw logits and decoded
+    scores.  F = 196 / 256 / 512 necks, head_depth 1 / 2 / 3, depth_multiple 1.5 (three dense 3x3 per level), lite0-lite4,
+    the three efficientnetv2 sizes, all four mobilenetv4 edge models."""
+    for S, seed in ((320, 3), (640, 4)):
+        meta = zoo_meta(name, 80, S)
+        sd = synth_state_dict(meta, seed=seed)
+        x = _x(1, S, seed=seed)
+        with torch.no_grad():
+            ref = _oracle_for(meta, sd)(x)
+        outs = _hip_for(meta, sd)(x.to(DEV))
+        _cmp_levels(outs, ref, C=80)
+
+
 def test_squeeze_excite_gate_is_deterministic_and_batch_invariant():
     """YL_OP_SE: the spatial mean is a fixed-order two-pass sum (no float atomics): the gates, and with them the whole
     forward, are bitwise repeatable, independent of the batch an image is part of and of the chunk split."""

@@ -197,3 +197,60 @@ def test_allgather_dets_gloo_world2(tmp_path, total):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+_WORKER8 = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import yololite_amd
+from yololite_amd import dist as ydist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+total, max_out, steps = 512, 300, 3
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=rank, world_size=world)
+b = total // world
+lo, hi = ydist.shard_range(total, rank, world)
+assert (lo, hi) == (rank * b, (rank + 1) * b)
+def shard_result(step, r):       # what rank r's yl_predict would leave in its gather slot at `step`: image-index stamped
+    g = torch.Generator().manual_seed(1000 * step + r)
+    d = torch.randn(b, max_out, 6, generator=g)
+    d[:, 0, 0] = torch.arange(r * b, (r + 1) * b, dtype=torch.float32)
+    c = torch.randint(0, max_out + 1, (b,), generator=g, dtype=torch.int32)
+    return d, c
+gat = ydist.DetGatherer(b, max_out, "cpu")
+assert gat.world == 8
+def check(views, step):
+    gd, gc = views
+    assert gd.shape == (world, b, max_out, 6) and gc.shape == (world, b)
+    for r in range(world):
+        d, c = shard_result(step, r)
+        assert torch.equal(gd[r], d) and torch.equal(gc[r], c), (rank, step, r)
+    flat = gd.reshape(total, max_out, 6)[:, 0, 0]            # image i of the global batch is (i // b, i % b)
+    assert torch.equal(flat, torch.arange(total, dtype=torch.float32))
+for step in range(steps):
+    d, c = shard_result(step, rank)
+    gat.dets.copy_(d); gat.counts.copy_(c)
+    prev = gat.gather()
+    assert (prev is None) == (step == 0)
+    if prev is not None:
+        check(prev, step - 1)
+check(gat.flush(), steps - 1)
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_config5_shape_gloo_world8(tmp_path):
+    """BASELINE config 5's shape on CPU: 8 gloo ranks, B=512 -> 64 images per rank, max_out 300, the pipelined
+    DetGatherer over 3 steps (one all-gather of [dets | counts] per step, result of step i returned at step i+1)."""
+    script = tmp_path / "w8.py"
+    script.write_text(_WORKER8)
+    port = 29950 + os.getpid() % 40
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(port)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=400)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

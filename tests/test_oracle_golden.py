@@ -175,6 +175,49 @@ def test_param_count_checksum():
     assert n == 552408
     n = sum(p.numel() for p in omodel.DetectorOracle(num_classes=3, **omodel.MODEL_ZOO["edge_m"]).parameters())
     assert abs(n - 2.950e6) < 0.002e6
+    # edge_s: 2 359 736 against the published 2.359 M (BENCHMARK.md:354) -- a fifth reference-held checksum of the
+    # mobilenetv4_conv_small restatement (1.0x widths) with F = int(256 * 0.75) = 192, d = round(1.8) = 2, head_depth 2
+    n = sum(p.numel() for p in omodel.DetectorOracle(num_classes=3, **omodel.MODEL_ZOO["edge_s"]).parameters())
+    assert n == 2359736 and abs(n - 2.359e6) < 0.001e6
+
+
+def test_every_buildable_reference_yaml_has_a_zoo_entry_in_oracle_and_program():
+    """/root/reference/configs/models/*.yaml and configs/v2_models/*.yaml, restated as data: the values below are those of the
+    14 yaml files; every one whose backbone is restated must build in the oracle AND in the host compiler, with the same
+    parameter count (the program consumes every tensor of the oracle's state_dict except num_batches_tracked)."""
+    from yololite_amd.program import MODEL_ZOO as PZ, build_program, synth_state_dict, zoo_meta
+    yamls = {   # name: (arch, backbone, depth_multiple, width_multiple, fpn_channels, head_depth)
+        "edge_n": ("YOLOLiteMS_CPU", "mobilenetv4_conv_small_050", 0.65, 0.60, 160, 1),
+        "edge_s": ("YOLOLiteMS_CPU", "mobilenetv4_conv_small", 0.90, 0.75, 256, 2),
+        "edge_m": ("YOLOLiteMS_CPU", "mobilenetv4_conv_small", 0.95, 0.85, 288, 2),
+        "edge_l": ("YOLOLiteMS_CPU", "mobilenetv4_conv_small", 1.05, 1.00, 320, 3),
+        "edge_xl": ("YOLOLiteMS_CPU", "hgnetv2_b0", 1.0, 1.0, 256, 3),
+        "yololite_n": ("YOLOLiteMS", "tf_efficientnet_lite0", 1.0, 1.0, 196, 1),
+        "yololite_s": ("YOLOLiteMS", "tf_efficientnet_lite1", 1.0, 1.0, 256, 1),
+        "yololite_m": ("YOLOLiteMS", "tf_efficientnet_lite2", 1.0, 1.0, 328, 2),
+        "yololite_l": ("YOLOLiteMS", "tf_efficientnet_lite3", 1.0, 1.0, 512, 3),
+        "yololite_xl": ("YOLOLiteMS", "tf_efficientnet_lite4", 1.5, 1.0, 512, 3),
+        "yololite_n_v2": ("YOLOLiteMS", "tf_efficientnetv2_b0", 1.0, 1.0, 196, 1),
+        "yololite_s_v2": ("YOLOLiteMS", "tf_efficientnetv2_b1", 1.0, 1.0, 256, 2),
+        "yololite_m_v2": ("YOLOLiteMS", "tf_efficientnetv2_b2", 1.0, 1.0, 328, 2),
+        "yololite_l_v2": ("YOLOLiteMS", "convnextv2_tiny", 1.0, 1.0, 512, 3),
+    }
+    from oracle import backbones as ob
+    for name, (arch, bb, dm, wm, fpn, hd) in yamls.items():
+        want = dict(arch=arch, backbone=bb, depth_multiple=dm, width_multiple=wm, fpn_channels=fpn, head_depth=hd)
+        if name not in PZ:
+            assert bb not in ob._ZOO, f"{name}: backbone {bb} is restated but the config has no zoo entry"
+            continue
+        assert PZ[name] == want and omodel.MODEL_ZOO[name] == want, name
+        meta = zoo_meta(name, 3, 256)
+        sd = synth_state_dict(meta)
+        prog = build_program(meta, sd)
+        o = omodel.DetectorOracle(num_classes=3, **omodel.MODEL_ZOO[name])
+        osd = {k: v for k, v in o.state_dict().items() if not k.endswith("num_batches_tracked")}
+        unused = sorted(k for k in osd if k not in prog.used_keys and not k.startswith(("p6_", "smooth6", "head6")))
+        assert not unused, (name, unused[:5])
+        for k in prog.used_keys:
+            assert tuple(sd[k].shape) == tuple(osd[k].shape), (name, k)
 
 
 def test_param_checksums_of_the_published_models():

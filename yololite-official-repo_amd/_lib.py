@@ -18,8 +18,8 @@ def _default_hw_queues():
     runtime initialises (first device call), so it is set HERE -- on import of the package, whatever the host
     program is (bench.py, the CLIs, a serving process) -- unless the user chose a value; if the runtime is
     already up the default cannot take effect any more and that is said loudly."""
-    if "GPU_MAX_HW_QUEUES" in os.environ:
-        return
+    if "GPU_MAX_HW_QUEUES" in os.environ or os.environ.get("YOLOLITE_NO_ENV_DEFAULTS"):
+        return          # the user's value, or an explicit opt-out (INTEGRATION.md): the host application owns its environment
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
     t = sys.modules.get("torch")
     try:

@@ -25,9 +25,11 @@ class YoloLite:
         self.device = dev
         # serving loop: the launches of a call are replayed from cached hipGraphs (keyed on the buffers of the call; a
         # batch-1 forward is 30-odd launches of a few microseconds each -- eager launch overhead would dominate it)
-        self.model._ctx_for(self.img_size).set_option("graph", 1)
-        # small batches are latency-bound: the 20x20-stage depthwise layers in their split-K form (-9 % batch-1 forward)
-        self.model._ctx_for(self.img_size).set_option("split_k", 1)
+        # small batches are latency-bound: the 20x20-stage depthwise layers in their split-K form (-9 % batch-1 forward).
+        # split_k is another fp32 summation order: detections of this API differ in low-order bits from YOLOLiteHIP(...) /
+        # the CLIs on the same checkpoint (both are held to the oracle by the same tolerances).  Applied to every
+        # context of the model (any input size), not only the checkpoint's img_size.
+        self.model.set_context_options(graph=1, split_k=1)
 
     @torch.no_grad()
     def predict(self, source: Union[np.ndarray, Sequence[np.ndarray]], device=None, draw: bool = False,

@@ -368,6 +368,10 @@ class YOLOLiteHIP:
         self._fuse_kw = dict(fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib, fuse_ir=fuse_ir, fuse_uir=fuse_uir,
                              fuse_lat=fuse_lat, fuse_chain=fuse_chain)
         self.export_concat = False
+        # yl_set_option values applied to EVERY context of this model (one per input size), e.g. the pip API's serving
+        # options; set with set_context_options() so that contexts that already exist get them too
+        self.context_options: Dict[str, int] = {}
+        self._ctxs: Dict[int, tuple] = {}
         self.program: Optional[Program] = None
         self.ctx: Optional[HipContext] = None
         self._sd = None
@@ -405,14 +409,25 @@ class YOLOLiteHIP:
         self.ctx = self._ctx_for(self.program.img_size)
         return self
 
+    def set_context_options(self, **opts: int):
+        """Options of the executor (yl_set_option) for every context of this model, present and future: a checkpoint run
+        at two input sizes must not get two different kernel selections (the pip API used to set its serving
+        options on the img_size context only)."""
+        self.context_options.update({k: int(v) for k, v in opts.items()})
+        for _, ctx in self._ctxs.values():
+            for k, v in opts.items():
+                ctx.set_option(k, int(v))
+
     def _ctx_for(self, img_size: int) -> HipContext:
         """The reference module is input-size agnostic (tools/infer.py --img_size); the HIP program is
         planned per size, so contexts are cached by input size."""
         if img_size not in self._ctxs:
             p = self.program if img_size == self.program.img_size else \
                 build_program(self.meta, self._sd, img_size=img_size, **self._fuse_kw)
-            self._ctxs[img_size] = (p, HipContext(p.img_size, p.num_classes, p.level_size, p.level_anchors, p,
-                                                  self._device_index))
+            ctx = HipContext(p.img_size, p.num_classes, p.level_size, p.level_anchors, p, self._device_index)
+            for k, v in self.context_options.items():       # one place for EVERY context of this model (ADVICE r04)
+                ctx.set_option(k, v)
+            self._ctxs[img_size] = (p, ctx)
         return self._ctxs[img_size][1]
 
     def eval(self):

@@ -16,12 +16,20 @@ nearest-upsample-add / activation epilogues, one GEMM for the three head output 
 """
 from __future__ import annotations
 
+import functools
 import math
 import zlib
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+
+def _make_divisible(v, divisor=8, round_limit=0.9):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
 
 # --------------------------------------------------------------------------------------------------
 # backbone tables (timm arch-string notation):  type_r<repeat>_a<dw_start k>_k<kernel>_s<stride>_e<expand>_c<out>
@@ -53,7 +61,9 @@ BACKBONES["tf_efficientnetv2_b0"] = dict(
           ["ir_r5_k3_s1_e6_c112_se0.25"], ["ir_r8_k3_s2_e6_c192_se0.25"]],
     cmult=1.0, dmult=1.0, act="silu", eps=1e-3, same=True, fix_first_last=False, stem=32, round_limit=0.0)
 for _n, _c, _d in (("1", 1.0, 1.1), ("2", 1.1, 1.2), ("3", 1.2, 1.4)):
-    BACKBONES["tf_efficientnetv2_b" + _n] = dict(BACKBONES["tf_efficientnetv2_b0"], cmult=_c, dmult=_d)
+    # the stem is rounded like every other width (timm: no fix_stem for this family): 32 for b0-b2, 40 for b3
+    BACKBONES["tf_efficientnetv2_b" + _n] = dict(BACKBONES["tf_efficientnetv2_b0"], cmult=_c, dmult=_d,
+                                                 stem=_make_divisible(32 * _c, 8, 0.0))
 # tiny efficientnetv2-style test vehicle (not a timm model; oracle/backbones.py: ORACLE_TINY_V2)
 BACKBONES["oracle_tiny_v2"] = dict(
     arch=[["cn_r2_k3_s1_e1_c8_skip"], ["er_r2_k3_s2_e2_c12"], ["er_r1_k3_s2_e4_c16"], ["ir_r2_k3_s2_e4_c24_se0.25"],
@@ -63,13 +73,6 @@ BACKBONES["mobilenetv4_conv_small_050"] = dict(BACKBONES["mobilenetv4_conv_small
 BACKBONES["oracle_tiny_tf"] = dict(BACKBONES["oracle_tiny"], act="relu6", eps=1e-3, same=True)
 for _n, _c, _d in (("1", 1.0, 1.1), ("2", 1.1, 1.2), ("3", 1.2, 1.4), ("4", 1.4, 1.8)):
     BACKBONES["tf_efficientnet_lite" + _n] = dict(BACKBONES["tf_efficientnet_lite0"], cmult=_c, dmult=_d)
-
-
-def _make_divisible(v, divisor=8, round_limit=0.9):
-    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
-    if new_v < round_limit * v:
-        new_v += divisor
-    return new_v
 
 
 def _parse(s: str) -> dict:
@@ -261,8 +264,16 @@ MODEL_ZOO = {
                    width_multiple=0.85, fpn_channels=288, head_depth=2),
     "edge_l": dict(arch="YOLOLiteMS_CPU", backbone="mobilenetv4_conv_small", depth_multiple=1.05,
                    width_multiple=1.00, fpn_channels=320, head_depth=3),
+    "yololite_n": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite0", depth_multiple=1.0,
+                       width_multiple=1.0, fpn_channels=196, head_depth=1),
+    "yololite_s": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite1", depth_multiple=1.0,
+                       width_multiple=1.0, fpn_channels=256, head_depth=1),
     "yololite_m": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite2", depth_multiple=1.0,
                        width_multiple=1.0, fpn_channels=328, head_depth=2),
+    "yololite_l": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite3", depth_multiple=1.0,
+                       width_multiple=1.0, fpn_channels=512, head_depth=3),
+    "yololite_xl": dict(arch="YOLOLiteMS", backbone="tf_efficientnet_lite4", depth_multiple=1.5,
+                        width_multiple=1.0, fpn_channels=512, head_depth=3),
     # /root/reference/configs/v2_models/*.yaml (the yololite_n / yololite_m whose parameters and MACs BENCHMARK.md:356-357
     # publishes: 8.923 M / 11.473 G and 17.916 M / 27.239 G)
     "yololite_n_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b0", depth_multiple=1.0,
@@ -288,8 +299,20 @@ def _query_fused_block(c_in, c_mid, c_out, dk, ds, oh, ow) -> int:
     """yl_query_fused_block: the LIBRARY says whether a fused inverted-residual block of this shape is instantiated
     (1 = yl_ir_kernel, 2 = yl_uib_kernel, 0 = no) -- host-side code of the .so, no device needed.  (the
     hand-copied mirrors of the kernels' shape tables that used to live here are gone.)"""
+    return _query_cached(int(c_in), int(c_mid), int(c_out), int(dk), int(ds), int(oh), int(ow))
+
+
+@functools.lru_cache(maxsize=None)
+def _query_cached(*shape) -> int:
     from . import _lib
-    return int(_lib.load().yl_query_fused_block(int(c_in), int(c_mid), int(c_out), int(dk), int(ds), int(oh), int(ow)))
+    try:
+        lib = _lib.load()
+    except Exception as e:      # program inspection on a box without the built library: say what is missing
+        raise _lib.YoloLiteHipError(
+            "build_program() asks libyololite_hip.so which fused block shapes are instantiated (yl_query_fused_block, host "
+            f"code, no GPU needed) and the library could not be loaded: {e}.  Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc cross-compiles without a GPU)") from e
+    return int(lib.yl_query_fused_block(*shape))
 
 
 class _Builder:
