@@ -458,7 +458,9 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     seed = wl["seed"]
     if args.tile_m:
         ctx.set_option("tile_m", args.tile_m)
-    ctx.set_option("streams", args.streams)
+    K = max(1, int(args.in_flight))                          # batches in flight (serving.ServingPipeline lanes)
+    streams = args.streams if args.streams > 0 else (2 if K == 1 else 1)
+    ctx.set_option("streams", streams)
     if args.bf16:
         ctx.set_option("mfma_bf16", 1)
     if args.f16:
@@ -473,30 +475,37 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
     max_out = MAX_OUT                                    # packed result rows per image
-    gat = None
-    if gather:
-        # equal shards: yl_predict writes into the gather buffer, one collective, no pack/unpack kernels
-        gat = ydist.DetGatherer(B, max_out, dev)
-        dets = counts = None
-    else:
-        dets = torch.empty((B, max_out, 6), device=dev, dtype=torch.float32)
-        counts = torch.empty((B,), device=dev, dtype=torch.int32)
-    mask_arena = (torch.empty((B * max_out * S * ((S + 31) // 32) * 4,), device=dev, dtype=torch.uint8) if seg else None)
+    # One set of buffers per LANE (batch in flight): its own resident input batch (different images per lane), result
+    # rows, gather slots (equal shards: yl_predict writes into the gather buffer, one collective, no pack/unpack kernels)
+    # and mask arena -- what a double-buffered serving loop holds.
+    xs = [x] + [synth_images(B, S, seed=1234 + rank + 1000 * k).to(dev) for k in range(1, K)]
+    gats = [ydist.DetGatherer(B, max_out, dev) for _ in range(K)] if gather else None
+    lane_dets = [None if gather else torch.empty((B, max_out, 6), device=dev, dtype=torch.float32) for _ in range(K)]
+    lane_counts = [None if gather else torch.empty((B,), device=dev, dtype=torch.int32) for _ in range(K)]
+    lane_arena = [(torch.empty((B * max_out * S * ((S + 31) // 32) * 4,), device=dev, dtype=torch.uint8) if seg else None)
+                  for _ in range(K)]
+    gat = gats[0] if gats else None
+    dets, counts = lane_dets[0], lane_counts[0]
 
-    def step():
+    def lane_work(c, k):
+        """ONE step = the complete hot path over one batch on context c (lane k)"""
         if seg:
-            _, _, idx = ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
-                                    out=(dets, counts), want_idx=True)
+            _, _, idx = c.predict(xs[k], _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
+                                  out=(lane_dets[k], lane_counts[k]), want_idx=True)
             # image-resolution (640 x 640) masks, bit-packed rows, into a fixed-capacity arena: asynchronous like the
             # detections themselves (no host read of the counts inside the step)
-            ctx.masks_image(dets, counts, idx, packed=True, arena=mask_arena)
-            return dets, counts
-        if gat is not None:      # results go straight into the gather slot; its all-gather overlaps the next step
-            ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
-                        out=(gat.dets, gat.counts))
-            return gat.gather()
-        ctx.predict(x, _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out, out=(dets, counts))
-        return dets, counts
+            c.masks_image(lane_dets[k], lane_counts[k], idx, packed=True, arena=lane_arena[k])
+            return lane_dets[k], lane_counts[k]
+        if gats is not None:     # results go straight into the gather slot; its all-gather overlaps the following steps
+            c.predict(xs[k], _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
+                      out=(gats[k].dets, gats[k].counts))
+            return gats[k].gather()
+        c.predict(xs[k], _lib.POST_MAIN, args.conf, args.iou, per_class_cap=300, max_out=max_out,
+                  out=(lane_dets[k], lane_counts[k]))
+        return lane_dets[k], lane_counts[k]
+
+    def step():                  # plain call on the model's own context (per-layer timing phase, serial comparison)
+        return lane_work(ctx, 0)
 
     # ---- per-layer durations (HIP events on the launch stream), eager launches
     ctx.set_option("graph", 0)
@@ -513,24 +522,50 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
         lay = np.full(len(prog.layers), 1e-3)
 
     ctx.set_option("graph", args.graph)
-    for _ in range(max(args.warmup, 1)):
-        step()
-    if gat is not None:
-        gat.flush()
+    # ---- the serial loop (ONE batch in flight: calls back to back on one context, two chunk streams) next to the
+    # pipelined one, same process, same clocks: reported as `one_batch_in_flight` so that the gain is visible
+    serial = None
+    if K > 1 and not gather:
+        ctx.set_option("streams", args.streams if args.streams > 0 else 2)
+        for _ in range(max(args.warmup, 1)):
+            step()
+        torch.cuda.synchronize()
+        n_ser, t_ser = 0, 0.0
+        while t_ser < min(0.3, max(min_seconds, 0.05)):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            t_ser += time.perf_counter() - t0
+            n_ser += args.steps
+        serial = {"value": round(B * n_ser / t_ser, 1), "unit": "images/sec", "ms_per_step": round(t_ser / n_ser * 1e3, 4),
+                  "steps": n_ser, "streams": int(ctx.get_option("streams")),
+                  "what": "the same steps issued back to back on ONE context (every call joins its chunk streams before "
+                          "the next call starts)"}
+        ctx.set_option("streams", streams)
+    from yololite_amd.serving import ServingPipeline
+    pipe = ServingPipeline(ctx, lanes=K, streams_per_lane=streams, graph=bool(args.graph), timing=True)
+    for _ in range(max(args.warmup, 1) * K):
+        pipe.run(lane_work)
+    pipe.flush()
+    for g in (gats or []):
+        g.flush()
 
     def block():
-        """exactly args.steps steps between barrier + synchronize on both sides; max over ranks"""
+        """exactly args.steps steps between barrier + synchronize on both sides; max over ranks.  Step i runs on lane
+        i % K; every step's work -- and every exchange -- has completed inside the timed region."""
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        pipe.events.clear()
+        ev0 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev[0].record()
+        ev0.record()
         for i in range(args.steps):
-            step()
-            ev[i + 1].record()
-        if gat is not None:
-            gat.flush()                    # every step's exchange has completed inside the timed region
+            pipe.run(lane_work)
+        pipe.flush()
+        for g in (gats or []):
+            g.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -541,16 +576,18 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, el_local, [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+        done = np.sort([ev0.elapsed_time(e1) for _, e1 in pipe.events])
+        # completion intervals of consecutive batches (the first one carries the pipeline fill) and per-batch latency
+        return el, el_local, list(np.diff(done)), [e0.elapsed_time(e1) for e0, e1 in pipe.events]
 
-    els, step_ms, el_locals = [], [], []
-    el, ell, sm = block()
-    els.append(el); el_locals.append(ell); step_ms += sm
+    els, step_ms, el_locals, lat_ms = [], [], [], []
+    el, ell, sm, lm = block()
+    els.append(el); el_locals.append(ell); step_ms += sm; lat_ms += lm
     # number of further blocks: the same on every rank (derived from the all-reduced first block)
     more = int(min(max_blocks - 1, max(0, np.ceil((min_seconds - el) / max(el, 1e-6)))))
     for _ in range(more):
-        el, ell, sm = block()
-        els.append(el); el_locals.append(ell); step_ms += sm
+        el, ell, sm, lm = block()
+        els.append(el); el_locals.append(ell); step_ms += sm; lat_ms += lm
     els = np.asarray(els)
     rates = world * B * args.steps / els
     k_med = int(np.argsort(els)[len(els) // 2])          # the median block: value and ms_per_step come from ONE block
@@ -638,6 +675,14 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(els[k_med]) / args.steps * 1e3, 4),
         "p50_ms_per_frame": round(float(np.median(step_ms)) / B, 5),
         "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
+        "p50_batch_latency_ms": round(float(np.median(lat_ms)), 4),
+        "in_flight": {"batches": K, "streams_per_context": streams,
+                      "what": "serving.ServingPipeline: step i = the complete yl_predict of one batch on context i % K "
+                              "(yl_clone: shared weights, own arenas / graphs), each lane on its own HIP stream, its own "
+                              "resident input batch and output rows; p50_ms_per_batch = median interval between the "
+                              "completions of consecutive batches, p50_batch_latency_ms = median start-to-done time of a "
+                              "batch on its lane (HIP events)"},
+        "one_batch_in_flight": serial,
         "blocks": {"n": int(len(els)), "steps_each": args.steps, "seconds_timed": round(float(els.sum()), 3),
                    "images_per_sec_min": round(float(rates.min()), 1), "images_per_sec_median": round(float(rates[k_med]), 1),
                    "images_per_sec_max": round(float(rates.max()), 1), "images_per_sec_first": round(float(rates[0]), 1)},
@@ -651,7 +696,7 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
                                f"(conf {args.conf}, iou {args.iou}), input resident in HBM"
                                + (", + RCCL all-gather of packed dets" if world > 1 else ""),
                    "global_batch": B * world, "img_size": S, "parallelism": f"dp{world} (batch sharded, weights replicated)",
-                   "hipgraph": bool(args.graph), "streams": args.streams, "weights_seed": seed,
+                   "hipgraph": bool(args.graph), "streams": streams, "batches_in_flight": K, "weights_seed": seed,
                    "head": "NMS stress: uncalibrated N(0,2) head noise (round-1 workload)" if args.stress else
                            "calibrated (program.calibrate_head)",
                    "mean_dets_per_image": round(ndet, 1), "mean_classes_per_image": round(ncls, 1),
@@ -695,7 +740,10 @@ def main():
     ap.add_argument("--fuse-stem", type=int, default=1, help="fused stem+blocks.0 entry kernel")
     ap.add_argument("--fuse-uib", type=int, default=0, help="whole inverted-residual blocks as one launch")
     ap.add_argument("--seg", type=int, default=0, help="add the build-defined instance-seg branch (BASELINE config 4)")
-    ap.add_argument("--streams", type=int, default=2, help="internal streams the batch is split over")
+    ap.add_argument("--streams", type=int, default=0, help="internal streams a context splits its batch over (0 = auto: 2 with "
+                    "one batch in flight, 1 with more)")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight: step i runs on context i %% K of a "
+                    "serving.ServingPipeline (1 = calls back to back on one context: the loop of rounds 1-4)")
     ap.add_argument("--tile-m", type=int, default=0, help="conv M-tile hint (0 auto, 1/2 force m-tiles per wave)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer timing table (stderr)")
     ap.add_argument("--seed", type=int, default=-1, help="synthetic weight seed (-1: 1).  The detection head is calibrated "

@@ -584,6 +584,49 @@ def test_predict_fused_equals_forward_plus_postprocess_and_graph():
     ctx.set_option("graph", 0)
 
 
+@pytest.mark.parametrize("lanes,streams", [(2, 1), (3, 1), (2, 2)])
+def test_serving_pipeline_and_cloned_contexts_are_bitwise_the_plain_calls(lanes, streams):
+    """serving.ServingPipeline (K batches in flight on K contexts, yl_clone: shared weights) hands back, for every batch,
+    exactly the rows a plain ctx.predict of that batch produces -- 7 batches of different images through 2 / 3 lanes, the
+    hand-back order is the submission order, and destroying the ORIGINAL context first leaves the clones usable (the last
+    owner frees the weights)."""
+    from yololite_amd.serving import ServingPipeline
+    S, B = 320, 6
+    meta = zoo_meta("edge_n", 80, S)
+    sd = synth_state_dict(meta, seed=1, head_noise=2.0)
+    m = _hip_for(meta, sd)
+    xs = [_x(B, S, seed=40 + i).to(DEV) for i in range(7)]
+    plain = m._ctx_for(S)
+    want = []
+    for x in xs:
+        d, c = plain.predict(x, _lib.POST_MAIN, 0.02, 0.5, 300)
+        want.append((d.cpu(), c.cpu()))
+    assert min(int(c.min()) for _, c in want) > 0
+    pipe = ServingPipeline(plain, lanes=lanes, streams_per_lane=streams, graph=True)
+    assert len({int(c.handle.value) for c in pipe.ctxs}) == lanes
+    got = []
+    for x in xs:
+        r = pipe.submit(x, _lib.POST_MAIN, 0.02, 0.5, 300)
+        if r is not None:
+            got.append((r[0].cpu(), r[1].cpu()))
+    assert len(got) == len(xs) - lanes
+    got += [(d.cpu(), c.cpu()) for d, c in pipe.flush()]
+    assert len(got) == len(xs) and pipe.flush() == []
+    for (d0, c0), (d1, c1) in zip(want, got):
+        assert torch.equal(c0, c1)
+        for b in range(B):
+            assert torch.equal(d0[b, :int(c0[b])], d1[b, :int(c1[b])])
+    # ownership: drop the model (and with it the original context); a clone still predicts the same rows
+    clone = pipe.ctxs[1]
+    del pipe, plain
+    m._ctxs.clear(); m.ctx = None
+    del m
+    import gc
+    gc.collect()
+    d, c = clone.predict(xs[0], _lib.POST_MAIN, 0.02, 0.5, 300)
+    assert torch.equal(c.cpu(), want[0][1]) and torch.equal(d.cpu()[0, :int(c[0])], want[0][0][0, :int(c[0])])
+
+
 @pytest.mark.parametrize("name,seg", [("edge_n", False), ("edge_m", True), ("yololite_m", False)])
 def test_liveness_slot_reuse_is_bitwise_and_smaller(name, seg):
     """activation tensors placed by liveness in one arena per batch chunk (default) vs one buffer per tensor:

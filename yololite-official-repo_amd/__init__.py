@@ -14,9 +14,10 @@ from .preprocess import letterbox_geometry, preprocess_batch  # noqa: F401
 from .program import BACKBONES, Program, build_program  # noqa: F401
 from .evalops import build_curves_from_coco, create_confusion_matrix  # noqa: F401
 from .tracker import KalmanSortTracker, TrackerBank  # noqa: F401
+from .serving import ServingPipeline  # noqa: F401
 
 __all__ = ["YoloLiteHipError", "load_library", "HipContext", "YOLOLiteHIP", "build_model_from_meta",
            "load_model_names_imgsize_from_ckpt", "decode_preds_anchorfree", "_decode_batch_to_coco_dets",
            "decode_anchorfree_like_train", "infer_main_postprocess", "nms", "predict_main", "predict_coco_dets", "build_program", "Program", "BACKBONES",
            "preprocess_batch", "letterbox_geometry", "build_curves_from_coco", "create_confusion_matrix",
-           "KalmanSortTracker", "TrackerBank"]
+           "KalmanSortTracker", "TrackerBank", "ServingPipeline"]

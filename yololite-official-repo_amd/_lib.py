@@ -38,7 +38,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # YOLOLITE_HIP_LIB selects another build of the same ABI (kernel A/B runs); default: the in-tree library
 LIB_PATH = os.environ.get("YOLOLITE_HIP_LIB") or os.path.join(_HERE, "libyololite_hip.so")
 
-YL_ABI_VERSION = 3
+YL_ABI_VERSION = 4
 YL_MAX_LEVELS = 8
 YL_OK = 0
 ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
@@ -86,6 +86,7 @@ _vp = C.c_void_p
 _vpp = C.POINTER(C.c_void_p)
 SYMBOLS = [
     ("yl_create", C.c_int32, [C.POINTER(yl_model_desc), C.c_int32, C.POINTER(_vp)]),
+    ("yl_clone", C.c_int32, [_vp, C.POINTER(_vp)]),
     ("yl_destroy", None, [_vp]),
     ("yl_strerror", C.c_char_p, [C.c_int32]),
     ("yl_last_error", C.c_char_p, [_vp]),

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -141,6 +142,9 @@ struct yl_ctx {
   };
   std::vector<GraphEntry> graphs;
   unsigned long long graph_clock = 0;
+  // The packed weights (every device pointer inside `layers`, and `zeros`) are immutable after yl_create and may be
+  // SHARED by several contexts (yl_clone: one context per batch in flight of a serving pipeline); the last owner frees them
+  std::shared_ptr<int> weights_owner;
   std::string err;
 };
 
@@ -1152,7 +1156,6 @@ void yl_destroy(yl_ctx* c) {
   free_act(c);
   free_post_ws(c);
   hipFree(c->ws_nms_clsws);
-  hipFree(c->zeros);
   for (int i = 0; i < 4; ++i) {
     if (c->work[i]) hipStreamDestroy(c->work[i]);
     if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
@@ -1163,12 +1166,47 @@ void yl_destroy(yl_ctx* c) {
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   for (int i = 0; i < 3; ++i) if (c->ev_t[i]) hipEventDestroy(c->ev_t[i]);
   hipFree(c->ws_nms_gkeys);
-  for (auto& L : c->layers) {
-    hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b);
-    hipFree(L.w2p); hipFree(L.b2); hipFree(L.w3p); hipFree(L.b3); hipFree(L.wino);
-    hipFree(L.wp_det); hipFree(L.b_det); hipFree(L.wp_mc); hipFree(L.b_mc);
+  if (c->weights_owner.use_count() <= 1) {                   // last context that shares these weights (yl_clone)
+    hipFree(c->zeros);
+    for (auto& L : c->layers) {
+      hipFree(L.wp); hipFree(L.bias); hipFree(L.dw_w); hipFree(L.dw_b);
+      hipFree(L.w2p); hipFree(L.b2); hipFree(L.w3p); hipFree(L.b3); hipFree(L.wino);
+      hipFree(L.wp_det); hipFree(L.b_det); hipFree(L.wp_mc); hipFree(L.b_mc);
+    }
   }
   delete c;
+}
+
+yl_status yl_clone(const yl_ctx* src, yl_ctx** out) {
+  if (!src || !out) return YL_ERR_INVALID;
+  *out = nullptr;
+  if (hipSetDevice(src->device) != hipSuccess) return YL_ERR_HIP;
+  yl_ctx* c = new (std::nothrow) yl_ctx();
+  if (!c) return YL_ERR_NOMEM;
+  *out = c;
+  // the model: geometry, layer program and the (shared, immutable) packed weights
+  c->device = src->device;
+  c->img_size = src->img_size; c->in_ch = src->in_ch; c->C = src->C; c->L = src->L; c->N = src->N; c->E = src->E;
+  c->NM = src->NM; c->proto_slot = src->proto_slot;
+  memcpy(c->level_S, src->level_S, sizeof(c->level_S));
+  memcpy(c->level_A, src->level_A, sizeof(c->level_A));
+  memcpy(c->level_off, src->level_off, sizeof(c->level_off));
+  c->slots.resize(src->slots.size());
+  for (size_t i = 0; i < src->slots.size(); ++i) { c->slots[i].h = src->slots[i].h; c->slots[i].w = src->slots[i].w; c->slots[i].c = src->slots[i].c; }
+  c->layers = src->layers;
+  c->zeros = src->zeros;
+  c->weights_owner = src->weights_owner;
+  c->se_unit = src->se_unit;
+  c->wino_max_hw = src->wino_max_hw;
+  c->lane = src->lane;
+  c->small_lo = src->small_lo; c->small_hi = src->small_hi; c->tiny_lo = src->tiny_lo; c->tiny_hi = src->tiny_hi;
+  // the options as they are now; activation arenas, workspaces, streams, events and cached graphs are the clone's own
+  c->opt_reuse = src->opt_reuse; c->opt_pre_norm = src->opt_pre_norm; c->opt_graph = src->opt_graph; c->opt_tile_m = src->opt_tile_m;
+  c->opt_streams = src->opt_streams; c->opt_nms_groups = src->opt_nms_groups; c->opt_hybrid = src->opt_hybrid;
+  c->opt_batch_levels = src->opt_batch_levels; c->opt_winograd = src->opt_winograd; c->opt_fuse_decode = src->opt_fuse_decode;
+  c->opt_fuse_head = src->opt_fuse_head; c->opt_split_k = src->opt_split_k; c->opt_dev = src->opt_dev; c->opt_bf16 = src->opt_bf16;
+  c->opt_lanes = src->opt_lanes;
+  return YL_OK;
 }
 
 yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
@@ -1192,6 +1230,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
   yl_ctx* c = new (std::nothrow) yl_ctx();
   if (!c) return YL_ERR_NOMEM;
   *out = c;   // handed out even on failure so that yl_last_error() can be read; caller destroys it
+  c->weights_owner = std::make_shared<int>(0);
   c->device = device_id;
   c->img_size = d->img_size; c->in_ch = d->in_channels; c->C = d->num_classes; c->L = d->num_levels;
   c->NM = d->num_masks; c->proto_slot = d->proto_slot;

@@ -122,6 +122,23 @@ class HipContext:
             out.append(t.contiguous())
         return out
 
+    def clone(self) -> "HipContext":
+        """yl_clone: another context of the same model on the same device -- shares the packed weights, copies the current
+        options, owns its arenas / workspaces / streams / graphs.  One context per batch in flight (serving.ServingPipeline)."""
+        o = object.__new__(HipContext)
+        for k in ("lib", "device", "img_size", "C", "level_size", "level_anchors", "L", "N", "NM", "proto_slot", "E",
+                  "num_layers", "proto_shape"):
+            setattr(o, k, getattr(self, k))
+        h = C.c_void_p()
+        st = self.lib.yl_clone(self.handle, C.byref(h))
+        o.handle = h
+        if st != _lib.YL_OK:
+            if h:
+                self.lib.yl_destroy(h)
+            o.handle = None
+            raise _lib.YoloLiteHipError(f"yl_clone: {self.lib.yl_strerror(st).decode()} ({st})")
+        return o
+
     def set_option(self, name: str, value: int):
         """yl_set_option.  A value that is already set is not sent again: the library drops its cached hipGraphs on
         every option write."""
