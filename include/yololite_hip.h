@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 4
+#define YL_ABI_VERSION 5
 #define YL_MAX_LEVELS 8
 
 typedef struct yl_ctx yl_ctx;
@@ -44,7 +44,12 @@ enum {
 
 /* activations fused into conv epilogues (reference: nn.ReLU / nn.SiLU in model_v2.py:21,34,132,299;
  * timm ReLU / ReLU6 inside the backbones) */
-enum { YL_ACT_NONE = 0, YL_ACT_RELU = 1, YL_ACT_RELU6 = 2, YL_ACT_SILU = 3 };
+enum {
+  YL_ACT_NONE = 0, YL_ACT_RELU = 1, YL_ACT_RELU6 = 2, YL_ACT_SILU = 3,
+  YL_ACT_GELU = 4,      /* erf form, x * 0.5 * (1 + erf(x / sqrt 2)): timm convnextv2 `GlobalResponseNormMlp` (ABI v5)   */
+  YL_ACT_RELU_LAB = 5   /* ReLU followed by timm's LearnableAffineBlock (hgnetv2 `ConvBNAct(use_lab=True)`): two scalars,
+                           lab_scale * relu(v) + lab_bias; valid as `act` of YL_OP_STEM / YL_OP_CONV / YL_OP_DW only (ABI v5) */
+};
 
 /* layer kinds of the forward program */
 enum {
@@ -55,12 +60,26 @@ enum {
   YL_OP_STEMBLOCK = 3, /* fused network entry: stem 3x3 s2 (w,b,act) -> dense 3x3 s2 pad 1 (w2,b2,act2, cout c2)
                          -> optional 1x1 (w3,b3,act3, cout c3), NCHW input to NHWC output; the stem's
                          full-resolution activation (the largest tensor of the network) never reaches HBM  */
-  YL_OP_SE = 4     /* squeeze-excite gate of timm's SqueezeExcite (efficientnetv2 `ir_..._se0.25` blocks behind
+  YL_OP_SE = 4,    /* squeeze-excite gate of timm's SqueezeExcite (efficientnetv2 `ir_..._se0.25` blocks behind
                       model_v2.py:94-100): in_slot [B,H,W,cin] -> out_slot [B,1,1,cin],
                       gate = sigmoid(w2 . act(w . mean_hw(x) + b) + b2); w = conv_reduce [cout][cin][1][1], b [cout],
                       w2 = conv_expand [cin][cout][1][1], b2 [cin] (cout = the reduced width, c2 must equal cin).
                       The spatial mean is a fixed-order two-pass sum (no floating-point atomics: bitwise repeatable).
                       The gate multiplies the INPUT of the conv that names it in `scale_slot`.                     */
+  /* ---- ABI v5: the op kinds of timm's hgnetv2 (configs/models/edge_xl.yaml:4) and convnextv2 (configs/v2_models/yololite_l.yaml:4)
+   * feature extractors behind model_v2.py:94-100,266-272.  Element-wise / reduction passes, HBM-bound. */
+  YL_OP_POOL = 5,  /* max-pool k x k, stride, window origin (oy*stride - pad_t, ox*stride - pad_l) over the input EXTENDED WITH
+                      ZEROS (timm hgnet StemV2: F.pad(x, (0,1,0,1)) then MaxPool2d(2, 1)); cin == cout                        */
+  YL_OP_COPY = 6,  /* channel-slice copy: in_slot [B,H,W,cin] -> channels [out_ch_off, out_ch_off + cin) of out_slot
+                      [B,H,W,C_total]; torch.cat(..., dim=1) = one copy per input (hgnet StemV2 / HighPerfGpuBlock)            */
+  YL_OP_LN = 7,    /* LayerNorm over the channels of every pixel (timm LayerNorm2d / nn.LayerNorm on channels-last):
+                      (x - mean) / sqrt(var + eps) * w + b, biased variance, w / b [cin]; cin == cout                         */
+  YL_OP_GRN = 8,   /* gate of timm's GlobalResponseNorm: in_slot [B,H,W,cin] -> out_slot [B,1,1,cin],
+                      g = sqrt(sum_hw x^2) (fixed-order two-pass sum), gate = 1 + w * g / (mean_c(g) + eps), w [cin].  With the
+                      gate as `scale_slot` of the following 1x1 conv and GRN's bias folded into that conv's bias by the host
+                      (W2 . beta), the conv computes fc2(x + (beta + w * (x * n))) without writing the normalised tensor      */
+  YL_OP_NHWC4 = 9  /* the NCHW fp32 network input [B,3,S,S] -> NHWC [B,S,S,4] (channel 3 = 0) for stems the MFMA stem kernel
+                      does not cover (convnext: 4x4 stride 4, 96 outputs -> a YL_OP_CONV with cin = 4 follows); in_slot ignored */
 };
 
 /*
@@ -108,6 +127,10 @@ typedef struct {
                                  values multiply the conv's input per image and input channel before the GEMM
                                  (x * gate, then conv_pwl: timm InvertedResidual.forward); -1 = none                 */
   int32_t reserved0;          /* 0                                                                                */
+  /* ---- ABI v5 */
+  float lab_scale, lab_bias;  /* act == YL_ACT_RELU_LAB: the two scalars of the LearnableAffineBlock                              */
+  float eps;                  /* YL_OP_LN / YL_OP_GRN                                                                            */
+  int32_t out_ch_off;         /* YL_OP_COPY: first channel of out_slot written; 0 otherwise                                      */
 } yl_layer;
 
 /*

@@ -361,12 +361,252 @@ class FeatureBackbone(nn.Module):
         return [feats[i] for i in self.out_indices]
 
 
+# ============================================================================= hgnetv2 (timm models/hgnet.py)
+# /root/reference/configs/models/edge_xl.yaml:4 (`backbone: hgnetv2_b0`).  RECOLLECTION of timm's HighPerfGpuNet:
+# StemV2 (3x3 s2 -> [2x2 -> 2x2 | max-pool 2x2 s1] on a bottom/right zero-padded map -> concat -> 3x3 s2 -> 1x1),
+# four HighPerfGpuStages (optional depthwise 3x3 s2 downsample without activation; HighPerfGpuBlocks = `layer_num`
+# 3x3 ConvBNAct -- or "light" pairs 1x1 (no act) + depthwise k x k -- whose outputs are concatenated with the block
+# input and aggregated by two 1x1 ConvBNAct ('se' aggregation: total -> out/2 -> out); blocks after the first of a
+# stage are residual).  ConvBNAct = conv (no bias, symmetric padding (k-1)//2) + BatchNorm (eps 1e-5) + ReLU +
+# LearnableAffineBlock (two scalars: scale * x + bias; `use_lab=True` for b0..b3).  Module names follow timm's
+# FeatureListNet with flatten_sequential=True (`stem.*`, `stages_<i>.*`).  Checksum: timm / PaddleClas publish 6.0 M
+# parameters for the classifier (tests/test_oracle_golden.py adds the 1024 -> 2048 -> 1000 head to this trunk).
+class LearnableAffineBlock(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor([1.0]))
+        self.bias = nn.Parameter(torch.tensor([0.0]))
+
+    def forward(self, x):
+        return self.scale * x + self.bias
+
+
+class HgConvBNAct(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, groups=1, use_act=True, use_lab=False):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, padding=(k - 1) // 2, groups=groups, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+        self.act = nn.ReLU() if use_act else nn.Identity()
+        self.lab = LearnableAffineBlock() if (use_act and use_lab) else nn.Identity()
+
+    def forward(self, x):
+        return self.lab(self.act(self.bn(self.conv(x))))
+
+
+class HgLightConvBNAct(nn.Module):
+    def __init__(self, cin, cout, k, use_lab=False):
+        super().__init__()
+        self.conv1 = HgConvBNAct(cin, cout, 1, use_act=False, use_lab=use_lab)
+        self.conv2 = HgConvBNAct(cout, cout, k, groups=cout, use_act=True, use_lab=use_lab)
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x))
+
+
+class HgStemV2(nn.Module):
+    def __init__(self, cin, mid, cout, use_lab=False):
+        super().__init__()
+        self.stem1 = HgConvBNAct(cin, mid, 3, 2, use_lab=use_lab)
+        self.stem2a = HgConvBNAct(mid, mid // 2, 2, 1, use_lab=use_lab)
+        self.stem2b = HgConvBNAct(mid // 2, mid, 2, 1, use_lab=use_lab)
+        self.stem3 = HgConvBNAct(mid * 2, mid, 3, 2, use_lab=use_lab)
+        self.stem4 = HgConvBNAct(mid, cout, 1, 1, use_lab=use_lab)
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=1, ceil_mode=True)
+
+    def forward(self, x):
+        x = self.stem1(x)
+        x = F.pad(x, (0, 1, 0, 1))
+        x2 = self.stem2a(x)
+        x2 = F.pad(x2, (0, 1, 0, 1))
+        x2 = self.stem2b(x2)
+        x1 = self.pool(x)
+        x = torch.cat([x1, x2], dim=1)
+        return self.stem4(self.stem3(x))
+
+
+class HgBlock(nn.Module):
+    def __init__(self, cin, mid, cout, layer_num, k=3, residual=False, light=False, use_lab=False):
+        super().__init__()
+        self.residual = residual
+        self.layers = nn.ModuleList()
+        for i in range(layer_num):
+            c = cin if i == 0 else mid
+            self.layers.append(HgLightConvBNAct(c, mid, k, use_lab) if light else HgConvBNAct(c, mid, k, 1, use_lab=use_lab))
+        total = cin + layer_num * mid
+        self.aggregation = nn.Sequential(HgConvBNAct(total, cout // 2, 1, use_lab=use_lab),
+                                         HgConvBNAct(cout // 2, cout, 1, use_lab=use_lab))
+
+    def forward(self, x):
+        identity = x
+        outs = [x]
+        for layer in self.layers:
+            x = layer(x)
+            outs.append(x)
+        x = self.aggregation(torch.cat(outs, dim=1))
+        return x + identity if self.residual else x
+
+
+class HgStage(nn.Module):
+    def __init__(self, cin, mid, cout, block_num, layer_num, downsample, light, k, use_lab):
+        super().__init__()
+        self.downsample = (HgConvBNAct(cin, cin, 3, 2, groups=cin, use_act=False, use_lab=use_lab) if downsample
+                           else nn.Identity())
+        self.blocks = nn.Sequential(*[HgBlock(cin if i == 0 else cout, mid, cout, layer_num, k, residual=i > 0,
+                                              light=light, use_lab=use_lab) for i in range(block_num)])
+
+    def forward(self, x):
+        return self.blocks(self.downsample(x))
+
+
+# name -> (stem [mid, out], stages [(in, mid, out, blocks, downsample, light, kernel, layer_num)], use_lab)
+_HGNET = {
+    "hgnetv2_b0": ((16, 16), [(16, 16, 64, 1, False, False, 3, 3), (64, 32, 256, 1, True, False, 3, 3),
+                              (256, 64, 512, 2, True, True, 5, 3), (512, 128, 1024, 1, True, True, 5, 3)], True),
+    # tiny test vehicle (NOT a timm model): every block flavour (plain / light, residual second block, no downsample)
+    "oracle_tiny_hg": ((8, 8), [(8, 8, 16, 1, False, False, 3, 2), (16, 8, 32, 1, True, False, 3, 3),
+                                (32, 8, 48, 2, True, True, 5, 2), (48, 16, 64, 1, True, True, 5, 3)], True),
+}
+
+
+class HgFeatureBackbone(nn.Module):
+    def __init__(self, name, out_indices=None):
+        super().__init__()
+        (smid, sout), stages, use_lab = _HGNET[name]
+        self.stem = HgStemV2(3, smid, sout, use_lab)
+        red, info = 4, []
+        for i, (cin, mid, cout, nb, ds, light, k, ln) in enumerate(stages):
+            setattr(self, f"stages_{i}", HgStage(cin, mid, cout, nb, ln, ds, light, k, use_lab))
+            red *= 2 if ds else 1
+            info.append(dict(num_chs=cout, reduction=red, module=f"stages.{i}"))
+        self._n = len(stages)
+        self.out_indices = tuple(out_indices) if out_indices is not None else tuple(range(len(info)))
+        self.feature_info = info
+
+    def forward(self, x):
+        x = self.stem(x)
+        feats = []
+        for i in range(self._n):
+            x = getattr(self, f"stages_{i}")(x)
+            feats.append(x)
+        return [feats[i] for i in self.out_indices]
+
+
+# ============================================================================= convnextv2 (timm models/convnext.py)
+# /root/reference/configs/v2_models/yololite_l.yaml:4 (`backbone: convnextv2_tiny`).  RECOLLECTION of timm's ConvNeXt with
+# use_grn=True, ls_init_value=None, conv_mlp=False: stem = conv 4x4 s4 (bias) + LayerNorm2d; stage i>0 starts with
+# LayerNorm2d + conv 2x2 s2 (bias); block = depthwise 7x7 pad 3 (bias) -> LayerNorm over C (eps 1e-6) -> Linear C->4C ->
+# GELU (erf) -> GlobalResponseNorm -> Linear 4C->C -> + shortcut.  GRN (channels last): g = ||x||_2 over (H, W) per image and
+# channel, n = g / (mean_C(g) + 1e-6), y = x + (bias + weight * (x * n)).  Module names follow FeatureListNet with
+# flatten_sequential=True (`stem_0`, `stem_1`, `stages_<i>.*`).  Checksum: timm publishes 28.64 M parameters for the
+# classifier (tests/test_oracle_golden.py adds the LayerNorm + 768 -> 1000 head to this trunk).
+class LayerNorm2d(nn.LayerNorm):
+    def __init__(self, ch, eps=1e-6):
+        super().__init__(ch, eps=eps)
+
+    def forward(self, x):
+        x = x.permute(0, 2, 3, 1)
+        x = F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        return x.permute(0, 3, 1, 2)
+
+
+class GlobalResponseNorm(nn.Module):
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.zeros(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):                                  # channels last [B, H, W, C]
+        x_g = x.norm(p=2, dim=(1, 2), keepdim=True)
+        x_n = x_g / (x_g.mean(dim=-1, keepdim=True) + self.eps)
+        return x + torch.addcmul(self.bias.view(1, 1, 1, -1), self.weight.view(1, 1, 1, -1), x * x_n)
+
+
+class GrnMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.grn = GlobalResponseNorm(hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.grn(self.act(self.fc1(x))))
+
+
+class ConvNeXtBlock(nn.Module):
+    def __init__(self, dim, k=7):
+        super().__init__()
+        self.conv_dw = nn.Conv2d(dim, dim, k, 1, padding=k // 2, groups=dim, bias=True)
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = GrnMlp(dim, 4 * dim)
+
+    def forward(self, x):
+        y = self.conv_dw(x).permute(0, 2, 3, 1)
+        y = self.mlp(self.norm(y)).permute(0, 3, 1, 2)
+        return y + x
+
+
+class ConvNeXtStage(nn.Module):
+    def __init__(self, cin, cout, stride, depth, k=7):
+        super().__init__()
+        if cin != cout or stride > 1:
+            self.downsample = nn.Sequential(LayerNorm2d(cin), nn.Conv2d(cin, cout, stride, stride, bias=True))
+        else:
+            self.downsample = nn.Identity()
+        self.blocks = nn.Sequential(*[ConvNeXtBlock(cout, k) for _ in range(depth)])
+
+    def forward(self, x):
+        return self.blocks(self.downsample(x))
+
+
+# name -> (depths, dims, depthwise kernel)
+_CONVNEXT = {
+    "convnextv2_tiny": ((3, 3, 9, 3), (96, 192, 384, 768), 7),
+    "convnextv2_nano": ((2, 2, 8, 2), (80, 160, 320, 640), 7),
+    "convnextv2_pico": ((2, 2, 6, 2), (64, 128, 256, 512), 7),
+    "convnextv2_femto": ((2, 2, 6, 2), (48, 96, 192, 384), 7),
+    "convnextv2_atto": ((2, 2, 6, 2), (40, 80, 160, 320), 7),
+    "oracle_tiny_cnx": ((1, 2, 2, 1), (8, 16, 24, 32), 7),          # tiny test vehicle (NOT a timm model)
+}
+
+
+class ConvNeXtFeatureBackbone(nn.Module):
+    def __init__(self, name, out_indices=None):
+        super().__init__()
+        depths, dims, k = _CONVNEXT[name]
+        self.stem_0 = nn.Conv2d(3, dims[0], 4, 4, bias=True)
+        self.stem_1 = LayerNorm2d(dims[0])
+        red, prev, info = 4, dims[0], []
+        for i, (d, c) in enumerate(zip(depths, dims)):
+            s = 2 if i > 0 else 1
+            setattr(self, f"stages_{i}", ConvNeXtStage(prev, c, s, d, k))
+            red *= s
+            prev = c
+            info.append(dict(num_chs=c, reduction=red, module=f"stages.{i}"))
+        self._n = len(depths)
+        self.out_indices = tuple(out_indices) if out_indices is not None else tuple(range(len(info)))
+        self.feature_info = info
+
+    def forward(self, x):
+        x = self.stem_1(self.stem_0(x))
+        feats = []
+        for i in range(self._n):
+            x = getattr(self, f"stages_{i}")(x)
+            feats.append(x)
+        return [feats[i] for i in self.out_indices]
+
+
 def create_model(name: str, features_only: bool = True, pretrained: bool = False,
                  out_indices: Optional[Sequence[int]] = None, **_):
     """Signature-compatible stand-in for ``timm.create_model`` (features_only models only).
     ``pretrained`` is accepted and ignored: there is no network and no weight file."""
     if not features_only:
         raise NotImplementedError("oracle restates features_only backbones only")
+    if name in _HGNET:
+        return HgFeatureBackbone(name, out_indices)
+    if name in _CONVNEXT:
+        return ConvNeXtFeatureBackbone(name, out_indices)
     if name not in _ZOO:
         raise ValueError(f"oracle backbone '{name}' not restated")
     return FeatureBackbone(name, out_indices)

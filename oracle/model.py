@@ -249,6 +249,11 @@ MODEL_ZOO = {
                           width_multiple=1.0, fpn_channels=256, head_depth=2),
     "yololite_m_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b2", depth_multiple=1.0,
                           width_multiple=1.0, fpn_channels=328, head_depth=2),
+    # /root/reference/configs/models/edge_xl.yaml (hgnetv2_b0), configs/v2_models/yololite_l.yaml (convnextv2_tiny)
+    "edge_xl": dict(arch="YOLOLiteMS_CPU", backbone="hgnetv2_b0", depth_multiple=1.0, width_multiple=1.0,
+                    fpn_channels=256, head_depth=3),
+    "yololite_l_v2": dict(arch="YOLOLiteMS", backbone="convnextv2_tiny", depth_multiple=1.0, width_multiple=1.0,
+                          fpn_channels=512, head_depth=3),
 }
 
 

@@ -68,6 +68,12 @@ TINY = [
          use_p2=True),
     # efficientnetv2-style: ConvBnAct with residual, fused MBConv (strided / residual), MBConv + squeeze-excite, SiLU
     dict(arch="YOLOLiteMS", backbone="oracle_tiny_v2", num_classes=6, fpn_channels=24, depth_multiple=0.5, head_depth=1),
+    # hgnetv2-style (round 5): StemV2 (2x2 convs on a zero-extended map, max-pool, concat), plain and light HG blocks with
+    # concat + two 1x1 aggregation convs, residual second block, depthwise downsample, ReLU + learnable affine everywhere
+    dict(arch="YOLOLiteMS_CPU", backbone="oracle_tiny_hg", num_classes=4, fpn_channels=16, depth_multiple=0.5, head_depth=1),
+    # convnextv2-style (round 5): 4x4 s4 stem on the NHWC4 copy of the input, LayerNorm2d, depthwise 7x7, LayerNorm, Linear +
+    # GELU, GlobalResponseNorm gate, gated Linear + residual, LayerNorm2d + 2x2 s2 downsample
+    dict(arch="YOLOLiteMS", backbone="oracle_tiny_cnx", num_classes=3, fpn_channels=16, depth_multiple=0.5, head_depth=1),
 ]
 
 
@@ -143,6 +149,28 @@ def test_every_zoo_config_runs_on_the_gpu(name):
             ref = _oracle_for(meta, sd)(x)
         outs = _hip_for(meta, sd)(x.to(DEV))
         _cmp_levels(outs, ref, C=80)
+
+
+def test_convnext_and_hgnet_ops_are_deterministic_and_batch_invariant():
+    """ABI v5 ops (YL_OP_POOL / COPY / LN / GRN / NHWC4, GELU, ReLU + learnable affine): the GRN gate is a fixed-order two-pass
+    sum per image (no float atomics), LayerNorm a per-pixel wave reduction -- the forward is bitwise repeatable and an
+    image's rows do not depend on the batch it is part of or on the chunk split."""
+    for idx in (len(TINY) - 2, len(TINY) - 1):
+        meta = make_meta(img_size=96, **TINY[idx])
+        m = _hip_for(meta, synth_state_dict(meta, seed=21 + idx))
+        ctx = m._ctx_for(96)
+        ops = {l.op for l in m.program.layers}
+        assert ({_lib.OP_POOL, _lib.OP_COPY} <= ops) if "hg" in TINY[idx]["backbone"] else ({_lib.OP_LN, _lib.OP_GRN, _lib.OP_NHWC4} <= ops)
+        x = _x(9, 96, seed=5).to(DEV)
+        a = [t.clone() for t in m(x)]
+        for streams in (1, 2, 3):
+            ctx.set_option("streams", streams)
+            for u, v in zip(a, m(x)):
+                assert torch.equal(u, v)
+        ctx.set_option("streams", 1)
+        for b in (0, 4, 8):
+            for u, v in zip(a, m(x[b:b + 1])):
+                assert torch.equal(u[b:b + 1], v)
 
 
 def test_squeeze_excite_gate_is_deterministic_and_batch_invariant():

@@ -38,11 +38,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # YOLOLITE_HIP_LIB selects another build of the same ABI (kernel A/B runs); default: the in-tree library
 LIB_PATH = os.environ.get("YOLOLITE_HIP_LIB") or os.path.join(_HERE, "libyololite_hip.so")
 
-YL_ABI_VERSION = 4
+YL_ABI_VERSION = 5
 YL_MAX_LEVELS = 8
 YL_OK = 0
-ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
+ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3, "gelu": 4, "relu_lab": 5}
 OP_STEM, OP_CONV, OP_DW, OP_STEMBLOCK, OP_SE = 0, 1, 2, 3, 4
+OP_POOL, OP_COPY, OP_LN, OP_GRN, OP_NHWC4 = 5, 6, 7, 8, 9
 POST_MAIN, POST_FALLBACK, POST_EVAL = 0, 1, 2
 CENTER = {"v8": 0, "simple": 1}
 WH = {"softplus": 0, "v8": 1, "exp": 2}
@@ -62,7 +63,8 @@ class yl_layer(C.Structure):
         "k", "stride", "pad_t", "pad_l", "act", "in_shift", "dw_k", "dw_stride", "dw_pad_t", "dw_pad_l", "dw_act")] + [
         ("w", _fp), ("b", _fp), ("dw_w", _fp), ("dw_b", _fp),
         ("c2", C.c_int32), ("act2", C.c_int32), ("c3", C.c_int32), ("act3", C.c_int32),
-        ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("scale_slot", C.c_int32), ("reserved0", C.c_int32)]
+        ("w2", _fp), ("b2", _fp), ("w3", _fp), ("b3", _fp), ("scale_slot", C.c_int32), ("reserved0", C.c_int32),
+        ("lab_scale", C.c_float), ("lab_bias", C.c_float), ("eps", C.c_float), ("out_ch_off", C.c_int32)]
 
 
 class yl_model_desc(C.Structure):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build libyololite_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
-nine translation units (three of them compiled three times: fp32, bf16-MFMA and fp16-MFMA builds), one shared library with a plain C ABI (include/yololite_hip.h).
+ten translation units (three of them compiled three times: fp32, bf16-MFMA and fp16-MFMA builds), one shared library with a plain C ABI (include/yololite_hip.h).
 
     python yololite-official-repo_amd/csrc/build.py [--force | --asan]
 """
@@ -20,6 +20,8 @@ UNITS = [   # (source, extra flags, object name)
     ("yl_convc.hip", [], "yl_convc.o"),
     ("yl_dpp.hip", [], "yl_dpp.o"),
     ("yl_se.hip", [], "yl_se.o"),
+    # element-wise / reduction ops of the hgnetv2 / convnextv2 backbones: one rounding per operation (LayerNorm, GRN)
+    ("yl_ops.hip", ["-ffp-contract=off"], "yl_ops.o"),
     ("yl_convc.hip", ["-DYL_BF16=1"], "yl_convc_bf16.o"),
     # bf16-MFMA inference mode: the same two units compiled again under distinct symbol names (yl_dev.h)
     ("yl_conv.hip", ["-DYL_BF16=1"], "yl_conv_bf16.o"),

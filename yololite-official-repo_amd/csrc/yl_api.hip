@@ -349,7 +349,7 @@ void plan_slots(yl_ctx* c, bool reuse) {
   for (size_t i = 0; i < NL; ++i) {
     const yl_layer& d = c->layers[i].d;
     if (d.head_level < 0 && d.out_slot >= 0 && grp[i] < def[d.out_slot]) def[d.out_slot] = grp[i];
-    const int ins[4] = {(d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? -1 : d.in_slot, d.res_slot, d.up_slot, d.scale_slot};
+    const int ins[4] = {(d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK || d.op == YL_OP_NHWC4) ? -1 : d.in_slot, d.res_slot, d.up_slot, d.scale_slot};
     for (int k = 0; k < 4; ++k)
       if (ins[k] >= 0 && grp[i] > last[ins[k]]) last[ins[k]] = grp[i];
   }
@@ -507,6 +507,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   p.OH = L.out_h; p.OW = L.out_w; p.N = d.cout;
   p.k = d.k; p.stride = d.stride; p.pad_t = d.pad_t; p.pad_l = d.pad_l; p.act = d.act;
   p.in_shift = d.in_shift;
+  p.lab_s = d.lab_scale; p.lab_b = d.lab_bias;
   p.dw_k = d.dw_k; p.dw_stride = d.dw_stride; p.dw_pad_t = d.dw_pad_t; p.dw_pad_l = d.dw_pad_l; p.dw_act = d.dw_act;
   p.MH = L.out_h; p.MW = L.out_w;
   p.KB = cdiv(d.cin, 16);
@@ -514,7 +515,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   p.NTtot = cdiv(d.cout, 16);
   p.M = B * L.out_h * L.out_w;
   auto slot_ptr = [&](int sl) { return slot_addr(c, sl, b0); };
-  p.x = (d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK) ? x + (size_t)b0 * 3 * L.in_h * L.in_w : slot_ptr(d.in_slot);
+  p.x = (d.op == YL_OP_STEM || d.op == YL_OP_STEMBLOCK || d.op == YL_OP_NHWC4) ? x + (size_t)b0 * 3 * L.in_h * L.in_w : slot_ptr(d.in_slot);
   if (d.op == YL_OP_CONV && d.c2 > 0) {      // fused expand -> depthwise -> project
     p.w2p = L.w2p; p.b2 = L.b2; p.C1 = d.c2; p.act2 = d.act2;
   }
@@ -573,7 +574,7 @@ bool head_run_fusable(const yl_ctx* c, size_t i, size_t gend, size_t lend) {
     const DevLayer& O = c->layers[gend + q];
     const yl_layer& t = T.d; const yl_layer& o = O.d;
     if (t.op != YL_OP_CONV || t.k != 1 || t.dw_k != 3 || t.dw_stride != 1 || t.c2 > 0 || t.c3 > 0 || t.head_level >= 0 ||
-        t.res_slot >= 0 || t.up_slot >= 0 || t.in_shift || t.act == YL_ACT_SILU || t.dw_act == YL_ACT_SILU || t.out_slot < 0)
+        t.res_slot >= 0 || t.up_slot >= 0 || t.in_shift || YL_SMOOTH(t.act) || YL_SMOOTH(t.dw_act) || t.out_slot < 0)
       return false;
     if (o.op != YL_OP_CONV || o.head_level < 0 || o.k != 1 || o.dw_k > 0 || o.c2 > 0 || o.c3 > 0 || o.in_slot != t.out_slot ||
         o.cin != t.cout || o.act != YL_ACT_NONE || o.res_slot >= 0 || o.up_slot >= 0 || o.in_shift)
@@ -596,10 +597,10 @@ bool pair_fusable(const yl_ctx* c, size_t i, size_t lend, bool ignore_options) {
   const DevLayer& T = c->layers[i];
   const yl_layer& t = T.d; const yl_layer& o = c->layers[i + 1].d;
   if (t.op != YL_OP_CONV || t.k != 1 || t.dw_k != 3 || t.dw_stride != 1 || t.c2 > 0 || t.c3 > 0 || t.head_level >= 0 ||
-      t.res_slot >= 0 || t.up_slot >= 0 || t.in_shift || t.act == YL_ACT_SILU || t.dw_act == YL_ACT_SILU || t.out_slot < 0)
+      t.res_slot >= 0 || t.up_slot >= 0 || t.in_shift || YL_SMOOTH(t.act) || YL_SMOOTH(t.dw_act) || t.out_slot < 0)
     return false;
   if (o.op != YL_OP_CONV || o.head_level >= 0 || o.k != 1 || o.dw_k > 0 || o.c2 > 0 || o.c3 > 0 || o.in_slot != t.out_slot ||
-      o.cin != t.cout || o.act == YL_ACT_SILU || o.up_slot >= 0 || o.in_shift || o.res_slot == t.out_slot ||
+      o.cin != t.cout || YL_SMOOTH(o.act) || o.up_slot >= 0 || o.in_shift || o.res_slot == t.out_slot ||
       o.scale_slot >= 0 || t.scale_slot >= 0)
     return false;
   if (T.in_h != T.out_h || T.in_w != T.out_w || !yl_dpq_supported(t.cin, t.cout, o.cout, T.out_h, T.out_w)) return false;
@@ -765,7 +766,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
       bool cross = false;
       const int ins[4] = {d.in_slot, d.res_slot, d.up_slot, d.scale_slot};
       for (int k = 0; k < 4; ++k)
-        if (ins[k] >= 0 && d.op != YL_OP_STEM && d.op != YL_OP_STEMBLOCK && prod[ins[k]] != ln) cross = true;
+        if (ins[k] >= 0 && d.op != YL_OP_STEM && d.op != YL_OP_STEMBLOCK && d.op != YL_OP_NHWC4 && prod[ins[k]] != ln) cross = true;
       if (ln == 1 && !side_used) cross = true;             // first side launch: order after everything enqueued so far
       if (cross) {
         hipEvent_t ev = ln ? c->ev_la[chunk] : c->ev_lb[chunk];
@@ -806,6 +807,25 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
           }
         }
         e = yl_launch_dw(p, ls);
+        break;
+      }
+      case YL_OP_POOL: case YL_OP_COPY: case YL_OP_LN: case YL_OP_GRN: case YL_OP_NHWC4: {
+        const DevLayer& L = c->layers[i];
+        YlOpP q;
+        memset(&q, 0, sizeof(q));
+        q.x = p.x; q.out = p.out; q.w = L.wp; q.b = L.bias;
+        q.B = B; q.H = L.in_h; q.W = L.in_w; q.C = d.cin;
+        q.OH = d.op == YL_OP_GRN ? L.in_h : L.out_h; q.OW = d.op == YL_OP_GRN ? L.in_w : L.out_w;
+        q.k = d.k; q.stride = d.stride; q.pad_t = d.pad_t; q.pad_l = d.pad_l;
+        q.ldo = d.op == YL_OP_COPY ? c->slots[d.out_slot].c : d.cin; q.ch_off = d.out_ch_off;
+        q.eps = d.eps;
+        if (d.op == YL_OP_GRN) {
+          q.P = yl_grn_parts(L.in_h * L.in_w);
+          int ch = 0;                                          // the chunk arena these images live in
+          while (ch + 1 < c->plan_n && b0 >= c->plan_b0[ch + 1]) ++ch;
+          q.partial = c->se_scratch[ch] + (size_t)(b0 - c->plan_b0[ch]) * c->se_unit;
+        }
+        e = yl_launch_op(d.op, q, ls);
         break;
       }
       case YL_OP_STEM: e = yl_launch_stem(p, ls); break;
@@ -1267,10 +1287,59 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       snprintf(msg, sizeof(msg), "layer %d: %s", i, what);
       return fail(c, YL_ERR_INVALID, msg);
     };
-    if (l.op < YL_OP_STEM || l.op > YL_OP_SE) return bad("unknown op");
+    if (l.op < YL_OP_STEM || l.op > YL_OP_NHWC4) return bad("unknown op");
+    if (l.reserved0 != 0) return bad("reserved0 must be 0");
+    if (l.act < YL_ACT_NONE || l.act > YL_ACT_RELU_LAB || l.dw_act < 0 || l.dw_act > YL_ACT_SILU || l.act2 < 0 || l.act2 > YL_ACT_SILU ||
+        l.act3 < 0 || l.act3 > YL_ACT_SILU)
+      return bad("unknown activation (GELU / ReLU+affine are valid as `act` only)");
+    if (l.act == YL_ACT_RELU_LAB && l.op != YL_OP_STEM && l.op != YL_OP_CONV && l.op != YL_OP_DW) return bad("ReLU + learnable affine: STEM / CONV / DW only");
+    if (l.out_ch_off != 0 && l.op != YL_OP_COPY) return bad("out_ch_off is a YL_OP_COPY field");
+    if (l.op >= YL_OP_POOL) {
+      // element-wise / reduction ops (ABI v5): in_slot -> out_slot, no conv fields
+      if (l.out_slot < 0 || l.out_slot >= d->num_slots) return bad("bad out_slot");
+      if (l.op != YL_OP_NHWC4 && (l.in_slot < 0 || l.in_slot >= d->num_slots)) return bad("bad in_slot");
+      if (l.res_slot >= 0 || l.up_slot >= 0 || l.scale_slot >= 0 || l.head_level >= 0 || l.dw_k || l.c2 || l.c3 || l.in_shift || l.act)
+        return bad("element-wise op: plain layer fields only");
+      const Slot& so = c->slots[l.out_slot];
+      if (l.op == YL_OP_NHWC4) {
+        if (so.h != d->img_size || so.w != d->img_size || so.c != 4 || l.cout != 4) return bad("NHWC4: out_slot must be [S,S,4]");
+        L.in_h = L.in_w = d->img_size; L.out_h = L.out_w = d->img_size;
+      } else {
+        const Slot& si = c->slots[l.in_slot];
+        if (si.c != l.cin || (l.cin & 3)) return bad("cin does not match the input slot / not a multiple of 4");
+        L.in_h = si.h; L.in_w = si.w; L.out_h = so.h; L.out_w = so.w;
+        if (l.op == YL_OP_POOL) {
+          if (l.k < 1 || l.stride < 1 || l.cout != l.cin || so.c != l.cin || l.pad_t < 0 || l.pad_l < 0 || l.pad_t >= l.k || l.pad_l >= l.k ||
+              (so.h - 1) * l.stride - l.pad_t >= si.h || (so.w - 1) * l.stride - l.pad_l >= si.w)
+            return bad("pool: bad geometry");
+        } else if (l.op == YL_OP_COPY) {
+          if (so.h != si.h || so.w != si.w || l.out_ch_off < 0 || (l.out_ch_off & 3) || l.out_ch_off + l.cin > so.c)
+            return bad("copy: channel slice outside the output slot");
+        } else if (l.op == YL_OP_LN) {
+          if (so.h != si.h || so.w != si.w || so.c != l.cin || l.cout != l.cin || !l.w || !l.b || !(l.eps > 0.0f)) return bad("layer norm: needs w, b [cin], eps > 0, same shape out");
+        } else {     // GRN
+          if (so.h != 1 || so.w != 1 || so.c != l.cin || !l.w || !(l.eps > 0.0f) || l.cin > 16384) return bad("GRN: out_slot must be [1,1,cin], needs w [cin], eps > 0");
+          const size_t unit = (size_t)64 * l.cin;
+          if (unit > c->se_unit) c->se_unit = unit;
+          L.out_h = L.out_w = 1;
+        }
+      }
+      yl_status s2;
+      if (l.w && (l.op == YL_OP_LN || l.op == YL_OP_GRN)) {
+        std::vector<float> wv(l.w, l.w + l.cin);
+        if ((s2 = upload(c, wv, &L.wp)) != YL_OK) return s2;
+      }
+      if (l.b && l.op == YL_OP_LN) {
+        std::vector<float> bv(l.b, l.b + l.cin);
+        if ((s2 = upload(c, bv, &L.bias)) != YL_OK) return s2;
+      }
+      L.d.w = L.d.b = L.d.dw_w = L.d.dw_b = nullptr;
+      L.d.w2 = L.d.b2 = L.d.w3 = L.d.b3 = nullptr;
+      c->layers.push_back(L);
+      continue;
+    }
     if (!l.w) return bad("weights are NULL");
     if (l.k < 1 || l.stride < 1) return bad("bad kernel geometry");
-    if (l.reserved0 != 0) return bad("reserved0 must be 0");
     if (l.op == YL_OP_SE) {
       // squeeze-excite gate: in_slot [H,W,cin] -> out_slot [1,1,cin]; w/b = conv_reduce [cout][cin], w2/b2 = conv_expand [cin][cout]
       if (l.in_slot < 0 || l.in_slot >= d->num_slots || l.out_slot < 0 || l.out_slot >= d->num_slots) return bad("bad slot");
@@ -1308,7 +1377,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       L.in_h = L.in_w = d->img_size;
       if (l.cin != 3 || l.k != 3) return fail(c, YL_ERR_UNSUPPORTED, "stem must be 3x3 with 3 input channels");
       if (!l.w2 || l.c2 < 1 || l.c3 < 0 || (l.c3 > 0 && !l.w3)) return bad("stem block needs w2 (and w3 when c3 > 0)");
-      if (l.act == YL_ACT_SILU || l.act2 == YL_ACT_SILU || l.act3 == YL_ACT_SILU)
+      if (YL_SMOOTH(l.act) || YL_SMOOTH(l.act2) || YL_SMOOTH(l.act3))
         return fail(c, YL_ERR_UNSUPPORTED, "stem block: ReLU-family activations only");
       if (!yl_stemblock_supported(l.cout, l.c2, l.c3))
         return fail(c, YL_ERR_UNSUPPORTED, "stem block: c1 in {16,32}, c2,c3 <= 32 and multiples of 4");
@@ -1388,7 +1457,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     }
     if (l.op == YL_OP_DW && l.cin != l.cout) return bad("depthwise needs cin == cout");
     if (l.op != YL_OP_STEM && l.op != YL_OP_STEMBLOCK && (l.cin & 3)) return fail(c, YL_ERR_UNSUPPORTED, "cin must be a multiple of 4");
-    if ((l.res_slot >= 0 || l.up_slot >= 0 || l.act == YL_ACT_SILU) && (l.cout & 3) && l.op == YL_OP_CONV)
+    if ((l.res_slot >= 0 || l.up_slot >= 0 || YL_SMOOTH(l.act)) && (l.cout & 3) && l.op == YL_OP_CONV)
       return fail(c, YL_ERR_UNSUPPORTED, "residual/upsample/SiLU epilogue needs cout % 4 == 0");
 
     // ---- pack + upload
@@ -1438,7 +1507,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       }
       if (l.c3 > 0) {       // chained 1x1 conv [c3][cout][1][1]: its k-blocks are this conv's 16-wide n-tiles
         if (!l.w3 || l.k < 2 || l.dw_k > 0 || l.c2 > 0 || l.head_level >= 0 || l.res_slot >= 0 || l.up_slot >= 0 || l.in_shift ||
-            (l.cout & 3) || (l.c3 & 3) || l.c3 > 32 || l.cout > 96 || l.act == YL_ACT_SILU || l.act3 == YL_ACT_SILU)
+            (l.cout & 3) || (l.c3 & 3) || l.c3 > 32 || l.cout > 96 || YL_SMOOTH(l.act) || YL_SMOOTH(l.act3))
           return fail(c, YL_ERR_UNSUPPORTED, "chained 1x1 conv: needs a plain dense k x k conv (<= 96 channels out), c3 <= 32, ReLU-family activations");
         std::vector<float> w3, b3v((size_t)cdiv(l.c3, 16) * 16, 0.0f);
         pack_conv(l.w3, l.c3, l.cout, 1, w3);

@@ -184,7 +184,7 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float e = fminf(fmaxf(v[r], lo), hi);
-          if (p.act == YL_ACT_SILU) e = yl_act1(v[r], YL_ACT_SILU);
+          if (YL_SMOOTH(p.act)) e = yl_post1(v[r], p.act, p.lab_s, p.lab_b);
           if (n + r < p.N) stg[(mt * 16 + pl) * p.N + n + r] = e;
         }
       }
@@ -213,7 +213,7 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float e = fminf(fmaxf(v[r], lo), hi);
-        if (p.act == YL_ACT_SILU) e = yl_act1(v[r], YL_ACT_SILU);
+        if (YL_SMOOTH(p.act)) e = yl_post1(v[r], p.act, p.lab_s, p.lab_b);
         if (n + r < p.N) orow[(nt0 + nt) * 16 + r] = e;
       }
     }
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 && MODE <= 1) ? YL_PW_WAVES : 3)
     if (p.dec_boxes) yl_epi_decode<NT, MT>(p, acc, px, nt0, kq, lane);
     if (p.dec_boxes && !p.dec_raw) continue;
     if (p.N & 3) yl_epi_scalar<NT, MT>(p, acc, px, nt0, kq, lo, hi, stg, ((size_t)tile * 4 + wave) * (MT * 16), lane);
-    else if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    else if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, !bias0);
   }
 }
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
         stage_store(stg);
       }
     }
-    if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, !bias0);
   }
 }
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256) void yl_uib_kernel(YlConvP p) {
           acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[ss], xq[ss], acc[0][nt], 0, 0, 0);
       }
     }
-    if (!pre_add && (p.res || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    if (!pre_add && (p.res || YL_SMOOTH(p.act))) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, true);
   }
 }
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void yl_stem_mfma_kernel(YlConvP p) {
       for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 16 + 4 * kq;
         f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
-        if (p.act == YL_ACT_SILU) v = yl_act4(v, YL_ACT_SILU);
+        if (YL_SMOOTH(p.act)) v = yl_post4(v, p.act, p.lab_s, p.lab_b);
         v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
         v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
         *reinterpret_cast<f32x4*>(orow + n) = v;
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void yl_dw_kernel(YlConvP p) {
       s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
     }
   }
-  s = yl_act4(s, p.act);
+  s = yl_post4(s, p.act, p.lab_s, p.lab_b);
   const size_t o = lin * p.N + c;
   if (p.res) s += yl_ld4(p.res + o);
   *reinterpret_cast<f32x4*>(p.out + o) = s;
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
       for (int j = 0; j < TX; ++j) {
         const int ox = ox0 + j;
         if (ox >= OW) continue;
-        f32x4 s4 = yl_act4(acc[t][j], p.act);
+        f32x4 s4 = yl_post4(acc[t][j], p.act, p.lab_s, p.lab_b);
         const size_t o = (((size_t)b * OH + oy) * OW + ox) * p.N + c;
         if (p.res) s4 += yl_ld4(p.res + o);
         if (POOL) psum += s4;

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwc_kernel(YlConvMulti mp) {
       for (int nt = 0; nt < NTW; ++nt) breg[nt] = yl_ld4(p.bias + (nt0 + nt) * 16 + 4 * kq);   // bias is padded
     }
     const bool pre_add = p.res != nullptr && p.up == nullptr && p.act == YL_ACT_NONE;
-    const bool generic = !pre_add && (p.res || p.up || p.act == YL_ACT_SILU);
+    const bool generic = !pre_add && (p.res || p.up || YL_SMOOTH(p.act));
     __syncthreads();
     DWC_STAMP(1);
     for (int it = 0; it <= nmine; ++it) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
   if (DEC) { yl_epi_decode<NTW, MT>(p, acc, px, nt0, kq, lane); return; }   // head output under yl_predict (one wave = whole rows)
-  if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NTW, MT>(p, acc, px, nt0, kq);
+  if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NTW, MT>(p, acc, px, nt0, kq);
   else yl_epi_fast<NTW, MT>(p, acc, px, nt0, kq, lo, hi, true);
 }
 
@@ -785,11 +785,11 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
         one[0][0] = ((rb[(0 * NT + nt) * 64 + lane] + rb[(1 * NT + nt) * 64 + lane]) + rb[(2 * NT + nt) * 64 + lane]) +
                     rb[(3 * NT + nt) * 64 + lane];
         const YlPix px1[1] = {px[0]};
-        if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<1, 1>(p, one, px1, nt, kq);
+        if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<1, 1>(p, one, px1, nt, kq);
         else yl_epi_fast<1, 1>(p, one, px1, nt, kq, lo, hi, true);
       }
     } else {
-      if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
+      if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
       else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
     }
     txi += sdx;
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_kxk_kernel(Y
         __syncthreads();           // every wave is done with `buf`; the copies into the other buffer have landed
       }
     }
-    if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
+    if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, MT>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, nt0, kq, lo, hi, true);
   }
 }
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
       }
       __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
     }
-    if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, 1>(p, acc, px, nt0, kq);
+    if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, 1>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, 1>(p, acc, px, nt0, kq, lo, hi, true);
   }
 }
@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
       for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
       yl_mma_step<NT, MT>(wq, xq, acc);
     }
-    if (!pre_add && (p.res || p.act == YL_ACT_SILU)) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
+    if (!pre_add && (p.res || YL_SMOOTH(p.act))) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
   }
 }
@@ -1766,7 +1766,7 @@ __global__ __launch_bounds__(NW * 64, GW == 1 ? 3 : 2) void yl_conv_dwk_kernel(Y
     }
 #pragma unroll
     for (int gw = 0; gw < GW; ++gw) {
-      if (!pre_add && (p.res || p.up || p.act == YL_ACT_SILU)) yl_epi_generic<NT, 1>(p, acc[gw], px, nt0 + gw * NT, kq);
+      if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, 1>(p, acc[gw], px, nt0 + gw * NT, kq);
       else yl_epi_fast<NT, 1>(p, acc[gw], px, nt0 + gw * NT, kq, lo, hi, true);
     }
   }
@@ -1985,7 +1985,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
             const int oy = 2 * ty + a, ox = 2 * tx + c2;
             if (oy < OH && ox < OW) {
               const size_t o = (((size_t)b * OH + oy) * OW + ox) * N + n;
-              f32x4 v = yl_actc(y[a][c2] + bias, p.act, lo, hi);
+              f32x4 v = YL_SMOOTH(p.act) ? yl_post4(y[a][c2] + bias, p.act, p.lab_s, p.lab_b) : yl_clamp4(y[a][c2] + bias, lo, hi);
               if (p.res) v += yl_ld4(p.res + o);                     // residual after the activation (yl_epi_generic's order)
               *reinterpret_cast<f32x4*>(p.out + o) = v;
             }

@@ -374,8 +374,8 @@ static hipError_t dpq_go(const YlConvP& p, hipStream_t st, bool attr_only) {
 // p: the depthwise -> expand layer's parameters with w3p / b3 / C3 / act3, `res` and `out` of the project layer
 hipError_t yl_launch_conv_dpq(const YlConvP& p, hipStream_t st) {
   const int c3 = p.w3p ? p.C3 : 0;                                   // no project conv: the wide-expand-only form
-  if (p.k != 1 || p.dw_k != 3 || p.dw_stride != 1 || p.C1 > 0 || p.up || p.act == YL_ACT_SILU ||
-      p.dw_act == YL_ACT_SILU || (p.w3p && p.act3 == YL_ACT_SILU) || (!p.w3p && p.res) || p.dec_boxes ||
+  if (p.k != 1 || p.dw_k != 3 || p.dw_stride != 1 || p.C1 > 0 || p.up || YL_SMOOTH(p.act) ||
+      YL_SMOOTH(p.dw_act) || (p.w3p && YL_SMOOTH(p.act3)) || (!p.w3p && p.res) || p.dec_boxes ||
       p.H != p.OH || p.W != p.OW || !yl_dpq_supported(p.Cin, p.N, c3, p.OH, p.OW))
     return hipErrorNotSupported;
   const int kb = p.Cin / 16, nc1 = p.N / 96, nt3 = (c3 + 15) / 16;
@@ -537,7 +537,7 @@ bool yl_s2c_supported(int cin, int cout, int c3, int oh, int ow) {
 // dense 3x3 stride-2 conv (16 -> 48) + chained 1x1 (-> 32).  hipErrorNotSupported: other shapes (yl_conv_mfma_kernel)
 hipError_t yl_launch_conv_s2c(const YlConvP& p, hipStream_t st) {
   if ((p.dev & YL_DEV_S2C_OFF) || !p.w3p || p.k != 3 || p.stride != 2 || p.dw_k || p.C1 > 0 || p.res || p.up || p.in_shift || p.dec_boxes ||
-      p.act == YL_ACT_SILU || p.act3 == YL_ACT_SILU || !yl_s2c_supported(p.Cin, p.N, p.C3, p.OH, p.OW) ||
+      YL_SMOOTH(p.act) || YL_SMOOTH(p.act3) || !yl_s2c_supported(p.Cin, p.N, p.C3, p.OH, p.OW) ||
       p.OH != (p.H + 2 * p.pad_t - 3) / 2 + 1 || p.OW != (p.W + 2 * p.pad_l - 3) / 2 + 1)
     return hipErrorNotSupported;
   const long t = (long)p.B * (p.OH >> 1) * (p.OW >> 3);
@@ -597,7 +597,7 @@ hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st) {
   if (n < 1 || n > 4) return hipErrorNotSupported;
   const YlConvP& q = ps[0];
   if (q.k != 1 || q.dw_k != 3 || q.dw_stride != 1 || q.C1 > 0 || q.res || q.up || !q.w3p || !q.dec_boxes || q.dec_raw ||
-      q.act == YL_ACT_SILU || q.dw_act == YL_ACT_SILU)
+      YL_SMOOTH(q.act) || YL_SMOOTH(q.dw_act))
     return hipErrorNotSupported;
   for (int k = 0; k < n; ++k)
     if (!yl_dpp_supported(ps[k].Cin, ps[k].N, ps[k].C3, ps[k].OH, ps[k].OW) || ps[k].Cin != q.Cin || ps[k].N != q.N ||

@@ -14,7 +14,7 @@ struct YlPix {
 
 // ReLU-family activations as a clamp with wave-uniform bounds; SiLU behind a uniform branch
 __device__ __forceinline__ f32x4 yl_actc(f32x4 v, int act, float lo, float hi) {
-  if (act == YL_ACT_SILU) return yl_act4(v, YL_ACT_SILU);
+  if (YL_SMOOTH(act)) return yl_act4(v, act);
   return yl_clamp4(v, lo, hi);
 }
 
@@ -65,7 +65,7 @@ __device__ __forceinline__ void yl_epi_generic(const YlConvP& p, f32x4 (&acc)[MT
       const int n = (nt0 + nt) * 16 + 4 * kq;
       if (n >= p.N) continue;
       f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
-      v = yl_act4(v, p.act);
+      v = yl_post4(v, p.act, p.lab_s, p.lab_b);
       if (p.res) v += yl_ld4(p.res + obase + n);
       if (p.up) v += yl_ld4(p.up + up_off + n);
       *reinterpret_cast<f32x4*>(p.out + obase + n) = v;
@@ -115,14 +115,35 @@ __device__ __forceinline__ void yl_epi_decode(const YlConvP& p, f32x4 (&acc)[MT]
       const float band = lmax - 1e-3f * (1.0f + fabsf(lmax));
       const bool wide = best < 1.2e-38f;
       int first = 0x7fffffff;                               // smallest class whose sigmoid equals `best`
+      // Fast path (round 5): a logit EQUAL to the maximum has the maximum's sigmoid by construction, so the sigmoid
+      // test is only needed for logits strictly below the maximum that pass the band test.  One cheap scan finds the
+      // first class equal to the maximum and whether any lane of the wave holds such a near-tie; only then (a
+      // wave-uniform branch, rare: another class within 1e-3 relative of the maximum, or saturated logits > 10) the
+      // full scan with one sigmoid per candidate runs.  Same predicate, same result; ~24 predicated sigmoids
+      // (exp + IEEE division each) per tile leave the common path.
+      bool near_tie = false;
 #pragma unroll
       for (int nt = NT - 1; nt >= 0; --nt)
 #pragma unroll
         for (int r = 3; r >= 0; --r) {
           const int ch = (nt0 + nt) * 16 + 4 * kq + r;
           const float l = v[nt][r];
-          if (ch >= 5 && ch < 5 + C && (wide || l >= band || l > 10.0f) && yl_sigmoid(l) == best) first = ch - 5;
+          if (ch >= 5 && ch < 5 + C) {
+            if (l == lmax) first = ch - 5;
+            else if (wide || l >= band || l > 10.0f) near_tie = true;
+          }
         }
+      if (__any(near_tie)) {
+        first = 0x7fffffff;
+#pragma unroll
+        for (int nt = NT - 1; nt >= 0; --nt)
+#pragma unroll
+          for (int r = 3; r >= 0; --r) {
+            const int ch = (nt0 + nt) * 16 + 4 * kq + r;
+            const float l = v[nt][r];
+            if (ch >= 5 && ch < 5 + C && (wide || l >= band || l > 10.0f) && yl_sigmoid(l) == best) first = ch - 5;
+          }
+      }
       first = min(first, __shfl_xor(first, 16, 64));
       first = min(first, __shfl_xor(first, 32, 64));
       ci = first;

@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include "../../include/yololite_hip.h"
 
+// activations that are not a clamp (SiLU, GELU, ReLU + learnable affine): the kernels' fast clamp epilogues refuse them
+// and the generic epilogue / yl_post1 / yl_post4 (yl_dev.h) applies them
+#define YL_SMOOTH(a) ((a) >= YL_ACT_SILU)
+
 #define YL_NUM_CU 256          // MI355X: 8 XCDs x 32 CUs
 #define YL_LDS_KEYS_MAX 16384  // 64-bit sort keys that fit the 160 KiB LDS of one CU (128 KiB)
 
@@ -118,6 +122,8 @@ struct YlConvP {
   // output row pitch in floats when it is not N (0 = N): the mask-coefficient part of a split head-output conv stores
   // its 32 columns into rows of 5+C+NM floats (yl_epi_fast only; scalar stores: the rows are not 16-byte aligned)
   int ldo;
+  // YL_ACT_RELU_LAB: scalar affine after the ReLU (timm LearnableAffineBlock of hgnetv2): lab_s * relu(v) + lab_b
+  float lab_s, lab_b;
 };
 
 // YlConvP::dev -- developer kernel-selection switches (A/B runs, bitwise kernel-equivalence tests); per context, never
@@ -146,6 +152,22 @@ struct YlSeP {
 hipError_t yl_launch_se(const YlSeP& p, bool pooled, hipStream_t st);   // pooled: p.partial already holds P partials per image
 int yl_se_parts(int HW, int C);            // partial sums per image the pool pass produces for this shape
 int yl_dw_pool_wpi(int k, int stride, int cin, int n, int oh, int ow);   // > 0: yl_launch_dw can pool (waves per image), else 0
+
+// element-wise / reduction ops of the hgnetv2 / convnextv2 backbones (yl_ops.hip; ABI v5 YL_OP_POOL .. YL_OP_NHWC4)
+struct YlOpP {
+  const float* x;        // input NHWC [B,H,W,C]  (YL_OP_NHWC4: the NCHW network input)
+  float* out;
+  const float* w;        // LN weight / GRN weight [C]
+  const float* b;        // LN bias [C]
+  float* partial;        // GRN: [B][P][C] scratch
+  int B, H, W, C, OH, OW;
+  int k, stride, pad_t, pad_l;   // pool
+  int ldo, ch_off;       // copy: channels of the destination rows, first channel written
+  int P;                 // GRN: partial sums per image
+  float eps;
+};
+hipError_t yl_launch_op(int op, const YlOpP& p, hipStream_t st);
+int yl_grn_parts(int HW);
 
 // Up to 4 independent convolutions of identical kernel configuration in ONE launch (the FPN smooth blocks,
 // head trunks and head outputs of all pyramid levels): every block serves one problem, the grid is split in

@@ -76,6 +76,7 @@ class HipContext:
                 y.c2, y.act2, y.c3, y.act3 = l.c2, l.act2, l.c3, l.act3
                 y.w2, y.b2, y.w3, y.b3 = fp(l.w2), fp(l.b2), fp(l.w3), fp(l.b3)
                 y.scale_slot, y.reserved0 = l.scale_slot, 0
+                y.lab_scale, y.lab_bias, y.eps, y.out_ch_off = l.lab_scale, l.lab_bias, l.eps, l.out_ch_off
             d.num_layers = len(program.layers)
             d.layers = arr
             keep.append(arr)

@@ -123,6 +123,10 @@ class Layer:
     b2: Optional[np.ndarray] = None
     w3: Optional[np.ndarray] = None
     b3: Optional[np.ndarray] = None
+    lab_scale: float = 1.0      # act == relu_lab: the two scalars of timm's LearnableAffineBlock (hgnetv2)
+    lab_bias: float = 0.0
+    eps: float = 0.0            # OP_LN / OP_GRN
+    out_ch_off: int = 0         # OP_COPY: first channel of out_slot written
     name: str = ""
     macs: int = 0               # per image
     bytes_in: int = 0           # algorithmic HBM bytes per image (read)
@@ -172,6 +176,12 @@ class SynthStateDict(dict):
             else:
                 base = {"obj": -math.log(99.0), "cls": (-math.log(self.C) if self.C > 1 else 0.0), "box": 0.0, "mc": 0.0}
                 v = base[key.split(".")[-2]] + r.randn(*shape) * self.head_noise
+        elif key.endswith("grn.weight"):
+            v = r.randn(*shape) * 0.2                   # timm initialises GRN at zero; trained values are small
+        elif key.endswith("lab.scale"):
+            v = 1.0 + r.randn(*shape) * 0.1
+        elif len(shape) == 2:                           # nn.Linear weight [out, in] (convnext mlp)
+            v = r.randn(*shape) * math.sqrt(1.0 / shape[1])
         elif key.endswith("se.conv_expand.bias"):
             v = 1.5 + r.randn(*shape) * 0.5             # gates around 0.8: activations keep their scale through 20 SE blocks
         elif key.endswith("running_var"):
@@ -282,6 +292,12 @@ MODEL_ZOO = {
                           width_multiple=1.0, fpn_channels=256, head_depth=2),
     "yololite_m_v2": dict(arch="YOLOLiteMS", backbone="tf_efficientnetv2_b2", depth_multiple=1.0,
                           width_multiple=1.0, fpn_channels=328, head_depth=2),
+    # round 5: the two remaining yamls -- configs/models/edge_xl.yaml (hgnetv2_b0), configs/v2_models/yololite_l.yaml
+    # (convnextv2_tiny)
+    "edge_xl": dict(arch="YOLOLiteMS_CPU", backbone="hgnetv2_b0", depth_multiple=1.0, width_multiple=1.0,
+                    fpn_channels=256, head_depth=3),
+    "yololite_l_v2": dict(arch="YOLOLiteMS", backbone="convnextv2_tiny", depth_multiple=1.0, width_multiple=1.0,
+                          fpn_channels=512, head_depth=3),
 }
 
 
@@ -290,8 +306,9 @@ def zoo_meta(name: str, num_classes: int = 80, img_size: int = 640, **kw) -> dic
     return make_meta(num_classes=num_classes, img_size=img_size, **MODEL_ZOO[name], **kw)
 
 
-_ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3}
+_ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3, "gelu": 4, "relu_lab": 5}
 _OP_STEM, _OP_CONV, _OP_DW, _OP_STEMBLOCK, _OP_SE = 0, 1, 2, 3, 4
+_OP_POOL, _OP_COPY, _OP_LN, _OP_GRN, _OP_NHWC4 = 5, 6, 7, 8, 9
 DW_PROLOGUE_LDS_MAX = 32 * 1024      # bytes; mirrors YL_DW_LDS_MAX in csrc/yl_api.hip
 
 
@@ -525,8 +542,200 @@ class _Builder:
         return o
 
 
+# timm hgnetv2 (models/hgnet.py) and convnextv2 (models/convnext.py) as DATA, like BACKBONES (recollection; see
+# oracle/backbones.py for the restated modules and the published-parameter checksums):
+#   name -> (stem (mid, out), stages [(in, mid, out, blocks, downsample, light, kernel, layer_num)], use_lab)
+HGNET: Dict[str, tuple] = {
+    "hgnetv2_b0": ((16, 16), [(16, 16, 64, 1, False, False, 3, 3), (64, 32, 256, 1, True, False, 3, 3),
+                              (256, 64, 512, 2, True, True, 5, 3), (512, 128, 1024, 1, True, True, 5, 3)], True),
+    "oracle_tiny_hg": ((8, 8), [(8, 8, 16, 1, False, False, 3, 2), (16, 8, 32, 1, True, False, 3, 3),
+                                (32, 8, 48, 2, True, True, 5, 2), (48, 16, 64, 1, True, True, 5, 3)], True),
+}
+#   name -> (depths, dims, depthwise kernel)
+CONVNEXT: Dict[str, tuple] = {
+    "convnextv2_tiny": ((3, 3, 9, 3), (96, 192, 384, 768), 7),
+    "convnextv2_nano": ((2, 2, 8, 2), (80, 160, 320, 640), 7),
+    "convnextv2_pico": ((2, 2, 6, 2), (64, 128, 256, 512), 7),
+    "convnextv2_femto": ((2, 2, 6, 2), (48, 96, 192, 384), 7),
+    "convnextv2_atto": ((2, 2, 6, 2), (40, 80, 160, 320), 7),
+    "oracle_tiny_cnx": ((1, 2, 2, 1), (8, 16, 24, 32), 7),
+}
+
+
+class _Ops:
+    """Emitters for the ABI-v5 op kinds on top of a _Builder (plain layers: nothing is fused across them)."""
+
+    def __init__(self, b: "_Builder"):
+        self.b = b
+
+    def raw_conv(self, x, w, bias, k, s, pad, oh, ow, act, name, groups=1, lab=None, res=-1, scale=-1):
+        b = self.b
+        h, wd, cin = b.dims(x)
+        cout = w.shape[0]
+        o = b.slot(oh, ow, cout)
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+        if groups == 1:
+            L = Layer(_OP_CONV, x, o, cin, cout, k, s, pad, pad, _ACT[act], f32(w), f32(bias), res_slot=res, scale_slot=scale,
+                      name=name, macs=oh * ow * cout * cin * k * k, bytes_in=4 * h * wd * cin, bytes_out=4 * oh * ow * cout)
+        else:
+            assert groups == cin == cout
+            L = Layer(_OP_DW, x, o, cin, cout, k, s, pad, pad, _ACT[act], f32(w), f32(bias), res_slot=res, name=name,
+                      macs=oh * ow * cout * k * k, bytes_in=4 * h * wd * cin, bytes_out=4 * oh * ow * cout)
+        if lab is not None:
+            L.lab_scale, L.lab_bias = float(lab[0]), float(lab[1])
+        if res >= 0:
+            L.bytes_in += 4 * oh * ow * cout
+        b.p.layers.append(L)
+        return o
+
+    def plain(self, op, x, out_hwc, name, **kw):
+        b = self.b
+        h, wd, c = b.dims(x) if x >= 0 else (b.p.img_size, b.p.img_size, 3)
+        o = kw.pop("out", None)
+        if o is None:
+            o = b.slot(*out_hwc)
+        oh, ow, oc = b.dims(o)
+        L = Layer(op, x, o, c if x >= 0 else 3, kw.pop("cout", c), kw.pop("k", 1), kw.pop("s", 1), 0, 0, 0, kw.pop("w", None),
+                  kw.pop("bias", None), name=name, macs=0, bytes_in=4 * h * wd * c, bytes_out=4 * oh * ow * (c if op == _OP_COPY else oc))
+        for kk, v in kw.items():
+            setattr(L, kk, v)
+        b.p.layers.append(L)
+        return o
+
+    def cat(self, xs, name):
+        """torch.cat(xs, dim=1): one channel-slice copy per input into a fresh slot"""
+        b = self.b
+        h, w, _ = b.dims(xs[0])
+        total = sum(b.dims(x)[2] for x in xs)
+        o = b.slot(h, w, total)
+        off = 0
+        for i, x in enumerate(xs):
+            self.plain(_OP_COPY, x, None, f"{name}[{i}]", out=o, out_ch_off=off)
+            off += b.dims(x)[2]
+        return o
+
+
+def _hgnet_backbone(b: "_Builder", name: str, prefix: str):
+    """timm HighPerfGpuNet features (hgnetv2): see oracle/backbones.py HgFeatureBackbone for the restated modules."""
+    (smid, sout), stages, use_lab = HGNET[name]
+    ops = _Ops(b)
+    S = b.p.img_size
+
+    def cba(x, key, cout, k, s=1, dw=False, use_act=True, same_size=False, res=-1):
+        """ConvBNAct: conv (no bias, pad (k-1)//2) + BN(eps 1e-5) + ReLU + LAB.  same_size: the input was zero-extended by one
+        row / column at the bottom / right (StemV2's F.pad): a k = 2 conv then keeps the size"""
+        h, wd, cin = b.dims(x)
+        w, bias = b.fold(key + ".conv", key + ".bn", 1e-5, False, (cout, 1 if dw else cin, k, k))
+        pad = (k - 1) // 2
+        oh, ow = ((h, wd) if same_size else ((h + 2 * pad - k) // s + 1, (wd + 2 * pad - k) // s + 1))
+        lab, act = None, ("relu" if use_act else "none")
+        if use_act and use_lab:
+            lab = (float(b.get(key + ".lab.scale", (1,))[0]), float(b.get(key + ".lab.bias", (1,))[0]))
+            act = "relu_lab"
+        return ops.raw_conv(x, w, bias, k, s, pad, oh, ow, act, key + ".conv", groups=(cin if dw else 1), lab=lab, res=res)
+
+    # ---- StemV2
+    sh = (S + 2 - 3) // 2 + 1
+    key = prefix + "stem.stem1"
+    w1, b1 = b.fold(key + ".conv", key + ".bn", 1e-5, False, (smid, 3, 3, 3))
+    lab, act = None, "relu"
+    if use_lab:
+        lab = (float(b.get(key + ".lab.scale", (1,))[0]), float(b.get(key + ".lab.bias", (1,))[0]))
+        act = "relu_lab"
+    if smid in (16, 32):                 # the MFMA stem kernel's shapes (reads NCHW directly)
+        x = b.slot(sh, sh, smid)
+        L = Layer(_OP_STEM, -1, x, 3, smid, 3, 2, 1, 1, _ACT[act], w1, b1, name=key + ".conv", macs=sh * sh * smid * 27,
+                  bytes_in=4 * 3 * S * S, bytes_out=4 * sh * sh * smid)
+        if lab:
+            L.lab_scale, L.lab_bias = lab
+        b.p.layers.append(L)
+    else:                                # NHWC copy of the input with a zero fourth channel, then the generic conv
+        x0 = ops.plain(_OP_NHWC4, -1, (S, S, 4), prefix + "input.nhwc4", cout=4)
+        w4 = np.zeros((smid, 4, 3, 3), np.float32)
+        w4[:, :3] = w1
+        x = ops.raw_conv(x0, w4, b1, 3, 2, 1, sh, sh, act, key + ".conv", lab=lab)
+    x2 = cba(x, prefix + "stem.stem2a", smid // 2, 2, same_size=True)
+    x2 = cba(x2, prefix + "stem.stem2b", smid, 2, same_size=True)
+    x1 = ops.plain(_OP_POOL, x, (sh, sh, smid), prefix + "stem.pool", k=2, s=1)
+    x = ops.cat([x1, x2], prefix + "stem.cat")
+    x = cba(x, prefix + "stem.stem3", smid, 3, 2)
+    x = cba(x, prefix + "stem.stem4", sout, 1)
+    red, feats = 4, []
+    for si, (cin, mid, cout, nb, ds, light, k, ln) in enumerate(stages):
+        sp = f"{prefix}stages_{si}."
+        if ds:
+            x = cba(x, sp + "downsample", cin, 3, 2, dw=True, use_act=False)
+            red *= 2
+        for bi in range(nb):
+            bp = f"{sp}blocks.{bi}."
+            ident, parts, y = x, [x], x
+            for li in range(ln):
+                if light:
+                    y = cba(y, f"{bp}layers.{li}.conv1", mid, 1, use_act=False)
+                    y = cba(y, f"{bp}layers.{li}.conv2", mid, k, dw=True)
+                else:
+                    y = cba(y, f"{bp}layers.{li}", mid, 3)
+                parts.append(y)
+            c = ops.cat(parts, bp + "cat")
+            a = cba(c, bp + "aggregation.0", cout // 2, 1)
+            x = cba(a, bp + "aggregation.1", cout, 1, res=(ident if bi > 0 else -1))
+        feats.append((x, cout, red))
+    return feats
+
+
+def _convnext_backbone(b: "_Builder", name: str, prefix: str):
+    """timm ConvNeXt features with GRN (convnextv2): see oracle/backbones.py ConvNeXtFeatureBackbone."""
+    depths, dims, dk = CONVNEXT[name]
+    ops = _Ops(b)
+    S = b.p.img_size
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+
+    def ln(x, key):
+        h, w, c = b.dims(x)
+        return ops.plain(_OP_LN, x, (h, w, c), key, w=f32(b.get(key + ".weight", (c,))), bias=f32(b.get(key + ".bias", (c,))),
+                         eps=1e-6)
+
+    x0 = ops.plain(_OP_NHWC4, -1, (S, S, 4), prefix + "input.nhwc4", cout=4)
+    w = b.get(prefix + "stem_0.weight", (dims[0], 3, 4, 4))
+    w4 = np.zeros((dims[0], 4, 4, 4), np.float32)
+    w4[:, :3] = w
+    x = ops.raw_conv(x0, w4, b.get(prefix + "stem_0.bias", (dims[0],)), 4, 4, 0, S // 4, S // 4, "none", prefix + "stem_0")
+    x = ln(x, prefix + "stem_1")
+    red, prev, feats = 4, dims[0], []
+    for si, (depth, c) in enumerate(zip(depths, dims)):
+        sp = f"{prefix}stages_{si}."
+        h, wd, _ = b.dims(x)
+        if si > 0:
+            y = ln(x, sp + "downsample.0")
+            x = ops.raw_conv(y, b.get(sp + "downsample.1.weight", (c, prev, 2, 2)), b.get(sp + "downsample.1.bias", (c,)),
+                             2, 2, 0, h // 2, wd // 2, "none", sp + "downsample.1")
+            red *= 2
+            h, wd = h // 2, wd // 2
+        for bi in range(depth):
+            bp = f"{sp}blocks.{bi}."
+            y = ops.raw_conv(x, b.get(bp + "conv_dw.weight", (c, 1, dk, dk)), b.get(bp + "conv_dw.bias", (c,)), dk, 1, dk // 2,
+                             h, wd, "none", bp + "conv_dw", groups=c)
+            y = ln(y, bp + "norm")
+            w1 = b.get(bp + "mlp.fc1.weight", (4 * c, c)).reshape(4 * c, c, 1, 1)
+            hid = ops.raw_conv(y, w1, b.get(bp + "mlp.fc1.bias", (4 * c,)), 1, 1, 0, h, wd, "gelu", bp + "mlp.fc1")
+            gw, gb = b.get(bp + "mlp.grn.weight", (4 * c,)), b.get(bp + "mlp.grn.bias", (4 * c,))
+            g = ops.plain(_OP_GRN, hid, (1, 1, 4 * c), bp + "mlp.grn", w=f32(gw), eps=1e-6)
+            w2 = b.get(bp + "mlp.fc2.weight", (c, 4 * c))
+            # GRN: y = x + (beta + gamma * (x * n)) = x * (1 + gamma * n) + beta; the gate multiplies fc2's input and beta
+            # goes through fc2 once, on the host (float64): b2' = b2 + W2 . beta
+            b2 = b.get(bp + "mlp.fc2.bias", (c,)) + w2 @ gb
+            x = ops.raw_conv(hid, w2.reshape(c, 4 * c, 1, 1), b2, 1, 1, 0, h, wd, "none", bp + "mlp.fc2", res=x, scale=g)
+        prev = c
+        feats.append((x, c, red))
+    return feats
+
+
 def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[int, int, int]]:
     """Emit the feature extractor; returns [(slot, channels, reduction)] for every feature tap."""
+    if name in HGNET:
+        return _hgnet_backbone(b, name, prefix)
+    if name in CONVNEXT:
+        return _convnext_backbone(b, name, prefix)
     if name not in BACKBONES:
         raise ValueError(f"backbone '{name}' has no layer table (known: {sorted(BACKBONES)})")
     spec = BACKBONES[name]
