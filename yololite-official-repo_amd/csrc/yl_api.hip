@@ -307,7 +307,7 @@ size_t layer_group_end(const yl_ctx* c, size_t i, size_t lend) {
     const yl_layer& a = c->layers[x].d; const yl_layer& e = c->layers[y].d;
     return a.op == YL_OP_CONV && e.op == YL_OP_CONV && a.cin == e.cin && a.cout == e.cout && a.k == e.k &&
            a.stride == e.stride && a.pad_t == e.pad_t && a.pad_l == e.pad_l && a.act == e.act &&
-           a.in_shift == e.in_shift && a.dw_k == e.dw_k && a.dw_stride == e.dw_stride && a.dw_pad_t == e.dw_pad_t &&
+           !YL_ACT_POSTPASS(a.act) && a.in_shift == e.in_shift && a.dw_k == e.dw_k && a.dw_stride == e.dw_stride && a.dw_pad_t == e.dw_pad_t &&
            a.dw_pad_l == e.dw_pad_l && a.dw_act == e.dw_act && a.c2 == 0 && e.c2 == 0 && a.scale_slot < 0 && e.scale_slot < 0 && a.res_slot < 0 &&
            e.res_slot < 0 && a.up_slot < 0 && e.up_slot < 0 && (a.head_level >= 0) == (e.head_level >= 0) &&
            (a.cout + 15) / 16 <= 8;
@@ -507,7 +507,6 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
   p.OH = L.out_h; p.OW = L.out_w; p.N = d.cout;
   p.k = d.k; p.stride = d.stride; p.pad_t = d.pad_t; p.pad_l = d.pad_l; p.act = d.act;
   p.in_shift = d.in_shift;
-  p.lab_s = d.lab_scale; p.lab_b = d.lab_bias;
   p.dw_k = d.dw_k; p.dw_stride = d.dw_stride; p.dw_pad_t = d.dw_pad_t; p.dw_pad_l = d.dw_pad_l; p.dw_act = d.dw_act;
   p.MH = L.out_h; p.MW = L.out_w;
   p.KB = cdiv(d.cin, 16);
@@ -531,6 +530,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
     p.N = d.c3 > 0 ? d.c3 : d.c2;
   }
   if (d.res_slot >= 0) p.res = slot_ptr(d.res_slot);
+  if (YL_ACT_POSTPASS(d.act)) { p.act = YL_ACT_NONE; p.res = nullptr; }     // applied by the activation pass (run_layers)
   if (d.scale_slot >= 0) p.scale = slot_ptr(d.scale_slot);
   p.dev = (unsigned)c->opt_dev | (c->opt_split_k ? 0u : YL_DEV_DWT_NOSPLIT);
   if (d.up_slot >= 0) {
@@ -837,6 +837,17 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         e = c->opt_bf16 == 1 ? yl_launch_stemblock_bf16(p, ls) : c->opt_bf16 == 2 ? yl_launch_stemblock_f16(p, ls) : yl_launch_stemblock(p, ls);
         break;
       default: e = yl_launch_dw(p, ls); break;
+    }
+    if (e == hipSuccess && YL_ACT_POSTPASS(d.act)) {
+      // GELU / ReLU + learnable affine (+ the residual behind it): element-wise pass over the layer's output, in place
+      const DevLayer& L = c->layers[i];
+      YlOpP q;
+      memset(&q, 0, sizeof(q));
+      q.x = p.out; q.out = p.out;
+      q.B = B; q.OH = L.out_h; q.OW = L.out_w; q.C = d.cout;
+      q.act = d.act; q.lab_s = d.lab_scale; q.lab_b = d.lab_bias;
+      if (d.res_slot >= 0) q.res = slot_addr(c, d.res_slot, b0);
+      e = yl_launch_op(YL_OP_ACTPASS, q, ls);
     }
     if (e != hipSuccess) {
       char b[256];
@@ -1292,7 +1303,9 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     if (l.act < YL_ACT_NONE || l.act > YL_ACT_RELU_LAB || l.dw_act < 0 || l.dw_act > YL_ACT_SILU || l.act2 < 0 || l.act2 > YL_ACT_SILU ||
         l.act3 < 0 || l.act3 > YL_ACT_SILU)
       return bad("unknown activation (GELU / ReLU+affine are valid as `act` only)");
-    if (l.act == YL_ACT_RELU_LAB && l.op != YL_OP_STEM && l.op != YL_OP_CONV && l.op != YL_OP_DW) return bad("ReLU + learnable affine: STEM / CONV / DW only");
+    if (YL_ACT_POSTPASS(l.act) && ((l.op != YL_OP_STEM && l.op != YL_OP_CONV && l.op != YL_OP_DW) || l.head_level >= 0 || l.up_slot >= 0 ||
+                                   l.c2 > 0 || l.c3 > 0 || (l.cout & 3)))
+      return bad("GELU / ReLU + learnable affine: plain STEM / CONV / DW layers with cout % 4 == 0 only");
     if (l.out_ch_off != 0 && l.op != YL_OP_COPY) return bad("out_ch_off is a YL_OP_COPY field");
     if (l.op >= YL_OP_POOL) {
       // element-wise / reduction ops (ABI v5): in_slot -> out_slot, no conv fields

@@ -184,7 +184,7 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float e = fminf(fmaxf(v[r], lo), hi);
-          if (YL_SMOOTH(p.act)) e = yl_post1(v[r], p.act, p.lab_s, p.lab_b);
+          if (YL_SMOOTH(p.act)) e = yl_act1(v[r], p.act);
           if (n + r < p.N) stg[(mt * 16 + pl) * p.N + n + r] = e;
         }
       }
@@ -213,7 +213,7 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float e = fminf(fmaxf(v[r], lo), hi);
-        if (YL_SMOOTH(p.act)) e = yl_post1(v[r], p.act, p.lab_s, p.lab_b);
+        if (YL_SMOOTH(p.act)) e = yl_act1(v[r], p.act);
         if (n + r < p.N) orow[(nt0 + nt) * 16 + r] = e;
       }
     }
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void yl_stem_mfma_kernel(YlConvP p) {
       for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 16 + 4 * kq;
         f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
-        if (YL_SMOOTH(p.act)) v = yl_post4(v, p.act, p.lab_s, p.lab_b);
+        if (YL_SMOOTH(p.act)) v = yl_act4(v, p.act);
         v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
         v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
         *reinterpret_cast<f32x4*>(orow + n) = v;
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void yl_dw_kernel(YlConvP p) {
       s.z = fmaf(v.z, w.z, s.z); s.w = fmaf(v.w, w.w, s.w);
     }
   }
-  s = yl_post4(s, p.act, p.lab_s, p.lab_b);
+  s = yl_act4(s, p.act);
   const size_t o = lin * p.N + c;
   if (p.res) s += yl_ld4(p.res + o);
   *reinterpret_cast<f32x4*>(p.out + o) = s;
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
       for (int j = 0; j < TX; ++j) {
         const int ox = ox0 + j;
         if (ox >= OW) continue;
-        f32x4 s4 = yl_post4(acc[t][j], p.act, p.lab_s, p.lab_b);
+        f32x4 s4 = yl_act4(acc[t][j], p.act);
         const size_t o = (((size_t)b * OH + oy) * OW + ox) * p.N + c;
         if (p.res) s4 += yl_ld4(p.res + o);
         if (POOL) psum += s4;

@@ -1985,7 +1985,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
             const int oy = 2 * ty + a, ox = 2 * tx + c2;
             if (oy < OH && ox < OW) {
               const size_t o = (((size_t)b * OH + oy) * OW + ox) * N + n;
-              f32x4 v = YL_SMOOTH(p.act) ? yl_post4(y[a][c2] + bias, p.act, p.lab_s, p.lab_b) : yl_clamp4(y[a][c2] + bias, lo, hi);
+              f32x4 v = yl_actc(y[a][c2] + bias, p.act, lo, hi);
               if (p.res) v += yl_ld4(p.res + o);                     // residual after the activation (yl_epi_generic's order)
               *reinterpret_cast<f32x4*>(p.out + o) = v;
             }

@@ -11,28 +11,12 @@ __device__ __forceinline__ float yl_act1(float v, int act) {
     case YL_ACT_RELU: return fmaxf(v, 0.0f);
     case YL_ACT_RELU6: return fminf(fmaxf(v, 0.0f), 6.0f);
     case YL_ACT_SILU: return v / (1.0f + expf(-v));
-    case YL_ACT_GELU: return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f));   // torch GELU (erf form), its operation order
-    case YL_ACT_RELU_LAB: return fmaxf(v, 0.0f);         // the scalar affine part follows in yl_post1 / yl_post4
     default: return v;
   }
 }
 __device__ __forceinline__ f32x4 yl_act4(f32x4 v, int act) {
   f32x4 r;
   r.x = yl_act1(v.x, act); r.y = yl_act1(v.y, act); r.z = yl_act1(v.z, act); r.w = yl_act1(v.w, act);
-  return r;
-}
-// activation + (YL_ACT_RELU_LAB) timm LearnableAffineBlock: lab_s * relu(v) + lab_b, one multiply and one add per element
-// as in `self.scale * x + self.bias` (no contraction: two roundings)
-__device__ __forceinline__ float yl_post1(float v, int act, float lab_s, float lab_b) {
-#pragma clang fp contract(off)
-  v = yl_act1(v, act);
-  if (act == YL_ACT_RELU_LAB) v = lab_s * v + lab_b;
-  return v;
-}
-__device__ __forceinline__ f32x4 yl_post4(f32x4 v, int act, float lab_s, float lab_b) {
-  f32x4 r;
-  r.x = yl_post1(v.x, act, lab_s, lab_b); r.y = yl_post1(v.y, act, lab_s, lab_b);
-  r.z = yl_post1(v.z, act, lab_s, lab_b); r.w = yl_post1(v.w, act, lab_s, lab_b);
   return r;
 }
 __device__ __forceinline__ f32x4 yl_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }

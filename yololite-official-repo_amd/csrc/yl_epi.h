@@ -65,7 +65,7 @@ __device__ __forceinline__ void yl_epi_generic(const YlConvP& p, f32x4 (&acc)[MT
       const int n = (nt0 + nt) * 16 + 4 * kq;
       if (n >= p.N) continue;
       f32x4 v = acc[mt][nt] + yl_ld4(p.bias + n);
-      v = yl_post4(v, p.act, p.lab_s, p.lab_b);
+      v = yl_act4(v, p.act);
       if (p.res) v += yl_ld4(p.res + obase + n);
       if (p.up) v += yl_ld4(p.up + up_off + n);
       *reinterpret_cast<f32x4*>(p.out + obase + n) = v;

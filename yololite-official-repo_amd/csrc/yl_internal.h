@@ -4,9 +4,12 @@
 #include <stdint.h>
 #include "../../include/yololite_hip.h"
 
-// activations that are not a clamp (SiLU, GELU, ReLU + learnable affine): the kernels' fast clamp epilogues refuse them
-// and the generic epilogue / yl_post1 / yl_post4 (yl_dev.h) applies them
+// activations that are not a clamp: SiLU runs in the conv kernels' generic epilogue (the fast clamp epilogues refuse it);
+// GELU and ReLU + learnable affine (ABI v5: YL_ACT_POSTPASS) never reach a conv kernel -- the executor launches the layer with
+// no activation (and no residual) and applies them in an element-wise pass over the output (yl_ops.hip: yl_act_kernel), so the
+// hot kernels carry no code for them
 #define YL_SMOOTH(a) ((a) >= YL_ACT_SILU)
+#define YL_ACT_POSTPASS(a) ((a) >= YL_ACT_GELU)
 
 #define YL_NUM_CU 256          // MI355X: 8 XCDs x 32 CUs
 #define YL_LDS_KEYS_MAX 16384  // 64-bit sort keys that fit the 160 KiB LDS of one CU (128 KiB)
@@ -122,8 +125,6 @@ struct YlConvP {
   // output row pitch in floats when it is not N (0 = N): the mask-coefficient part of a split head-output conv stores
   // its 32 columns into rows of 5+C+NM floats (yl_epi_fast only; scalar stores: the rows are not 16-byte aligned)
   int ldo;
-  // YL_ACT_RELU_LAB: scalar affine after the ReLU (timm LearnableAffineBlock of hgnetv2): lab_s * relu(v) + lab_b
-  float lab_s, lab_b;
 };
 
 // YlConvP::dev -- developer kernel-selection switches (A/B runs, bitwise kernel-equivalence tests); per context, never
@@ -165,7 +166,11 @@ struct YlOpP {
   int ldo, ch_off;       // copy: channels of the destination rows, first channel written
   int P;                 // GRN: partial sums per image
   float eps;
+  const float* res;      // activation pass: residual added after the activation, or nullptr
+  int act;               // activation pass: YL_ACT_GELU / YL_ACT_RELU_LAB
+  float lab_s, lab_b;    // YL_ACT_RELU_LAB: lab_s * relu(v) + lab_b (timm LearnableAffineBlock of hgnetv2)
 };
+#define YL_OP_ACTPASS 100   // internal op code of yl_launch_op: the activation pass above (not an ABI op)
 hipError_t yl_launch_op(int op, const YlOpP& p, hipStream_t st);
 int yl_grn_parts(int HW);
 

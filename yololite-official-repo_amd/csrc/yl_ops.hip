@@ -6,6 +6,24 @@
 #include "yl_internal.h"
 #include "yl_dev.h"
 
+// ---- activation pass: GELU (erf form, torch's operation order x * 0.5 * (1 + erf(x / sqrt 2))) or ReLU + timm's
+// LearnableAffineBlock (scale * relu(v) + bias, two roundings), then the residual -- in place over a conv's output -------
+__device__ __forceinline__ float yl_post1(float v, int act, float lab_s, float lab_b) {
+  if (act == YL_ACT_GELU) return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f));
+  v = fmaxf(v, 0.0f);
+  return lab_s * v + lab_b;
+}
+__global__ __launch_bounds__(256) void yl_act_kernel(YlOpP p) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const size_t total = (size_t)p.B * p.OH * p.OW * p.C;
+  if (i >= total) return;
+  f32x4 v = yl_ld4(p.x + i);
+  v.x = yl_post1(v.x, p.act, p.lab_s, p.lab_b); v.y = yl_post1(v.y, p.act, p.lab_s, p.lab_b);
+  v.z = yl_post1(v.z, p.act, p.lab_s, p.lab_b); v.w = yl_post1(v.w, p.act, p.lab_s, p.lab_b);
+  if (p.res) v += yl_ld4(p.res + i);
+  *reinterpret_cast<f32x4*>(p.out + i) = v;
+}
+
 // ---- max-pool over the zero-extended input (StemV2: F.pad(x, (0,1,0,1)) -> MaxPool2d(kernel 2, stride 1)) -------------
 __global__ __launch_bounds__(256) void yl_pool_kernel(YlOpP p) {
   const int cq = p.C >> 2;
@@ -152,6 +170,9 @@ hipError_t yl_launch_op(int op, const YlOpP& p, hipStream_t st) {
       hipLaunchKernelGGL(yl_grn_gate_kernel, dim3((unsigned)p.B), dim3(1024), 0, st, p);
       break;
     }
+    case YL_OP_ACTPASS:
+      hipLaunchKernelGGL(yl_act_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p);
+      break;
     case YL_OP_NHWC4:
       hipLaunchKernelGGL(yl_nhwc4_kernel, dim3((unsigned)(((size_t)p.B * p.H * p.W + 255) / 256)), dim3(256), 0, st, p);
       break;
