@@ -283,6 +283,12 @@ yl_status yl_get_option(const yl_ctx* ctx, const char* name, int32_t* value);
  * "compiler" (program.py) asks this instead of mirroring the kernels' shape tables.                                */
 int32_t yl_query_fused_block(int32_t c_in, int32_t c_mid, int32_t c_out, int32_t dw_k, int32_t dw_stride, int32_t out_h,
                              int32_t out_w);
+/* Host-side query (ABI v5): can a depthwise dw_k x dw_k (stride dw_stride) conv on c_in channels be the PROLOGUE of the 1x1
+ * conv c_in -> c_out that follows it (yl_layer.dw_k > 0; timm `conv_dw` -> `conv_pwl`, DWConvBlock model_v2.py:23-39), output
+ * out_h x out_w?  2: the streamed-tap kernel takes it (yl_conv_dws_kernel: >= 192 depthwise channels, 7..22 output n-tiles,
+ * 4x4-tileable output -- tf_efficientnet_lite stages 4-6), 1: the generic depthwise-prologue kernels do (taps + bias of all
+ * channels within 32 KiB of LDS), 0: no -- emit the depthwise conv as its own YL_OP_DW layer.                          */
+int32_t yl_query_dw_prologue(int32_t c_in, int32_t c_out, int32_t dw_k, int32_t dw_stride, int32_t out_h, int32_t out_w);
 
 /* ---- pre-processing ----------------------------------------------------------------------------
  * Replaces letterbox() + cv2.cvtColor + /255 + (x-mean)/std + transpose of tools/infer.py:121-131,446-453

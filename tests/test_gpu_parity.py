@@ -173,6 +173,24 @@ def test_convnext_and_hgnet_ops_are_deterministic_and_batch_invariant():
                 assert torch.equal(u[b:b + 1], v)
 
 
+@pytest.mark.parametrize("name,S", [("yololite_m", 256), ("yololite_m", 640), ("yololite_n", 320), ("yololite_xl", 256)])
+def test_streamed_tap_depthwise_kernel_is_bitwise_the_two_launches(name, S):
+    """yl_conv_dws_kernel (round 5: depthwise k x k -> 1x1 with the 1x1 AND the tap weights streamed through LDS, halo patch in
+    LDS) against the two launches it replaces (yl_dw_tile_kernel, then the plain 1x1): same fmaf chain per channel, same k
+    order and epilogues -> the raw levels are bitwise equal.  tf_efficientnet_lite0 / lite2 / lite4: 5x5 stride 1 and 2, 3x3,
+    8 / 13 / 22 n-tile accumulator sets, residual pre-add, channel tails (720 = 45 k-blocks, 1248 = 78)."""
+    meta = zoo_meta(name, 80, S)
+    sd = synth_state_dict(meta, seed=2)
+    x = _x(3, S, seed=9).to(DEV)
+    a = _hip_for(meta, sd, fuse_dws=True)
+    b = _hip_for(meta, sd, fuse_dws=False)
+    oa, ob = a(x), b(x)
+    na = sum(1 for l in a.program.layers if l.dw_k and (l.dw_k ** 2 + 1) * l.cin * 4 > 32 * 1024)
+    assert na >= 2 and len(b.program.layers) == len(a.program.layers) + na, (na, len(a.program.layers), len(b.program.layers))
+    for u, v in zip(oa, ob):
+        assert torch.equal(u, v)
+
+
 def test_squeeze_excite_gate_is_deterministic_and_batch_invariant():
     """YL_OP_SE: the spatial mean is a fixed-order two-pass sum (no float atomics): the gates, and with them the whole
     forward, are bitwise repeatable, independent of the batch an image is part of and of the chunk split."""

@@ -101,6 +101,7 @@ SYMBOLS = [
     ("yl_set_option", C.c_int32, [_vp, C.c_char_p, C.c_int32]),
     ("yl_get_option", C.c_int32, [_vp, C.c_char_p, _ip]),
     ("yl_query_fused_block", C.c_int32, [C.c_int32] * 7),
+    ("yl_query_dw_prologue", C.c_int32, [C.c_int32] * 6),
     ("yl_forward_decoded", C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     ("yl_preprocess", C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     ("yl_decode", C.c_int32, [_vp, _vpp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),

@@ -1430,8 +1430,14 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       if (l.k != 1 || l.stride != 1) return fail(c, YL_ERR_UNSUPPORTED, "dw prologue needs a 1x1 stride-1 main conv");
       if (!l.dw_w) return bad("dw prologue weights are NULL");
       if (l.dw_stride < 1) return bad("bad dw_stride");
-      if ((size_t)(l.dw_k * l.dw_k + 1) * l.cin * sizeof(float) > YL_DW_LDS_MAX)
-        return fail(c, YL_ERR_UNSUPPORTED, "dw prologue: taps+bias of all input channels must fit 32 KiB of LDS");
+      if ((size_t)(l.dw_k * l.dw_k + 1) * l.cin * sizeof(float) > YL_DW_LDS_MAX) {
+        // beyond the tap image of the generic depthwise-prologue kernels: only the streamed-tap kernel (yl_conv_dws_kernel) runs it
+        const bool dws = l.out_slot >= 0 && l.out_slot < d->num_slots && l.c2 == 0 && l.c3 == 0 && l.scale_slot < 0 && l.head_level < 0 &&
+                         yl_dws_supported(l.cin, l.cout, l.dw_k, l.dw_stride, c->slots[l.out_slot].h, c->slots[l.out_slot].w);
+        if (!dws)
+          return fail(c, YL_ERR_UNSUPPORTED, "dw prologue: taps+bias of all input channels must fit 32 KiB of LDS (or the layer must "
+                                             "be one yl_query_dw_prologue reports as 2)");
+      }
     }
     if (l.head_level >= 0) {
       if (l.op != YL_OP_CONV || l.head_level >= c->L) return bad("bad head_level");
@@ -1612,6 +1618,13 @@ int32_t yl_query_fused_block(int32_t c_in, int32_t c_mid, int32_t c_out, int32_t
   if (yl_ir_supported(c_in, c_mid, c_out, dw_k, dw_stride, out_h, out_w)) return 1;
   // per-wave kernel: stride 1 (input grid == output grid), grids multiples of 4 (the checks of yl_create)
   if (dw_stride == 1 && !(out_h & 3) && !(out_w & 3) && yl_uib_supported(c_in, c_mid, c_out, dw_k)) return 2;
+  return 0;
+}
+
+int32_t yl_query_dw_prologue(int32_t c_in, int32_t c_out, int32_t dw_k, int32_t dw_stride, int32_t out_h, int32_t out_w) {
+  if (c_in < 1 || c_out < 1 || dw_k < 1 || dw_stride < 1 || out_h < 1 || out_w < 1) return 0;
+  if (yl_dws_supported(c_in, c_out, dw_k, dw_stride, out_h, out_w)) return 2;
+  if ((size_t)(dw_k * dw_k + 1) * c_in * sizeof(float) <= YL_DW_LDS_MAX) return 1;
   return 0;
 }
 

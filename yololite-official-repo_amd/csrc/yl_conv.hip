@@ -45,6 +45,7 @@
 #define yl_launch_conv_ir YL_LP_NAME(yl_launch_conv_ir)
 #define yl_launch_conv_wino YL_LP_NAME(yl_launch_conv_wino)
 #define yl_launch_conv_dwk YL_LP_NAME(yl_launch_conv_dwk)
+#define yl_launch_conv_dws YL_LP_NAME(yl_launch_conv_dws)
 #define yl_launch_conv_dwt YL_LP_NAME(yl_launch_conv_dwt)
 #endif
 #include <stdio.h>
@@ -1328,6 +1329,13 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   if (n == 1 && p.dw_k == 0 && p.k > 1 && tile_hint != 6) {
     const hipError_t ek = yl_launch_conv_kxk(p, st);
     if (ek != hipErrorNotSupported) return ek;
+  }
+  // depthwise k x k -> 1x1 with >= 192 depthwise channels and 7..22 n-tiles (EfficientNet-Lite conv_dw -> conv_pwl): streamed 1x1
+  // AND tap weights, halo patch through LDS (yl_convc.hip, round 5).  Not behind tile_hint: these layers carry more tap
+  // weights than the 32 KB image of the other depthwise-prologue kernels, nothing else can run them
+  if (n == 1 && p.dw_k > 0) {
+    const hipError_t es = yl_launch_conv_dws(p, st);
+    if (es != hipErrorNotSupported) return es;
   }
   // depthwise 3x3 -> wide 1x1 whose weight image is beyond LDS: streamed weights, taps from L1/L2 (yl_convc.hip)
   if (n == 1 && p.dw_k == 3 && tile_hint != 6 && tile_hint != 3) {

@@ -36,6 +36,8 @@
 #define yl_launch_conv_dwt YL_LP_NAME(yl_launch_conv_dwt)
 #define yl_conv_dwk_kernel YL_LP_NAME(yl_conv_dwk_kernel)
 #define yl_launch_conv_dwk YL_LP_NAME(yl_launch_conv_dwk)
+#define yl_conv_dws_kernel YL_LP_NAME(yl_conv_dws_kernel)
+#define yl_launch_conv_dws YL_LP_NAME(yl_launch_conv_dws)
 #define yl_conv_wino_kernel YL_LP_NAME(yl_conv_wino_kernel)
 #define yl_launch_conv_wino YL_LP_NAME(yl_launch_conv_wino)
 #define yl_conv_kxk_kernel YL_LP_NAME(yl_conv_kxk_kernel)
@@ -1804,6 +1806,272 @@ hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depthwise DK x DK (stride DS) -> 1x1 with MANY channels on the depthwise side (round 5): the `conv_dw` -> `conv_pwl` halves of
+// timm's EfficientNet-Lite inverted-residual blocks behind model_v2.py:94-100 (yololite_m = tf_efficientnet_lite2 stages 4-6:
+// 528 / 720 / 1248 channels, 5x5 stride 1 and 2, 3x3 at 1248 -> 352).  Neither fused kernel
+// covered them -- yl_conv_dwt_kernel keeps the taps of ALL channels in LDS (26 x 1248 floats = 130 KB) and reads its 1x1
+// weights per wave from L1/L2 (<= 6 n-tiles), yl_conv_dwk_kernel fetches nine taps per lane from L1/L2 (25 at 5x5: bound by
+// the vector-memory path) -- so the depthwise conv ran as its own launch (yl_dw_tile_kernel: ten launches, ~0.8 ms of the
+// 12 ms step at B = 32, the expanded tensor written and re-read).  This kernel joins the two recipes:
+//   from yl_conv_dwk_kernel  the 1x1 weight stream double-buffered through LDS in chunks of S k-steps shared by the NW waves
+//                            of a workgroup (asynchronous copies, one barrier per chunk), a wave holds EVERY n-tile of its
+//                            pixels (GW x NT accumulator sets), items dealt in XCD bands;
+//   from yl_conv_dwt_kernel  wave = one 4x4-pixel tile, the (3 DS + DK)^2 halo patch of a 16-channel block staged through the
+//                            wave's private LDS region (4 / 8 / 3 coalesced float4 loads per lane, requested one k-step
+//                            ahead), B = act(bias + sum_taps w * x) from conflict-free ds_read_b128;
+//   new                      the tap weights + depthwise bias of a k-step (26 x 16 floats) ride in the weight chunk: LDS holds
+//                            2 x S k-steps of them, whatever the channel count.
+// Same tap order (dy, dx), k order and epilogues as yl_dw_tile_kernel + yl_conv_pws_kernel: the depthwise value of a channel is
+// the same fmaf chain, the 1x1 sums its k blocks in ascending order -> bit-identical to the two launches it replaces.
+template <int NT, int GW, int DK, int DS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void yl_conv_dws_kernel(YlConvP p) {
+  constexpr int NTW = NT * GW;                                        // n-tiles a wave accumulates (all of the layer's)
+  constexpr int S = NTW <= 8 ? 2 : 1;                                // k-steps per chunk (= per barrier)
+  constexpr int TAPS = DK * DK, TQ = (TAPS + 1) * 4;                 // float4s of taps + bias per k-step
+  constexpr int TQP = ((TQ + 63) / 64) * 64;                         // ... padded to whole 64-lane copies
+  constexpr int HP = 3 * DS + DK;                                    // halo patch rows = columns
+  constexpr int PITCHF = ((HP * 16 + 7) / 64) * 64 + 56;             // row pitch in floats (see yl_conv_dwh_kernel)
+  constexpr int HF4 = HP * HP * 4, NSLOT = (HF4 + 63) / 64;
+  constexpr int PCS = S * NTW + S * (TQP / 64);                      // 1 KiB pieces per chunk: weights, then taps
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int KB = p.KB, NTtot = p.NTtot, Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW;
+  const float* const xin = p.x;
+  const long zdelta = p.zeros - p.x;
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);                     // [2][S][NTW][64] float4
+  f32x4* tl = wl + (size_t)2 * S * NTW * 64;                         // [2][S][TQP] float4: row t = tap t (t = TAPS: bias), 4 quads
+  float* halo = reinterpret_cast<float*>(tl + (size_t)2 * S * TQP) + wave * (HP * PITCHF);
+  const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
+  const int NC = (KB + S - 1) / S;
+  const int twn = OW >> 2, tiles_img = twn * (OH >> 2);
+  const long ntiles4 = (long)p.B * tiles_img;                        // 4x4 tiles; p.ntiles = items of NW tiles
+  const int bx = blockIdx.x, gx = gridDim.x;                         // gx % 8 == 0
+  const int per = gx >> 3, slot = bx >> 3;
+  const int tpx = (p.ntiles + 7) >> 3;
+  const int band0 = (bx & 7) * tpx;
+  const int band1 = (band0 + tpx) < p.ntiles ? (band0 + tpx) : p.ntiles;
+  const int bt = band1 > band0 ? band1 - band0 : 0;
+  const int nmine = slot < bt ? (bt - 1 - slot) / per + 1 : 0;
+  const long total_chunks = (long)nmine * NC;
+  auto load_chunk = [&](int c, int buf) {
+    for (int i = wave; i < PCS; i += NW) {
+      if (i < S * NTW) {
+        const int j = i / NTW, nt = i - j * NTW;
+        const int kb = c * S + j;
+        if (kb < KB) yl_glds16(wg + ((size_t)kb * NTtot + (nt < NTtot ? nt : NTtot - 1)) * 64 + lane, wl + ((size_t)buf * S * NTW + i) * 64);
+      } else {
+        const int i2 = i - S * NTW;
+        const int j = i2 / (TQP / 64), r = i2 - j * (TQP / 64);
+        const int kb = c * S + j;
+        const int idx = r * 64 + lane, t = idx >> 2, ch = kb * 16 + (idx & 3) * 4;
+        if (kb < KB && idx < TQ) {
+          const float* src = (ch < Cin) ? (t < TAPS ? p.dw_w + (size_t)t * Cin + ch : (p.dw_b ? p.dw_b + ch : p.zeros)) : p.zeros;
+          yl_glds16(src, tl + ((size_t)(buf * S + j) * TQP + r * 64));
+        }
+      }
+    }
+  };
+  if (total_chunks > 0) load_chunk(0, 0);
+  long gchunk = 0;
+  // staging slots of this lane: halo pixel / channel quad -> LDS offset
+  int s_lo[NSLOT];
+  bool s_ok[NSLOT];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int e = j * 64 + lane;
+    s_ok[j] = e < HF4;
+    const int hp = (s_ok[j] ? e : 0) >> 2, quad = e & 3;
+    const int hr = hp / HP, hc = hp - hr * HP;
+    s_lo[j] = hr * PITCHF + hc * 16 + quad * 4;
+  }
+  __syncthreads();
+  const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE;
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const int dw_act = p.dw_act;
+  const int rbase = ((pl >> 2) * DS) * PITCHF + ((pl & 3) * DS) * 16 + 4 * kq;
+
+  for (int wi = 0; wi < nmine; ++wi) {
+    const int item = band0 + slot + wi * per;
+    long t4 = (long)item * NW + wave;
+    const bool tvalid = t4 < ntiles4;
+    if (!tvalid) t4 = ntiles4 - 1;
+    const int b = (int)(t4 / tiles_img);
+    const int trem = (int)(t4 - (long)b * tiles_img);
+    const int tyi = trem / twn, txi = trem - tyi * twn;
+    YlPix px[1];
+    px[0].b = b; px[0].oy = 4 * tyi + (pl >> 2); px[0].ox = 4 * txi + (pl & 3); px[0].valid = tvalid;
+    px[0].lin = ((size_t)b * OH + px[0].oy) * OW + px[0].ox;
+    f32x4 acc[GW][1][NT];
+#pragma unroll
+    for (int gw = 0; gw < GW; ++gw)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[gw][0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pre_add) {
+      const size_t obase = px[0].lin * p.N;
+      size_t up_off = 0;
+      if (p.up) {
+        const int uy = (px[0].oy * p.UH) / p.OH, ux = (px[0].ox * p.UW) / p.OW;
+        up_off = (((size_t)px[0].b * p.UH + uy) * p.UW + ux) * p.N;
+      }
+#pragma unroll
+      for (int gw = 0; gw < GW; ++gw)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = (gw * NT + nt) * 16 + 4 * kq;
+          if (n < p.N) {
+            if (p.res) acc[gw][0][nt] = yl_ld4(p.res + obase + n);
+            if (p.up) acc[gw][0][nt] += yl_ld4(p.up + up_off + n);
+          }
+        }
+    }
+    long goff[NSLOT];
+    {
+      const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * txi * DS - p.dw_pad_l;
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j) {
+        const int e = j * 64 + lane;
+        const int hp = (e < HF4 ? e : 0) >> 2;
+        const int hr = hp / HP, hc = hp - hr * HP;
+        const int iy = iy0 + hr, ix = ix0 + hc;
+        const bool in = e < HF4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        goff[j] = in ? (((long)b * H + iy) * W + ix) * Cin + (lane & 3) * 4 : -1;
+      }
+    }
+    auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
+      const bool cok = kb * 16 + (lane & 3) * 4 < Cin;
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j) r[j] = yl_ld4(xin + ((cok && goff[j] >= 0) ? goff[j] + kb * 16 : zdelta));
+    };
+    auto stage_store = [&](const f32x4 (&r)[NSLOT]) {
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j)
+        if (s_ok[j]) *reinterpret_cast<f32x4*>(halo + s_lo[j]) = r[j];
+    };
+    f32x4 stg[NSLOT];
+    stage_load(0, stg);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // previous item's tap reads are complete
+    stage_store(stg);
+    for (int c = 0; c < NC; ++c, ++gchunk) {
+      const int buf = (int)(gchunk & 1);
+      if (gchunk + 1 < total_chunks) load_chunk(c + 1 < NC ? c + 1 : 0, buf ^ 1);
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        const int kb = c * S + j;
+        if (kb < KB) {
+          const bool more = kb + 1 < KB;
+          if (more) stage_load(kb + 1, stg);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // halo writes (all lanes) -> tap reads
+          const f32x4* tw = tl + (size_t)(buf * S + j) * TQP + kq;
+          f32x4 xq[1];
+          xq[0] = tw[TAPS * 4];
+#pragma unroll 1
+          for (int dy = 0; dy < DK; ++dy) {                          // one tap row at a time bounds the register footprint
+#pragma unroll
+            for (int dx = 0; dx < DK; ++dx) {
+              const f32x4 w = tw[(dy * DK + dx) * 4];
+              const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + dx * 16);
+              xq[0].x = fmaf(v.x, w.x, xq[0].x); xq[0].y = fmaf(v.y, w.y, xq[0].y);
+              xq[0].z = fmaf(v.z, w.z, xq[0].z); xq[0].w = fmaf(v.w, w.w, xq[0].w);
+            }
+          }
+          xq[0] = yl_actc(xq[0], dw_act, dlo, dhi);
+          // channel tail (c >= Cin): the packed 1x1 weights of those k slots are zero (and the taps were copied from zeros)
+          const f32x4* wb = wl + (size_t)(buf * S + j) * NTW * 64 + lane;
+#pragma unroll
+          for (int gw = 0; gw < GW; ++gw) {
+            f32x4 wq[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wq[nt] = wb[(gw * NT + nt) * 64];
+            yl_mma_step<NT, 1>(wq, xq, acc[gw]);
+          }
+          if (more) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // this block's tap reads are complete
+            stage_store(stg);
+          }
+        }
+      }
+      __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
+    }
+#pragma unroll
+    for (int gw = 0; gw < GW; ++gw) {
+      if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, 1>(p, acc[gw], px, gw * NT, kq);
+      else yl_epi_fast<NT, 1>(p, acc[gw], px, gw * NT, kq, lo, hi, true);
+    }
+  }
+}
+
+static size_t yl_dws_lds(int ntw, int dk, int ds, int nw) {
+  const int s = ntw <= 8 ? 2 : 1, tqp = ((dk * dk + 1) * 4 + 63) / 64 * 64, hp = 3 * ds + dk;
+  const int pitch = ((hp * 16 + 7) / 64) * 64 + 56;
+  return ((size_t)2 * s * ntw * 256 + (size_t)2 * s * tqp * 4 + (size_t)nw * hp * pitch) * 4;
+}
+
+template <int NT, int GW, int DK, int DS, int NW>
+static hipError_t dws_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_dws_kernel<NT, GW, DK, DS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  YlConvP p = p0;
+  const long t4 = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
+  p.ntiles = (int)((t4 + NW - 1) / NW);
+  const size_t lds = yl_dws_lds(NT * GW, DK, DS, NW);
+  const int res = yl_resident_blocks_n(yl_conv_dws_kernel<NT, GW, DK, DS, NW>, NW * 64, lds);
+  int gx = res & ~7;
+  while (gx > 8 && gx - 8 >= p.ntiles) gx -= 8;
+  hipLaunchKernelGGL((yl_conv_dws_kernel<NT, GW, DK, DS, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
+  return hipGetLastError();
+}
+
+// instantiated: (n-tiles per accumulator set, sets, depthwise k, stride): 8 n-tiles (N <= 128), 13 (N <= 208), 2 x 11 (N <= 352).
+// Measured on yololite_m B = 32 (eager, ms; two launches -> this kernel): 528 -> 120 5x5 @40x40 0.191 -> 0.160, 720 -> 120 0.246 ->
+// 0.217, 720 -> 208 5x5 s2 0.131 -> 0.127, 1248 -> 208 5x5 @20x20 0.168 -> 0.164, 1248 -> 352 3x3 (22 n-tiles) 0.188 -> 0.228.
+// 45-50 TFLOP/s: the 25 tap + 25 tap-weight ds_read_b128 per k-step make it LDS-bound at two waves per SIMD (S = 1, 8 waves per
+// workgroup and a fully unrolled tap loop were measured: 0.220 / 0.210 (but 0.233 at 13 n-tiles) / 0.226 against 0.217).  What
+// counts is the step with two batches in flight, where launches and HBM traffic are the currency: 2.58 k images/s with the
+// eleven stand-alone depthwise launches, 2.65 k with ten of them fused, 2.72 k with all eleven (the 22 n-tile layer included,
+// although it is slower in isolation) -- 2.9 GB of expanded-tensor traffic fewer per step.
+#define YL_DWS_SHAPES(X) X(8, 1, 5, 1) X(8, 1, 5, 2) X(13, 1, 5, 1) X(13, 1, 5, 2) X(8, 1, 3, 1) X(13, 1, 3, 1) X(11, 2, 3, 1) X(11, 2, 5, 1)
+
+#if !YL_BF16
+// depthwise -> 1x1 layers this kernel takes: >= 12 k-blocks (below that yl_conv_dwt / dwh / dwk_kernel and the 32 KB tap
+// image are the better fit), 4x4-tileable output, N % 4 == 0, one of the instantiated (n-tiles, k, stride) shapes
+bool yl_dws_supported(int cin, int n, int dk, int ds, int oh, int ow) {
+  const int kb = (cin + 15) / 16, ntt = (n + 15) / 16;
+  if (kb < 12 || (n & 3) || (cin & 3) || (oh & 3) || (ow & 3) || oh < 4 || ow < 4) return false;
+#define YL_DWS_CHECK(A, G, K, S_) if (dk == K && ds == S_ && ntt <= A * G && ntt > (A * G == 8 ? 6 : A * G == 13 ? 8 : 13)) return true;
+  YL_DWS_SHAPES(YL_DWS_CHECK)
+#undef YL_DWS_CHECK
+  return false;
+}
+#endif
+
+hipError_t yl_launch_conv_dws(const YlConvP& p, hipStream_t st) {
+  if (p.dw_k == 0 || p.k != 1 || p.stride != 1 || p.dec_boxes || p.C1 > 0 || p.scale || p.in_shift || p.w3p ||
+      !yl_dws_supported(p.Cin, p.N, p.dw_k, p.dw_stride, p.OH, p.OW) ||
+      (size_t)p.B * p.H * p.W * p.Cin >= ((size_t)1 << 40))
+    return hipErrorNotSupported;
+  const int ntt = p.NTtot;
+#define YL_DWS_RUN(A, G, K, S_) \
+  if (p.dw_k == K && p.dw_stride == S_ && ntt <= A * G && ntt > (A * G == 8 ? 6 : A * G == 13 ? 8 : 13)) return dws_go<A, G, K, S_, 4>(p, st, false);
+  YL_DWS_SHAPES(YL_DWS_RUN)
+#undef YL_DWS_RUN
+  return hipErrorNotSupported;
+}
+
+static hipError_t yl_dws_init() {
+  YlConvP q = {};
+  hipError_t e = hipSuccess;
+#define YL_DWS_ATTR(A, G, K, S_) if (e == hipSuccess) e = dws_go<A, G, K, S_, 4>(q, nullptr, true);
+  YL_DWS_SHAPES(YL_DWS_ATTR)
+#undef YL_DWS_ATTR
+  return e;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense 3x3 stride-1 convolution as Winograd F(2x2,3x3): Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A -- 16 multiplications
 // per 2x2 output tile and channel pair instead of 36 (2.25x fewer MFMAs; option "winograd": every eligible layer by
 // default since round 4 -- the transforms round differently from the direct convolution, so the result is not
@@ -2101,6 +2369,7 @@ hipError_t yl_convc_init() {
   if (e == hipSuccess) e = dwk_go<7, 3, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<8, 1, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<8, 2, 4>(q, nullptr, true);
+  if (e == hipSuccess) e = yl_dws_init();
   if (e != hipSuccess) return e;
   return dwc_any(m, 0, 0, 0, 0, 0, nullptr, true, nullptr);
 }

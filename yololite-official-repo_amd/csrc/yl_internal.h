@@ -241,6 +241,12 @@ hipError_t yl_launch_conv_dwt_bf16(YlConvMulti& m, hipStream_t st);
 // streamed-weight depthwise 3x3 -> 1x1 kernel for K >= 192 and more than 8 n-tiles (yl_convc.hip)
 hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_dwk_bf16(const YlConvP& p, hipStream_t st);
+// depthwise k x k -> 1x1 for >= 192 depthwise channels: streamed 1x1 weights AND tap weights, halo patch through LDS (yl_convc.hip,
+// round 5); hipErrorNotSupported = shape not instantiated
+hipError_t yl_launch_conv_dws(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv_dws_bf16(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_conv_dws_f16(const YlConvP& p, hipStream_t st);
+bool yl_dws_supported(int cin, int n, int dk, int ds, int oh, int ow);
 // Winograd F(2x2,3x3) dense 3x3 (yl_convc.hip); hipErrorNotSupported = not this layer
 hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_conv_wino_bf16(const YlConvP& p, hipStream_t st);

@@ -379,12 +379,12 @@ class YOLOLiteHIP:
     a [B,3,S,S] float tensor, returns the list of level tensors."""
 
     def __init__(self, meta: dict, fuse_dw="auto", fuse_stem: bool = True, fuse_uib: bool = False, fuse_ir=None,
-                 fuse_uir: bool = True, fuse_lat: bool = True, fuse_chain: bool = True):
+                 fuse_uir: bool = True, fuse_lat: bool = True, fuse_chain: bool = True, fuse_dws: bool = True):
         self.meta = meta
         self.fuse_dw, self.fuse_stem, self.fuse_uib, self.fuse_ir = fuse_dw, fuse_stem, fuse_uib, fuse_ir
         # every fusion policy of the host compiler is resolved HERE, once per model (no process environment)
         self._fuse_kw = dict(fuse_dw=fuse_dw, fuse_stem=fuse_stem, fuse_uib=fuse_uib, fuse_ir=fuse_ir, fuse_uir=fuse_uir,
-                             fuse_lat=fuse_lat, fuse_chain=fuse_chain)
+                             fuse_lat=fuse_lat, fuse_chain=fuse_chain, fuse_dws=fuse_dws)
         self.export_concat = False
         # yl_set_option values applied to EVERY context of this model (one per input size), e.g. the pip API's serving
         # options; set with set_context_options() so that contexts that already exist get them too

@@ -319,6 +319,11 @@ def _query_fused_block(c_in, c_mid, c_out, dk, ds, oh, ow) -> int:
     return _query_cached(int(c_in), int(c_mid), int(c_out), int(dk), int(ds), int(oh), int(ow))
 
 
+def _query_dw_prologue(c_in, c_out, dk, ds, oh, ow) -> int:
+    """yl_query_dw_prologue: 2 = the streamed-tap depthwise -> 1x1 kernel takes the pair, 1 = the generic prologue kernels, 0 = no"""
+    return _query_cached("dw", int(c_in), int(c_out), int(dk), int(ds), int(oh), int(ow))
+
+
 @functools.lru_cache(maxsize=None)
 def _query_cached(*shape) -> int:
     from . import _lib
@@ -329,14 +334,17 @@ def _query_cached(*shape) -> int:
             "build_program() asks libyololite_hip.so which fused block shapes are instantiated (yl_query_fused_block, host "
             f"code, no GPU needed) and the library could not be loaded: {e}.  Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc cross-compiles without a GPU)") from e
+    if shape and shape[0] == "dw":
+        return int(lib.yl_query_dw_prologue(*shape[1:]))
     return int(lib.yl_query_fused_block(*shape))
 
 
 class _Builder:
     def __init__(self, sd: Dict[str, np.ndarray], prog: Program, fuse_dw, fuse_stem=True, fuse_uib=True, fuse_ir=True,
-                 fuse_uir=True, fuse_lat=True, fuse_chain=True):
+                 fuse_uir=True, fuse_lat=True, fuse_chain=True, fuse_dws=True):
         self.sd, self.p, self.fuse_dw, self.fuse_stem, self.fuse_uib = sd, prog, fuse_dw, fuse_stem, fuse_uib
         self.fuse_ir, self.fuse_uir, self.fuse_lat, self.fuse_chain = fuse_ir, fuse_uir, fuse_lat, fuse_chain
+        self.fuse_dws = fuse_dws
 
     # ---- state-dict access
     def get(self, key: str, shape: Tuple[int, ...]) -> np.ndarray:
@@ -498,8 +506,12 @@ class _Builder:
             dow, _ = self.geom(wd, dw["k"], dw["s"], same)
             dmacs = doh * dow * cin * dw["k"] ** 2
             fuse = (dw["k"] == 3) if self.fuse_dw == "dw3" else bool(self.fuse_dw)      # "auto" -> all
-            # the prologue keeps the depthwise taps + bias of all Cin channels in LDS (yl_conv.hip)
-            fuse = fuse and (dw["k"] ** 2 + 1) * cin * 4 <= DW_PROLOGUE_LDS_MAX
+            # the prologue keeps the depthwise taps + bias of all Cin channels in LDS (yl_conv.hip) -- or, for the wide
+            # EfficientNet-Lite conv_dw -> conv_pwl pairs, streams them with the 1x1 weights (yl_conv_dws_kernel, round 5): the
+            # library says which (yl_query_dw_prologue)
+            if fuse and (dw["k"] ** 2 + 1) * cin * 4 > DW_PROLOGUE_LDS_MAX:
+                fuse = (self.fuse_dws and k == 1 and s == 1 and head_level < 0 and scale < 0 and not chain
+                        and _query_dw_prologue(cin, cout, dw["k"], dw["s"], doh, dow) == 2)
             if fuse and k == 1 and s == 1:
                 pro = dict(k=dw["k"], s=dw["s"], pad=dpad, act=_ACT[dw["act"]], w=dww,
                            b=dwb if (dw.get("bn") or dw.get("bias")) else None, macs=dmacs)
@@ -866,14 +878,15 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
 def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto",
                   img_size: Optional[int] = None, fuse_stem: bool = True, fuse_uib: bool = False,
                   fuse_ir: Optional[bool] = None, fuse_uir: bool = True, fuse_lat: bool = True,
-                  fuse_chain: bool = True) -> Program:
+                  fuse_chain: bool = True, fuse_dws: bool = True) -> Program:
     """meta: the checkpoint's `meta` dict (tools/train.py:62-75); reads the keys
     build_model_from_meta reads (tools/infer.py:35-50).
     fuse_dw: True = every depthwise conv becomes the prologue of the following 1x1 conv, False = none,
     "dw3" = only 3x3; "auto" = measured best policy (currently: all, LDS-halo kernel).
     fuse_ir: EfficientNet-style inverted-residual blocks of the shapes yl_ir_kernel is instantiated for as ONE launch
     (None = on); fuse_uir: likewise the MobileNetV4 UIB blocks without a start depthwise; fuse_lat: FPN lateral + first
-    depthwise smooth block as one launch; fuse_chain: a 1x1 conv chained in the epilogue of the dense k x k conv before
+    depthwise smooth block as one launch; fuse_dws: wide EfficientNet-Lite conv_dw -> conv_pwl pairs through the streamed-tap
+    kernel (yl_query_dw_prologue == 2); fuse_chain: a 1x1 conv chained in the epilogue of the dense k x k conv before
     it.  All of them are arguments (resolved once per model: YOLOLiteHIP.__init__), never process environment: two
     programs built in one process cannot silently differ."""
     if fuse_ir is None:
@@ -907,7 +920,7 @@ def build_program(meta: dict, state_dict: Dict[str, "np.ndarray"], fuse_dw="auto
     prog = Program(img_size=S, num_classes=C, level_size=[], level_anchors=[], strides=[])
     on = fuse_dw is not False
     b = _Builder(sd, prog, fuse_dw, fuse_stem, bool(fuse_uib) and on, bool(fuse_ir) and on, bool(fuse_uir) and on,
-                 bool(fuse_lat) and on, bool(fuse_chain) and on)
+                 bool(fuse_lat) and on, bool(fuse_chain) and on, bool(fuse_dws) and on)
 
     feats = _backbone(b, backbone)
     take = 4 if use_p2 else 3
