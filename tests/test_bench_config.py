@@ -288,9 +288,10 @@ def test_full_size_configs_3_and_4(name, seg, seed):
         print(f"[parity {name} seed {seed}] winograd {mode}: max |score - oracle score| {err:.3e}")
         assert err <= 1e-4
         dw_, cw_ = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo)
-        selw = _safe_images(_score_tensor(det_lv), None, 0.4, range(len(cand)), need=2)
-        for i in selw:
-            _assert_north_star(_rows(dw_, cw_, cand[i]), exp, i)
+        # (round 5, VERDICT r04: the other Winograd settings used to be held to two sampled images) EVERY threshold-safe image
+        _assert_all_safe_images(dw_, cw_, exp, _score_tensor(det_lv), 0.4, cand, exp_index=pos,
+                                what=f"{name}{'+seg' if seg else ''} B=32 seed {seed} winograd {mode}",
+                                got_scores=_score_tensor([t[cand].cpu() for t in lw]))
     if seg:                                                        # edge_m: only the prototype branch has eligible convs
         assert not torch.equal(outs[0][0], a[1]) and float((outs[0][0] - a[1]).abs().max()) <= 1e-4
         # (mode 2 = the >= 64-channel layer on the largest grid: the second prototype conv at 160x160 only)
