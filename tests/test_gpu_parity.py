@@ -414,6 +414,37 @@ def test_winograd_option_matches_direct_convolution(name, B, S):
     ctx.set_option("winograd", 1)
 
 
+@pytest.mark.parametrize("name,B,S,seg", [("yololite_m", 3, 256, 0), ("yololite_m", 1, 224, 0), ("yololite_m", 2, 640, 0),
+                                          ("edge_m", 2, 320, 1), ("yololite_m_v2", 2, 256, 0)])
+def test_winograd_position_split_kernel_is_bitwise_the_first_form(name, B, S, seg):
+    """yl_conv_wino2_kernel (round 5: the 16 transform positions dealt to the waves, input window through LDS once per item)
+    evaluates the same transform expressions, k order and epilogue as yl_conv_wino_kernel -> identical bits, for every item
+    shape ("dev_select" bits 12-13) against the first form ("dev_select" bit 11).  224: odd level grids (partial m-tiles);
+    640: the shapes the benchmark runs (4 m-tiles x 3 n-tiles at 80x80); edge_m + seg: the prototype branch's conv on a
+    nearest-upsampled input (in_shift 1) with SiLU."""
+    meta = zoo_meta(name, 80, S, **(dict(seg=True) if seg else {}))
+    sd = synth_state_dict(meta, seed=6)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    x = _x(B, S, seed=13).to(DEV)
+    ctx.set_option("winograd", 1)
+    ctx.set_option("dev_select", _lib.DEV_WINO_V1)
+    def run():
+        out = m(x)
+        return ([t.clone() for t in out[0]] + [out[1].clone()]) if seg else [t.clone() for t in out]   # (+ mask prototypes)
+    first = run()
+    ctx.set_option("winograd", 0)
+    direct = run()
+    ctx.set_option("winograd", 1)
+    assert any(not torch.equal(u, v) for u, v in zip(first, direct))          # Winograd layers exist in this model
+    for shape in (0, 1, 2, 3):
+        ctx.set_option("dev_select", shape << _lib.DEV_WINO_SHAPE_SHIFT)
+        got = run()
+        for u, v in zip(first, got):
+            assert torch.equal(u, v), (shape, float((u - v).abs().max()))
+    ctx.set_option("dev_select", 0)
+
+
 def test_tiled_depthwise_kernel_is_bitwise_the_per_output_kernel():
     """yl_dw_tile_kernel (register-tiled stand-alone depthwise, yololite_m's backbone) accumulates every output's taps
     in the (dy, dx) order of yl_dw_kernel -> identical bits.  The switch is a per-context developer option

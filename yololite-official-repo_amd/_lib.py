@@ -52,6 +52,8 @@ NMS_TORCHVISION, NMS_GREEDY = 0, 1
 # "dev_select" bits (developer A/B, bitwise kernel-equivalence tests; see yl_get_option in the header)
 DEV_DW_TILE_OFF, DEV_PWS_OFF, DEV_S2C_OFF, DEV_DWC_ALL, DEV_DWT_OFF = 1, 2, 4, 8, 16
 DEV_DWT_NOSPLIT = 1 << 10
+DEV_WINO_V1 = 1 << 11            # Winograd: yl_conv_wino_kernel (every position in one wave) instead of yl_conv_wino2_kernel
+DEV_WINO_SHAPE_SHIFT = 12         # yl_conv_wino2_kernel item shape (2 bits): 0 auto, 1 (4,4), 2 (2,7), 3 two m-tiles
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)

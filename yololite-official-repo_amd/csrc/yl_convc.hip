@@ -50,6 +50,7 @@
 #endif
 #include <stdlib.h>
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <utility>
 #include "yl_internal.h"
@@ -88,6 +89,20 @@ extern "C" int yl_debug_dwc_stamps(void* host) {
 }
 #else
 #define DWC_STAMP(i) do {} while (0)
+#endif
+// the same aid for yl_conv_wino2_kernel (-DYL_WINO_STAMP=<Cin>; tools/wino_stamps.py): 7 stamps per k-block of the second item
+#ifdef YL_WINO_STAMP
+__device__ unsigned long long yl_wino_stamps[256 * 8 * 64];
+#define WINO_STAMP(i)                                                                                            \
+  do {                                                                                                           \
+    if (p.Cin == YL_WINO_STAMP && p.OH >= 80 && lane == 0 && blockIdx.x < 256 && wi == 1 && (i) < 64)              \
+      yl_wino_stamps[((size_t)blockIdx.x * 8 + wave) * 64 + (i)] = __builtin_readcyclecounter();                \
+  } while (0)
+extern "C" int yl_debug_wino_stamps(void* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(yl_wino_stamps), sizeof(yl_wino_stamps)) == hipSuccess ? 0 : -1;
+}
+#else
+#define WINO_STAMP(i) do {} while (0)
 #endif
 
 template <int NTW>
@@ -2284,13 +2299,341 @@ static hipError_t wino_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3), second form (round 5): the 16 transform positions are dealt to the WAVES -- wave w owns positions
+// (i, j) = (w >> 1, 2 (w & 1) + {0, 1}) -- and every wave holds MT m-tiles x NT n-tiles of accumulators for its two
+// positions.  yl_conv_wino_kernel gives each wave all 16 positions of 16 tiles x 2 n-tiles: per 128 MFMAs it fetches and
+// transforms a 16 KB patch and reads 32 KB of U from LDS, the input is re-fetched and re-transformed once per 32 output
+// channels (11 times at N = 328), and its two wave groups alternate between a memory phase and an MFMA phase with two
+// barriers per k-block (MFMA pipe 56 % busy at 80 x 80).  Here a workgroup item is MT m-tiles (m-tile = 4 x 4 Winograd
+// tiles = 8 x 8 output pixels of one image) x NT n-tiles; per 16-channel k-block:
+//   window  the 10 x 10-pixel input window of each m-tile (64 B per pixel) lands in LDS by asynchronous LDS-DMA copies
+//           (MT per wave, no VGPRs), double-buffered, requested a whole k-block ahead: every input pixel is fetched ONCE
+//           per item -- not once per tile that touches it -- and once per NT n-tiles (7 times at N = 328, NT = 3)
+//   B       a position (i, j) of B^T d B is a signed sum of FOUR window pixels (rows {0,2} {1,2} {2,1} {1,3} by i, columns
+//           likewise by j), so a wave builds the B fragments of its two positions itself: per m-tile 6 ds_read_b128 (2 rows
+//           x 3 columns), 3 row combinations X + s Y, 2 column combinations -- 10 packed VALU operations between the MFMAs.
+//           No transformed image in LDS, no second barrier.  (A first version wrote V = B^T d B to LDS with all 512
+//           threads and read it back as B fragments: two barriers per k-block, a 16-read / 8-write LDS round trip per
+//           thread and a 160 KB footprint; tools/wino_stamps.py and the ablation builds priced that round trip at 0.24 ms
+//           of a 1.98 ms launch and the bare MFMA + barrier skeleton at 1.45 ms.)
+//   A       NT 1-KB fragment loads of U_xi straight from L1/L2 per position, requested one position ahead -- U of a
+//           position is used by one wave only, LDS would not share anything
+//   MFMA    2 x MT x NT x 4 per wave and k-block; the memory requests sit BETWEEN them (issued back to back -- 8 waves x 7
+//           instructions at one moment -- they filled the CU's vector-memory queue, and in-order issue kept every wave in
+//           front of its MFMAs until its own requests were taken: 2300 of 11000 cycles per k-block)
+// ONE barrier per k-block.  After the K loop the accumulators of one n-tile at a time go through LDS so that thread
+// (m-tile, lane, output row) gathers the 12 positions of its row: output transform, bias, activation, residual, float4
+// NHWC stores.  Same transform expressions (X - Y == X + (-1) Y in one rounding), k order (k-blocks ascending, the four
+// MFMAs of a block in yl_mma_step's order per accumulator) and epilogue as yl_conv_wino_kernel: BIT-IDENTICAL to it
+// (tests/test_gpu_parity.py).  Reads the same U image (pack_wino).
+// Window layout (16-byte slots, 512 per m-tile and buffer, 480 used): pixel index P = R(y) * 12 + C(x) with R(y) =
+// 5 (y & 1) + (y >> 1), C likewise -- even rows / columns first, so that tiles two pixels apart are neighbours --,
+// slot = 4 P + (kq ^ 2 ((P >> 2) & 1)).  (a) the four lanes of a quad copy the 64 contiguous bytes of ONE pixel: a copy
+// instruction touches 16 cache lines, not 64; (b) a ds_read_b128 lane group holds 8 tiles with channel group kq = a
+// (tile rows {0,3}) and 8 with a ^ 1 (tile rows {1,2}) (MI355X_MICROARCH.md, LDS): P = ty4 * 12 + tx4 + const takes every
+// residue mod 4 twice per set, the two with bit 2 of P different (36 = 9 * 4, 12 = 3 * 4), so the low slot bits are
+// {a, a ^ 2} and {a ^ 1, a ^ 3}: sixteen distinct 16-byte bank groups, conflict-free.
+template <int MT, int NT, int SH>
+__global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
+  constexpr int RP = 12, RM = 512;                              // slots per m-tile window (480 used: 8 full copy instructions)
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  f32x4* const Rl = reinterpret_cast<f32x4*>(yl_clds);          // [2][MT][RM] windows
+  f32x4* const Xl = Rl + 2 * MT * RM;                           // [16][MT][64] accumulator exchange of the epilogue
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;                      // MFMA lane: 4 channels 4kq.. of tile pl
+  const int ty4 = pl >> 2, tx4 = pl & 3;
+  const int KB = p.KB, Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N;
+  const int Hs = H >> SH, Ws = W >> SH;
+  const int TW = (OW + 1) >> 1, TH = (OH + 1) >> 1;
+  const int MX = (TW + 3) >> 2, MY = (TH + 3) >> 2;
+  const int mimg = MX * MY;
+  const long MTOT = (long)p.B * mimg;                           // m-tiles
+  const float* const xin = p.x;
+  const long zdelta = p.zeros - p.x;
+  const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wino);
+  const int NG2 = (p.NTtot + 1) >> 1;                           // n-tile pairs of the U image
+  const int G = (p.NTtot + NT - 1) / NT;
+  const int bx = blockIdx.x, gx = gridDim.x;                    // gx % 8 == 0
+  const int per = gx >> 3, slot = bx >> 3;
+  const int tpx = (p.ntiles + 7) >> 3;                          // m-blocks per XCD band
+  const int band0 = (bx & 7) * tpx;
+  const int band1 = (band0 + tpx) < p.ntiles ? (band0 + tpx) : p.ntiles;
+  const int bt = band1 > band0 ? band1 - band0 : 0;
+  const int nitems = bt * G;
+  const int nmine = slot < nitems ? (nitems - 1 - slot) / per + 1 : 0;
+  // item -> (n-group, m-block): as in yl_conv_wino_kernel (the workgroups of an XCD walk GBS n-groups of one input window)
+  constexpr int GBS = 4;
+  const int nbf = G / GBS;
+  auto item_g = [&](int item, int& mt) {
+    int gb = item / (bt * GBS), cnt = GBS;
+    if (gb >= nbf) { gb = nbf; cnt = G - nbf * GBS; }
+    const int rem = item - gb * bt * GBS;
+    mt = rem / cnt;
+    return gb * GBS + (rem - mt * cnt);
+  };
+  // copy role of the lane: slot rs = wave * 64 + lane of every m-tile's window
+  const int rs = wave * 64 + lane;
+  const int rP = rs >> 2, rkq = (rs & 3) ^ (((rP >> 2) & 1) << 1);
+  const int rpr = rP / RP, rpc = rP - rpr * RP;
+  const int ry = rpr < 5 ? 2 * rpr : 2 * (rpr - 5) + 1, rx = rpc < 5 ? 2 * rpc : 2 * (rpc - 5) + 1;
+  const bool rpix = rpr < 10 && rpc < 10;                        // (slots 480..511 and the pad columns copy zeros)
+  // position role of the wave: rows X + sr * Y, columns u0 - u1 and u1 + sc * u2
+  const int pi = wave >> 1, pj = wave & 1;
+  const int rowX = pi == 0 ? 0 : pi == 2 ? 2 : 1, rowY = pi == 2 ? 1 : pi == 3 ? 3 : 2;
+  const float sr = pi == 1 ? 1.0f : -1.0f, sc = pj ? -1.0f : 1.0f;
+  const f32x4 sr4 = (f32x4){sr, sr, sr, sr}, sc4 = (f32x4){sc, sc, sc, sc};
+  const int col0 = pj ? 2 : 0, col1 = pj ? 1 : 2, col2 = pj ? 3 : 1;
+  auto wslot = [&](int r, int c) {                               // the lane's slot of window pixel (2 ty4 + r, 2 tx4 + c)
+    const int P = (ty4 + (r & 1) * 5 + (r >> 1)) * RP + tx4 + (c & 1) * 5 + (c >> 1);
+    return 4 * P + (kq ^ (((P >> 2) & 1) << 1));
+  };
+  const int sX0 = wslot(rowX, col0), sX1 = wslot(rowX, col1), sX2 = wslot(rowX, col2);
+  const int sY0 = wslot(rowY, col0), sY1 = wslot(rowY, col1), sY2 = wslot(rowY, col2);
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+
+  int soff[MT];                                                  // float offset of the lane's window slot (k-block 0), -1 = zeros
+  auto setup = [&](int mblock) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const long mi = (long)mblock * MT + mt;
+      const int b = (int)(mi / mimg);
+      const int r = (int)(mi - (long)b * mimg);
+      const int my = r / MX, mx = r - my * MX;
+      const int gy = 8 * my - 1 + ry, gxx = 8 * mx - 1 + rx;
+      const bool in = rpix && mi < MTOT && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+      soff[mt] = in ? ((b * Hs + (gy >> SH)) * Ws + (gxx >> SH)) * Cin + 4 * rkq : -1;
+    }
+  };
+  auto issue_raw = [&](int kb, int buf) {                        // branch-free: it is scheduled between MFMAs
+#if defined(YL_WINO_ABL) && (YL_WINO_ABL & 1)                    // ablation builds (tools/run_wino_abl.sh): results wrong
+    if (kb > 0) return;
+#endif
+    const bool tail = kb * 16 + 4 * rkq >= Cin;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      yl_glds16((soff[mt] >= 0 && !tail) ? xin + soff[mt] + kb * 16 : xin + zdelta, Rl + (buf * MT + mt) * RM + wave * 64);
+  };
+
+  int mb0 = 0, g = 0;
+  if (nmine > 0) { g = item_g(slot, mb0); setup(band0 + mb0); issue_raw(0, 0); }
+  for (int wi = 0; wi < nmine; ++wi) {
+    const int mblock = band0 + mb0;
+    // U fragment of (n-tile g*NT + nt, k-block kb, position xi): pair-major image of pack_wino
+    size_t ub[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int ntg = g * NT + nt;
+      if (ntg >= 2 * NG2) ntg = 0;                                // beyond the image: any fragment (columns never stored)
+      ub[nt] = ((size_t)(ntg >> 1) * KB * 32 + (ntg & 1)) * 64 + lane;
+    }
+    auto load_u = [&](int kb, int xi, f32x4 (&dst)[NT]) {
+#if defined(YL_WINO_ABL) && (YL_WINO_ABL & 2)
+      if (kb > 0) return;
+#endif
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dst[nt] = wg[ub[nt] + (size_t)(kb * 16 + xi) * 128];
+    };
+    f32x4 acc[2][MT][NT];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ps][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // B fragments of the wave's two positions for m-tile mt out of window buffer `buf`
+    auto load_win = [&](int buf, int mt, f32x4 (&x)[3], f32x4 (&y)[3]) {
+      const f32x4* const wb = Rl + (buf * MT + mt) * RM;
+      x[0] = wb[sX0]; x[1] = wb[sX1]; x[2] = wb[sX2];
+      y[0] = wb[sY0]; y[1] = wb[sY1]; y[2] = wb[sY2];
+    };
+    auto make_b = [&](const f32x4 (&x)[3], const f32x4 (&y)[3], f32x4& b0, f32x4& b1) {
+      const f32x4 u0 = y[0] * sr4 + x[0], u1 = y[1] * sr4 + x[1], u2 = y[2] * sr4 + x[2];
+      b0 = u0 - u1;
+      b1 = u2 * sc4 + u1;
+    };
+    auto mma_mt = [&](const f32x4 (&a)[NT], const f32x4& b, f32x4 (&c)[NT]) {    // one m-tile: the 4 steps x NT n-tiles
+#if YL_BF16
+      const f32x4 bb[1] = {b};
+      f32x4 cc[1][NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) cc[0][nt] = c[nt];
+      yl_mma_step<NT, 1>(a, bb, cc);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) c[nt] = cc[0][nt];
+#else
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][st], b[st], c[nt], 0, 0, 0);
+#endif
+    };
+    f32x4 a0[NT], a1[NT];
+    load_u(0, 2 * wave, a0);
+    load_u(0, 2 * wave + 1, a1);
+    // One k-block: MT x (window reads of the next m-tile, B fragments, 2 x NT x 4 MFMAs).  The block's ONE barrier sits in
+    // front of the LAST m-tile's MFMAs: by then the wave has read all it needs of window(kb) and its copies of
+    // window(kb + 1) (requested a k-block ago) have landed, so behind the barrier window(kb + 1) is complete and window(kb)'s
+    // buffer is free -- the wave requests window(kb + 2) into it and the first m-tile's reads of block kb + 1, and only
+    // then issues the last m-tile's 2 x NT x 4 MFMAs: barrier and LDS latency lie under them and the MFMA stream runs on
+    // across k-blocks (with the barrier at the top of the block both waves of a SIMD met it with nothing to issue).
+    // MODE 0: any block; 1: the second-to-last (nothing left to request); 2: the last (peeled like this so that the body
+    // is branch-free: with conditional requests every merge waited for all outstanding loads).  The U fragments of block
+    // kb + 1 are requested into a second register set under the first two m-tiles and renamed at the end -- requested
+    // behind the last use of a0 / a1 they had no time to arrive.
+    f32x4 x[2][3], y[2][3];
+    __syncthreads();                                              // window(0) landed (requested under the previous epilogue)
+    issue_raw(1, 1);
+    load_win(0, 0, x[0], y[0]);
+    auto kblock = [&](int kb, auto mode) {
+      constexpr int MODE = decltype(mode)::value;
+      const int buf = kb & 1;
+      WINO_STAMP(kb * 7 + 0);
+      f32x4 an0[NT], an1[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt + 1 < MT) load_win(buf, mt + 1, x[(mt + 1) & 1], y[(mt + 1) & 1]);
+        f32x4 b0, b1;
+        make_b(x[mt & 1], y[mt & 1], b0, b1);
+        if (mt == MT - 1 && MODE < 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          WINO_STAMP(kb * 7 + 4);
+          __syncthreads();
+          WINO_STAMP(kb * 7 + 5);
+          if (MODE == 0) issue_raw(kb + 2, buf);
+          load_win(buf ^ 1, 0, x[0], y[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          WINO_STAMP(kb * 7 + 6);
+        }
+        mma_mt(a0, b0, acc[0][mt]);
+        if (MODE < 2 && mt == 0) load_u(kb + 1, 2 * wave, an0);
+        mma_mt(a1, b1, acc[1][mt]);
+        if (MODE < 2 && mt == (MT > 2 ? 1 : 0)) load_u(kb + 1, 2 * wave + 1, an1);
+        // m-tile by m-tile: left alone the scheduler gathered all window reads at the top (spills) and pushed the U
+        // requests behind the last MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt < 3) WINO_STAMP(kb * 7 + 1 + mt);
+      }
+      if (MODE < 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { a0[nt] = an0[nt]; a1[nt] = an1[nt]; }
+      }
+    };
+    for (int kb = 0; kb + 2 < KB; ++kb) kblock(kb, std::integral_constant<int, 0>{});
+    kblock(KB - 2, std::integral_constant<int, 1>{});
+    kblock(KB - 1, std::integral_constant<int, 2>{});
+    // the item's coordinates for the epilogue, then the next item's window(0) request flies under the epilogue
+    const int eg = g;
+    const int emt = wave & (MT - 1), epart = wave / MT;            // output role: m-tile, row a (and column c2 when MT = 2)
+    const long emi = (long)mblock * MT + emt;
+    if (wi + 1 < nmine) { g = item_g(slot + (wi + 1) * per, mb0); setup(band0 + mb0); }
+    const bool evalid = emi < MTOT;
+    const int eb = (int)((evalid ? emi : 0) / mimg);
+    const int er = (int)((evalid ? emi : 0) - (long)eb * mimg);
+    const int emy = er / MX, emx = er - emy * MX;
+    const int oa = epart & 1;
+    const int oy = 2 * (4 * emy + ty4) + oa, ox0 = 2 * (4 * emx + tx4);
+    __syncthreads();                                              // every wave is done with the windows
+    if (wi + 1 < nmine) issue_raw(0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nt > 0) __syncthreads();                                // the previous n-tile's exchange is read
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Xl[((size_t)(2 * wave + ps) * MT + mt) * 64 + lane] = acc[ps][mt][nt];
+      __syncthreads();
+      const f32x4* const mb = Xl + (size_t)emt * 64 + lane;
+      f32x4 r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 m1 = mb[((4 + j) * MT) * 64], m2 = mb[((8 + j) * MT) * 64];
+        if (oa == 0) r[j] = mb[(j * MT) * 64] + m1 + m2;
+        else r[j] = m1 - m2 - mb[((12 + j) * MT) * 64];
+      }
+      f32x4 yy[2];
+      yy[0] = r[0] + r[1] + r[2]; yy[1] = r[1] - r[2] - r[3];
+      const int n = ((eg * NT + nt) * 16) + 4 * kq;
+      if (evalid && n < N && oy < OH) {
+        const f32x4 bias = yl_ld4(p.bias + n);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          if (MT == 2 && c2 != (epart >> 1)) continue;
+          const int ox = ox0 + c2;
+          if (ox < OW) {
+            const size_t o = (((size_t)eb * OH + oy) * OW + ox) * N + n;
+            f32x4 v = yl_actc(yy[c2] + bias, p.act, lo, hi);
+            if (p.res) v += yl_ld4(p.res + o);
+            *reinterpret_cast<f32x4*>(p.out + o) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NT>
+static hipError_t wino2_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
+  const size_t lds = ((size_t)2 * MT * 512 + (size_t)16 * MT * 64) * 16;      // two window buffers + the epilogue exchange
+  if (attr_only) {
+    const hipError_t e = hipFuncSetAttribute((const void*)yl_conv_wino2_kernel<MT, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)yl_conv_wino2_kernel<MT, NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  YlConvP p = p0;
+  const int TW = (p.OW + 1) >> 1, TH = (p.OH + 1) >> 1;
+  const long MTOT = (long)p.B * ((TW + 3) >> 2) * ((TH + 3) >> 2);
+  p.ntiles = (int)((MTOT + MT - 1) / MT);
+  const int res = yl_resident_blocks_n(yl_conv_wino2_kernel<MT, NT, 0>, 512, lds);
+  const int G = (p.NTtot + NT - 1) / NT;
+  int gx = res & ~7;
+  if (gx < 8) gx = 8;
+  while (gx > 8 && gx - 8 >= p.ntiles * G) gx -= 8;
+  if (p.in_shift) hipLaunchKernelGGL((yl_conv_wino2_kernel<MT, NT, 1>), dim3(gx), dim3(512), lds, st, p);
+  else hipLaunchKernelGGL((yl_conv_wino2_kernel<MT, NT, 0>), dim3(gx), dim3(512), lds, st, p);
+  return hipGetLastError();
+}
+
 // dense 3x3 stride-1 pad-1 layers that carry a Winograd image (yl_api.hip builds it for >= 64 channels, plain
 // ReLU-family epilogue; layer_params hands it over only under option "winograd").
 hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st) {
   if (!p.wino || p.k != 3 || p.stride != 1 || p.dw_k > 0 || p.up || p.dec_boxes || p.C1 > 0 || (p.N & 3) || p.w3p || p.scale ||
       p.in_shift > 1 || (size_t)p.B * (p.H >> p.in_shift) * (p.W >> p.in_shift) * p.Cin >= ((size_t)1 << 31))
     return hipErrorNotSupported;
+  // second form (positions across the waves): K loops long enough to amortise the accumulator exchange, grids that fill
+  // the 4 x 4-tile m-tiles; "dev_select" bit 11 keeps the first form (bitwise A/B), bits 12-13 pick a shape (A/B runs)
+  if (!(p.dev & YL_DEV_WINO_V1) && p.KB >= 4 && p.NTtot >= 3) {
+    const int TW = (p.OW + 1) >> 1, TH = (p.OH + 1) >> 1;
+    const int MX = (TW + 3) >> 2, MY = (TH + 3) >> 2;
+    const long MTOT = (long)p.B * MX * MY;
+    if ((long)TW * TH * 10 >= (long)MX * MY * 16 * 8) {           // >= 80 % of the m-tiles' Winograd tiles exist
+      const int pad3 = (p.NTtot + 2) / 3 * 3, pad4 = (p.NTtot + 3) / 4 * 4;
+      int nt = pad3 <= pad4 ? 3 : 4;
+      // 4 m-tiles halve the U bytes per MFMA (80 x 80: 1.79 against 1.95 ms) when there are >= 3 items per CU; with 4
+      // n-tiles that shape spills (2 x 4 x 4 accumulator quads + two U register sets)
+      int mt = nt == 3 && (MTOT / 4) * ((p.NTtot + nt - 1) / nt) >= 3 * YL_NUM_CU ? 4 : 2;
+      const unsigned v = YL_DEV_WINO_SHAPE(p.dev);
+      if (v == 1) { mt = 4; nt = 4; } else if (v == 2) { mt = 2; nt = 7; } else if (v == 3) { mt = 2; }
+      if (mt == 4 && nt == 3) return wino2_go<4, 3>(p, st, false);
+      if (mt == 4 && nt == 4) return wino2_go<4, 4>(p, st, false);
+      if (mt == 2 && nt == 3) return wino2_go<2, 3>(p, st, false);
+      if (mt == 2 && nt == 4) return wino2_go<2, 4>(p, st, false);
+      if (mt == 2 && nt == 7) return wino2_go<2, 7>(p, st, false);
+    }
+  }
   return wino_go(p, st, false);
+}
+
+static hipError_t yl_wino2_init() {
+  YlConvP q = {};
+  hipError_t e = wino2_go<4, 3>(q, nullptr, true);
+  if (e == hipSuccess) e = wino2_go<4, 4>(q, nullptr, true);
+  if (e == hipSuccess) e = wino2_go<2, 3>(q, nullptr, true);
+  if (e == hipSuccess) e = wino2_go<2, 4>(q, nullptr, true);
+  if (e == hipSuccess) e = wino2_go<2, 7>(q, nullptr, true);
+  return e;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2365,6 +2708,7 @@ hipError_t yl_convc_init() {
   if (e == hipSuccess) e = dwt_any(m, 0, nullptr, false, false, true);
   if (e == hipSuccess) e = dwt_splitk(m, nullptr, true);
   if (e == hipSuccess) e = wino_go(q, nullptr, true);
+  if (e == hipSuccess) e = yl_wino2_init();
   if (e == hipSuccess) e = dwk_go<7, 1, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<7, 3, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<8, 1, 4>(q, nullptr, true);

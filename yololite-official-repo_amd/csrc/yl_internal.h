@@ -138,6 +138,8 @@ struct YlConvP {
 #define YL_DEV_KXK_NW(d) (((d) >> 7) & 3u) // yl_conv_kxk_kernel waves per workgroup: 0 auto, 1 four, 2 eight, 3 off (4-n-tile layers)
 #define YL_DEV_KXK_MT2 (1u << 9)       // ... two m-tiles per wave in the 4-wave form
 #define YL_DEV_DWT_NOSPLIT (1u << 10)  // depthwise -> 1x1 on <= 20x20 grids: one wave per tile instead of the split-K form
+#define YL_DEV_WINO_V1 (1u << 11)      // Winograd: yl_conv_wino_kernel (all positions per wave) instead of yl_conv_wino2_kernel
+#define YL_DEV_WINO_SHAPE(d) (((d) >> 12) & 3u) // yl_conv_wino2_kernel item shape: 0 auto, 1 (4,4), 2 (2,7), 3 two m-tiles
 
 // squeeze-excite gate (yl_se.hip): fixed-order two-pass spatial mean + the two FCs + sigmoid
 struct YlSeP {
