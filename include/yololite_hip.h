@@ -274,7 +274,10 @@ yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
  * shape it supports (with "tile_m" 7), 4: no wave-autonomous depthwise kernel, 5-6: streamed depthwise->1x1 kernel
  * variant (0 default, 1 one n-group per item, 2 off), 7-8: streamed dense 3x3 waves per workgroup (0 auto, 1 four,
  * 2 eight, 3 off for 4-n-tile layers), 9: two m-tiles per wave in its 4-wave form, 10: depthwise -> 1x1 layers on
- * grids of <= 20 x 20 pixels with one wave per tile instead of the split-K form).                                  */
+ * grids of <= 20 x 20 pixels with one wave per tile instead of the split-K form, 11: Winograd layers through the first
+ * kernel form (every transform position in one wave), 12-13: item shape of the position-split Winograd kernel (0 auto),
+ * 14: depthwise 3x3 -> wide 1x1 layers with the taps from L1/L2 instead of the window-in-LDS kernel, 15: that kernel on
+ * every grid it supports).                                                                                         */
 yl_status yl_get_option(const yl_ctx* ctx, const char* name, int32_t* value);
 /* Host-side query, no device needed: would yl_create accept a fused inverted-residual block (yl_layer with c2 > 0:
  * 1x1 expand c_in -> c_mid, depthwise dw_k x dw_k stride dw_stride, 1x1 project c_mid -> c_out) producing an

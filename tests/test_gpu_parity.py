@@ -445,6 +445,30 @@ def test_winograd_position_split_kernel_is_bitwise_the_first_form(name, B, S, se
     ctx.set_option("dev_select", 0)
 
 
+@pytest.mark.parametrize("name,B,S", [("edge_m", 2, 320), ("edge_m", 3, 224), ("yololite_m", 2, 256), ("edge_l", 1, 320),
+                                      ("edge_m", 12, 640)])
+def test_window_in_lds_depthwise_kernel_is_bitwise_the_tap_load_kernel(name, B, S):
+    """yl_conv_dwl_kernel (round 5: depthwise 3x3 -> wide 1x1 with the 10 x 10-pixel input windows of two 8 x 8-pixel output
+    windows in LDS, 1x1 weights triple-buffered, one barrier per k-block) runs the fmaf chain, k order and epilogues of
+    yl_conv_dwk_kernel (nine taps per lane from L1/L2) -> identical bits.  "dev_select" bit 15: on every grid (224: 28 x 28 /
+    14 x 14 / 7 x 7 levels = partial windows; few items), bit 14: off.  edge_m B = 12 at 640: the default selection takes it
+    on the 80 x 80 level (>= 4 windows per CU)."""
+    meta = zoo_meta(name, 80, S)
+    sd = synth_state_dict(meta, seed=8)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    x = _x(B, S, seed=17).to(DEV)
+    ctx.set_option("winograd", 0)
+    ctx.set_option("dev_select", _lib.DEV_DWL_OFF)
+    old = [t.clone() for t in m(x)]
+    ctx.set_option("dev_select", _lib.DEV_DWL_ALL if B < 12 else 0)
+    new = m(x)
+    ctx.set_option("dev_select", 0)
+    ctx.set_option("winograd", 1)
+    for u, v in zip(old, new):
+        assert torch.equal(u, v), float((u - v).abs().max())
+
+
 def test_tiled_depthwise_kernel_is_bitwise_the_per_output_kernel():
     """yl_dw_tile_kernel (register-tiled stand-alone depthwise, yololite_m's backbone) accumulates every output's taps
     in the (dy, dx) order of yl_dw_kernel -> identical bits.  The switch is a per-context developer option

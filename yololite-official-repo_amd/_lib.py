@@ -53,6 +53,8 @@ NMS_TORCHVISION, NMS_GREEDY = 0, 1
 DEV_DW_TILE_OFF, DEV_PWS_OFF, DEV_S2C_OFF, DEV_DWC_ALL, DEV_DWT_OFF = 1, 2, 4, 8, 16
 DEV_DWT_NOSPLIT = 1 << 10
 DEV_WINO_V1 = 1 << 11            # Winograd: yl_conv_wino_kernel (every position in one wave) instead of yl_conv_wino2_kernel
+DEV_DWL_OFF = 1 << 14             # depthwise 3x3 -> wide 1x1: yl_conv_dwk_kernel instead of yl_conv_dwl_kernel (window in LDS)
+DEV_DWL_ALL = 1 << 15             # ... yl_conv_dwl_kernel on every grid (partial windows, few items: the bitwise test)
 DEV_WINO_SHAPE_SHIFT = 12         # yl_conv_wino2_kernel item shape (2 bits): 0 auto, 1 (4,4), 2 (2,7), 3 two m-tiles
 
 _fp = C.POINTER(C.c_float)

@@ -1596,7 +1596,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }
   if (!strcmp(name, "split_k")) { c->opt_split_k = value ? 1 : 0; drop_graph(c); return YL_OK; }
-  if (!strcmp(name, "dev_select")) { c->opt_dev = value & 0x3fff; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "dev_select")) { c->opt_dev = value & 0xffff; drop_graph(c); return YL_OK; }
   return fail(c, YL_ERR_INVALID, std::string("unknown option ") + name);
 }
 

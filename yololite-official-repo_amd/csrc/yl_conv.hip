@@ -1333,6 +1333,15 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
   // depthwise k x k -> 1x1 with >= 192 depthwise channels and 7..22 n-tiles (EfficientNet-Lite conv_dw -> conv_pwl): streamed 1x1
   // AND tap weights, halo patch through LDS (yl_convc.hip, round 5).  Not behind tile_hint: these layers carry more tap
   // weights than the 32 KB image of the other depthwise-prologue kernels, nothing else can run them
+  // depthwise 3x3 -> wide 1x1 with 16 / 21 n-tiles (the 244- / 328-channel neck and head blocks): the input window through
+  // LDS where the grid fills 8 x 8-pixel windows (yl_conv_dwl_kernel), else streamed weights with the taps from L1/L2
+  // (yl_conv_dwk_kernel).  In front of yl_conv_dws_kernel, which also runs these shapes but slower (244 -> 244 @80x80 B = 32:
+  // 0.45 ms against 0.36 for yl_conv_dwk_kernel -- it took them over unnoticed when it was written for the 528 - 1248-channel
+  // 5x5 layers)
+  if (n == 1 && p.dw_k == 3 && p.dw_stride == 1 && tile_hint != 6 && tile_hint != 3) {
+    const hipError_t ed = yl_launch_conv_dwk(p, st);
+    if (ed != hipErrorNotSupported) return ed;
+  }
   if (n == 1 && p.dw_k > 0) {
     const hipError_t es = yl_launch_conv_dws(p, st);
     if (es != hipErrorNotSupported) return es;

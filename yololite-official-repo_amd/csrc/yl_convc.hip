@@ -35,6 +35,7 @@
 #define yl_conv_dwt_kernel YL_LP_NAME(yl_conv_dwt_kernel)
 #define yl_launch_conv_dwt YL_LP_NAME(yl_launch_conv_dwt)
 #define yl_conv_dwk_kernel YL_LP_NAME(yl_conv_dwk_kernel)
+#define yl_conv_dwl_kernel YL_LP_NAME(yl_conv_dwl_kernel)
 #define yl_launch_conv_dwk YL_LP_NAME(yl_launch_conv_dwk)
 #define yl_conv_dws_kernel YL_LP_NAME(yl_conv_dws_kernel)
 #define yl_launch_conv_dws YL_LP_NAME(yl_launch_conv_dws)
@@ -1805,6 +1806,9 @@ static hipError_t dwk_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
   return hipGetLastError();
 }
 
+template <int NTT>
+static hipError_t dwl_go(const YlConvP& p0, hipStream_t st, bool attr_only);
+
 // depthwise 3x3 (stride 1 / 2) -> 1x1 with K >= 192, N % 4 == 0 and an n-tile count that is a multiple of 7 or 8,
 // single problem.  hipErrorNotSupported otherwise (yl_conv_mfma_kernel's streamed mode then runs the layer).
 hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
@@ -1813,11 +1817,281 @@ hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
   // 0 = default: a wave holds every n-group
   const int sel = YL_DEV_DWK(p.dev) == 2 ? 0 : (YL_DEV_DWK(p.dev) == 1 ? 1 : 2);
   if (sel == 0) return hipErrorNotSupported;
+  // window-in-LDS form (yl_conv_dwl_kernel): stride 1, pad 1, grids that fill the 8 x 8-pixel windows to >= 80 % (20 x 20: 69 %, slower than the tap-load kernel), >= 1.5 items
+  // per CU (40 x 40 at B = 32: 0.116 -> 0.098 ms); "dev_select" bit 14 = off, bit 15 = on every grid (the bitwise test)
+  if (!(p.dev & YL_DEV_DWL_OFF) && p.dw_stride == 1 && p.dw_pad_t == 1 && p.dw_pad_l == 1 && !p.scale &&
+      (size_t)p.B * p.H * p.W * p.Cin < ((size_t)1 << 31)) {
+    const long wins = (long)p.B * ((p.OW + 7) >> 3) * ((p.OH + 7) >> 3);
+    if (((long)p.B * p.OH * p.OW * 10 >= wins * 64 * 8 && wins >= 3 * YL_NUM_CU) || (p.dev & YL_DEV_DWL_ALL)) {
+      if (p.NTtot == 16) return dwl_go<16>(p, st, false);
+      if (p.NTtot == 21) return dwl_go<21>(p, st, false);
+    }
+  }
   if (p.NTtot == 21) return sel == 2 ? dwk_go<7, 3, 4>(p, st, false) : dwk_go<7, 1, 4>(p, st, false);
   if (p.NTtot == 16) return sel == 2 ? dwk_go<8, 2, 4>(p, st, false) : dwk_go<8, 1, 4>(p, st, false);
   if (p.NTtot % 7 == 0) return dwk_go<7, 1, 4>(p, st, false);
   if (p.NTtot % 8 == 0) return dwk_go<8, 1, 4>(p, st, false);
   return hipErrorNotSupported;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise 3x3 (stride 1, pad 1) -> wide 1x1 with the INPUT WINDOW IN LDS (round 5): the layers of yl_conv_dwk_kernel
+// on grids that fill 8 x 8-pixel windows.  yl_conv_dwk_kernel fetches nine float4 taps per lane and k-block straight
+// from L1/L2 with the MFMA lane layout (lane = channel group * 16 + pixel): the four lanes of a quad sit on four
+// different pixels, i.e. four cache lines, so a tap load keeps the texture addresser busy for 64 cycles and the nine of
+// them for more cycles than the 64 MFMAs they feed (244 -> 244 @80x80: 55 TFLOP/s).  Here, with the machinery of
+// yl_conv_wino2_kernel:
+//   window   a workgroup item is TWO 8 x 8-pixel output windows (8 waves x one 4 x 4-pixel MFMA m-tile); their 10 x 10-pixel
+//            input windows (64 B per pixel and k-block) land in LDS by asynchronous LDS-DMA copies whose quads read the 64
+//            contiguous bytes of ONE pixel (2 copy instructions per wave and k-block; every input pixel once per item instead
+//            of once per tap that touches it), double-buffered, requested a k-block ahead;
+//   B        the lane's nine taps by ds_read_b128 from the window (slot = 4 P + (kq ^ 2 ((P >> 2) & 1)), P = y * 12 + x: a
+//            lane group holds pixel rows {0,3} with one channel group and {1,2} with its neighbour -- conflict-free, see
+//            yl_conv_wino2_kernel), tap weights + bias from LDS, the fmaf chain and activation of yl_conv_dwk_kernel;
+//   A        the 1x1 weights of a k-block (all n-tiles: a wave accumulates every output channel of its 16 pixels, as in
+//            yl_conv_dwk_kernel's GW = all form) shared by the 8 waves through LDS, TRIPLE-buffered;
+//   barrier  ONE per k-block, in the middle of its MFMAs: behind it window(kb + 1) and weights(kb + 1) are complete, the
+//            wave requests window(kb + 2) / weights(kb + 2) into the buffers of blocks kb / kb - 1, builds B(kb + 1) and goes
+//            on with the second half of block kb's MFMAs -- the MFMA stream runs on across k-blocks.
+// Same tap order, k order and epilogues as yl_conv_dwk_kernel: BIT-IDENTICAL to it ("dev_select" bit 14 keeps the old kernel).
+template <int NTT>
+__global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
+  constexpr int RP = 12, RM = 512;
+  constexpr int NTP = (NTT + 7) & ~7;                            // weight pieces per buffer (8 waves x NTP / 8 copies)
+  // MFMA groups of <= 4 n-tiles, an even number of them (their A fragments alternate between two register sets across
+  // k-blocks): 16 = 4 x 4, 21 = 3 x 4 + 3 x 3
+  constexpr int NCH = NTT == 16 ? 4 : 6;
+  static_assert(NTT == 16 || NTT == 21, "n-tile groups");
+  auto c0of = [](int c) { return NTT == 16 ? 4 * c : (c <= 3 ? 4 * c : 12 + 3 * (c - 3)); };
+  extern __shared__ __attribute__((aligned(16))) float yl_clds[];
+  f32x4* const Wl = reinterpret_cast<f32x4*>(yl_clds);           // [3][NTP][64]
+  f32x4* const Rl = Wl + 3 * NTP * 64;                           // [2 buffers][2 windows][RM]
+  float* const dwl = reinterpret_cast<float*>(Rl + 2 * 2 * RM);  // [9][Cin] taps, [Cin] bias
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  const int KB = p.KB, NTtot = p.NTtot, Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW;
+  const int WX = (OW + 7) >> 3, WY = (OH + 7) >> 3;
+  const int wimg = WX * WY;
+  const long WTOT = (long)p.B * wimg;                            // windows
+  const float* const xin = p.x;
+  const long zdelta = p.zeros - p.x;
+  const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wp);
+  const long wgmax = (long)KB * NTtot - 1;                       // last weight piece
+  const int bx = blockIdx.x, gx = gridDim.x;                     // gx % 8 == 0
+  const int per = gx >> 3, slot = bx >> 3;
+  const int tpx = (p.ntiles + 7) >> 3;                           // items per XCD band
+  const int band0 = (bx & 7) * tpx;
+  const int band1 = (band0 + tpx) < p.ntiles ? (band0 + tpx) : p.ntiles;
+  // copy role of the lane: slot rs = wave * 64 + lane of both windows
+  const int rs = wave * 64 + lane;
+  const int rP = rs >> 2, rkq = (rs & 3) ^ (((rP >> 2) & 1) << 1);
+  const int ry = rP / RP, rx = rP - ry * RP;
+  const bool rpix = ry < 10 && rx < 10;
+  // compute role: window wsel, 4 x 4-pixel block (qy, qx) of it, pixel (sy, sx) of the block
+  const int wsel = wave >> 2, qy = (wave >> 1) & 1, qx = wave & 1;
+  const int sy = pl >> 2, sx = pl & 3;
+  int ts[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int P = (4 * qy + sy + tap / 3) * RP + 4 * qx + sx + tap % 3;
+    ts[tap] = wsel * RM + 4 * P + (kq ^ (((P >> 2) & 1) << 1));
+  }
+  {
+    const int nw = 9 * Cin;
+    yl_glds_floats(p.dw_w, dwl, nw, tid, 512);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cin, tid, 512);
+    else for (int i = tid; i < Cin; i += 512) dwl[nw + i] = 0.0f;
+  }
+  const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE;
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const int dw_act = p.dw_act;
+
+  int soff[2];
+  auto issue_win = [&](int kb, int buf) {
+    const bool tail = kb * 16 + 4 * rkq >= Cin;
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2)
+      yl_glds16((soff[w2] >= 0 && !tail) ? xin + soff[w2] + kb * 16 : xin + zdelta, Rl + (buf * 2 + w2) * RM + wave * 64);
+  };
+  auto issue_wts = [&](int kb, int wb) {
+#pragma unroll
+    for (int j = 0; j < NTP / 8; ++j) {
+      const int i = wave + 8 * j;                                // (pieces NTT..NTP-1: pad, any valid source)
+      long src = (long)kb * NTtot + (i < NTT ? i : 0);
+      src = src < wgmax ? src : wgmax;
+      yl_glds16(wg + src * 64 + lane, Wl + ((size_t)wb * NTP + i) * 64);
+    }
+  };
+  auto make_b = [&](int kb, int buf) {
+    const int cc = kb * 16 + 4 * kq;
+    const int cs = cc < Cin ? cc : Cin - 4;
+    const float* tapw = dwl + cs;
+    const f32x4* const wb = Rl + buf * 2 * RM;
+    f32x4 xq = yl_ld4(tapw + 9 * Cin);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const f32x4 x = wb[ts[tap]];
+      const f32x4 w = yl_ld4(tapw + tap * Cin);
+      xq.x = fmaf(x.x, w.x, xq.x); xq.y = fmaf(x.y, w.y, xq.y);
+      xq.z = fmaf(x.z, w.z, xq.z); xq.w = fmaf(x.w, w.w, xq.w);
+    }
+    return yl_actc(xq, dw_act, dlo, dhi);
+  };
+
+  for (int item = band0 + slot; item < band1; item += per) {
+    // the two windows of the item, the lane's output pixel, the lane's copy sources
+    YlPix px[1];
+    {
+      const long wi = (long)item * 2 + wsel;
+      const bool wv = wi < WTOT;
+      const long wc = wv ? wi : WTOT - 1;
+      const int b = (int)(wc / wimg);
+      const int r = (int)(wc - (long)b * wimg);
+      const int wy = r / WX, wx = r - wy * WX;
+      int oy = 8 * wy + 4 * qy + sy, ox = 8 * wx + 4 * qx + sx;
+      px[0].valid = wv && oy < OH && ox < OW;
+      if (oy >= OH) oy = OH - 1;
+      if (ox >= OW) ox = OW - 1;
+      px[0].b = b; px[0].oy = oy; px[0].ox = ox;
+      px[0].lin = ((size_t)b * OH + oy) * OW + ox;
+    }
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+      const long wi = (long)item * 2 + w2;
+      const int b = (int)(wi / wimg);
+      const int r = (int)(wi - (long)b * wimg);
+      const int wy = r / WX, wx = r - wy * WX;
+      const int gy = 8 * wy - 1 + ry, gxx = 8 * wx - 1 + rx;
+      const bool in = rpix && wi < WTOT && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+      soff[w2] = in ? ((b * H + gy) * W + gxx) * Cin + 4 * rkq : -1;
+    }
+    f32x4 acc[1][NTT];
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pre_add) {
+      const size_t obase = px[0].lin * p.N;
+      size_t up_off = 0;
+      if (p.up) {
+        const int uy = (px[0].oy * p.UH) / p.OH, ux = (px[0].ox * p.UW) / p.OW;
+        up_off = (((size_t)px[0].b * p.UH + uy) * p.UW + ux) * p.N;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) {
+        const int n = nt * 16 + 4 * kq;
+        if (n < p.N) {
+          if (p.res) acc[0][nt] = yl_ld4(p.res + obase + n);
+          if (p.up) acc[0][nt] += yl_ld4(p.up + up_off + n);
+        }
+      }
+    }
+    __syncthreads();                                              // the previous item's last weight reads are done
+    issue_win(0, 0); issue_wts(0, 0);
+    issue_win(1, 1); issue_wts(1, 1);                             // (KB >= 12: the launcher)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+    __syncthreads();
+    f32x4 xq[1];
+    xq[0] = make_b(0, 0);
+    int wb = 0;
+    f32x4 wq[2][4];                                               // A fragments of the current / the next MFMA group
+    auto read_a = [&](int wbuf, int c, f32x4 (&dst)[4]) {
+      const f32x4* const wl = Wl + (size_t)wbuf * NTP * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (c0of(c) + i < c0of(c + 1)) dst[i] = wl[(c0of(c) + i) * 64];
+    };
+    read_a(0, 0, wq[0]);
+    // One k-block.  Top: the barrier behind which window(kb + 1) / weights(kb + 1) are complete (requested a k-block ago)
+    // and nobody reads window(kb) / weights(kb - 1) any more -- their buffers take the requests of block kb + 2.  Then the
+    // MFMA groups; in front of group c the wave issues the LDS reads of what it needs one group later -- the A fragments of
+    // group c + 1 (of block kb + 1's group 0 at the end: complete since this block's barrier) and three taps + tap weights
+    // of B(kb + 1) -- and behind the group's MFMAs their arithmetic: no LDS round trip is waited for, the tap fma chain sits
+    // between MFMA groups (a first version built B(kb + 1) in one piece between two halves of the block's MFMAs: both waves
+    // of a SIMD waited there for 19 LDS reads with nothing to issue).  MODE 0 any block, 1 the second-to-last (no
+    // requests), 2 the last (no next B): branch-free bodies.
+    auto kblock = [&](int kb, auto mode) {
+      constexpr int MODE = decltype(mode)::value;
+      const int wb1 = wb == 2 ? 0 : wb + 1;
+      // the wave's own copies first: the compiler's wait-count pass does not carry the LDS-DMA requests of the previous
+      // iteration across the loop's back edge (the barrier here came out with lgkmcnt(0) only, and two runs of edge_m at
+      // B = 32 differed in a few bits)
+      __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+      __syncthreads();
+      if (MODE == 0) {
+        issue_win(kb + 2, kb & 1);
+        issue_wts(kb + 2, wb >= 1 ? wb - 1 : 2);                  // (wb + 2) % 3
+      }
+      const int cc = (kb + 1) * 16 + 4 * kq;
+      const int cs = cc < Cin ? cc : Cin - 4;
+      const float* const tapw = dwl + cs;
+      const f32x4* const win = Rl + ((kb + 1) & 1) * 2 * RM;
+      f32x4 xn = xq[0];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        f32x4 tx[3], tw[3];
+        if (c + 1 < NCH) read_a(wb, c + 1, wq[(c + 1) & 1]);
+        else if (MODE < 2) read_a(wb1, 0, wq[0]);
+        if (MODE < 2 && c < 3) {
+          if (c == 0) xn = yl_ld4(tapw + 9 * Cin);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) { tx[t] = win[ts[3 * c + t]]; tw[t] = yl_ld4(tapw + (3 * c + t) * Cin); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#if YL_BF16
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (c0of(c) + i < c0of(c + 1)) {
+            const f32x4 w1[1] = {wq[c & 1][i]};
+            yl_mma_step<1, 1>(w1, xq, *reinterpret_cast<f32x4 (*)[1][1]>(&acc[0][c0of(c) + i]));
+          }
+#else
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (c0of(c) + i < c0of(c + 1))
+              acc[0][c0of(c) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c & 1][i][st], xq[0][st], acc[0][c0of(c) + i], 0, 0, 0);
+#endif
+        if (MODE < 2 && c < 3) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            xn.x = fmaf(tx[t].x, tw[t].x, xn.x); xn.y = fmaf(tx[t].y, tw[t].y, xn.y);
+            xn.z = fmaf(tx[t].z, tw[t].z, xn.z); xn.w = fmaf(tx[t].w, tw[t].w, xn.w);
+          }
+          if (c == 2) xn = yl_actc(xn, dw_act, dlo, dhi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      xq[0] = xn;
+      wb = wb1;
+    };
+    for (int kb = 0; kb + 2 < KB; ++kb) kblock(kb, std::integral_constant<int, 0>{});
+    kblock(KB - 2, std::integral_constant<int, 1>{});
+    kblock(KB - 1, std::integral_constant<int, 2>{});
+    if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NTT, 1>(p, acc, px, 0, kq);
+    else yl_epi_fast<NTT, 1>(p, acc, px, 0, kq, lo, hi, true);
+  }
+}
+
+template <int NTT>
+static hipError_t dwl_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
+  constexpr int NTP = (NTT + 7) & ~7;
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_conv_dwl_kernel<NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  YlConvP p = p0;
+  const long WTOT = (long)p.B * ((p.OW + 7) >> 3) * ((p.OH + 7) >> 3);
+  p.ntiles = (int)((WTOT + 1) / 2);
+  const size_t lds = ((size_t)3 * NTP * 64 + 4 * 512) * 16 + (((size_t)10 * p.Cin + 3) & ~(size_t)3) * 4;
+  if (lds > 128 * 1024) return hipErrorNotSupported;
+  const int res = yl_resident_blocks_n(yl_conv_dwl_kernel<NTT>, 512, lds);
+  int gx = res & ~7;
+  if (gx < 8) gx = 8;
+  while (gx > 8 && gx - 8 >= p.ntiles) gx -= 8;
+  hipLaunchKernelGGL((yl_conv_dwl_kernel<NTT>), dim3(gx), dim3(512), lds, st, p);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2484,6 +2758,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
     // kb + 1 are requested into a second register set under the first two m-tiles and renamed at the end -- requested
     // behind the last use of a0 / a1 they had no time to arrive.
     f32x4 x[2][3], y[2][3];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
     __syncthreads();                                              // window(0) landed (requested under the previous epilogue)
     issue_raw(1, 1);
     load_win(0, 0, x[0], y[0]);
@@ -2500,7 +2775,8 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
         if (mt == MT - 1 && MODE < 2) {
           __builtin_amdgcn_sched_barrier(0);
           WINO_STAMP(kb * 7 + 4);
-          __syncthreads();
+          __builtin_amdgcn_s_waitcnt(0x0070);                     // vmcnt(0) lgkmcnt(0): the wave's own window copies and reads (not left to the
+          __syncthreads();                                        // compiler: LDS-DMA requests of the previous iteration are not carried over the back edge)
           WINO_STAMP(kb * 7 + 5);
           if (MODE == 0) issue_raw(kb + 2, buf);
           load_win(buf ^ 1, 0, x[0], y[0]);
@@ -2713,6 +2989,8 @@ hipError_t yl_convc_init() {
   if (e == hipSuccess) e = dwk_go<7, 3, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<8, 1, 4>(q, nullptr, true);
   if (e == hipSuccess) e = dwk_go<8, 2, 4>(q, nullptr, true);
+  if (e == hipSuccess) e = dwl_go<16>(q, nullptr, true);
+  if (e == hipSuccess) e = dwl_go<21>(q, nullptr, true);
   if (e == hipSuccess) e = yl_dws_init();
   if (e != hipSuccess) return e;
   return dwc_any(m, 0, 0, 0, 0, 0, nullptr, true, nullptr);
