@@ -2055,12 +2055,10 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
             if (c0of(c) + i < c0of(c + 1))
               acc[0][c0of(c) + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c & 1][i][st], xq[0][st], acc[0][c0of(c) + i], 0, 0, 0);
 #endif
-        if (MODE < 2 && c < 3) {
+        __builtin_amdgcn_sched_barrier(0);                        // (else the fma chain moves up to the group's first MFMA and waits there
+        if (MODE < 2 && c < 3) {                                  //  for the reads issued a moment before)
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            xn.x = fmaf(tx[t].x, tw[t].x, xn.x); xn.y = fmaf(tx[t].y, tw[t].y, xn.y);
-            xn.z = fmaf(tx[t].z, tw[t].z, xn.z); xn.w = fmaf(tx[t].w, tw[t].w, xn.w);
-          }
+          for (int t = 0; t < 3; ++t) xn = __builtin_elementwise_fma(tx[t], tw[t], xn);   // (two v_pk_fma_f32: the same fma per component)
           if (c == 2) xn = yl_actc(xn, dw_act, dlo, dhi);
         }
         __builtin_amdgcn_sched_barrier(0);
