@@ -333,10 +333,11 @@ def wino_layers(prog, mode):
     return {i for i in el if hw(i) >= top}
 
 
-def kernel_family(L, winograd=False):
+def kernel_family(L, winograd=False, out_hw=None, batch=1):
     """Kernel the dispatcher (yl_launch_conv_multi, yl_conv.hip / yl_convc.hip) picks for a fused layer of the program:
     a label for the roofline object, the rocprofv3 summaries under profiles/ carry the exact instantiation.
-    winograd: this layer runs as Winograd (see wino_layers)."""
+    winograd: this layer runs as Winograd (see wino_layers); out_hw / batch: output grid and images per launch (the
+    round-5 kernels with 8 x 8-pixel windows take a layer only where the grid fills them, yl_convc.hip)."""
     if L.op == 3:
         return "yl_stemblock_kernel"
     if L.op == 4:
@@ -344,7 +345,11 @@ def kernel_family(L, winograd=False):
     if L.op != 1:
         return "yl_stem_mfma_kernel" if L.op == 0 else "yl_dw_tile_kernel"
     nt, kb = -(-L.cout // 16), -(-L.cin // 16)
+    oh, ow = out_hw if out_hw else (0, 0)
     if winograd and wino_eligible(L):
+        th, tw = (oh + 1) // 2, (ow + 1) // 2
+        if kb >= 4 and nt >= 3 and th * tw * 10 >= -(-th // 4) * -(-tw // 4) * 16 * 8:
+            return "yl_conv_wino2_kernel"
         return "yl_conv_wino_kernel"
     if L.dw_k == 0:
         if L.k == 1:
@@ -354,6 +359,9 @@ def kernel_family(L, winograd=False):
     if nt <= 6:
         return "yl_conv_dwt_kernel"
     if L.dw_k == 3 and kb >= 12 and nt > 8 and (nt % 7 == 0 or nt % 8 == 0):
+        wins = batch * -(-oh // 8) * -(-ow // 8)
+        if L.dw_stride == 1 and L.dw_pad_t == 1 and nt in (16, 21) and batch * oh * ow * 10 >= wins * 64 * 8 and wins >= 768:
+            return "yl_conv_dwl_kernel"
         return "yl_conv_dwk_kernel"
     return "yl_conv_dwh_kernel"
 
@@ -636,8 +644,8 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
         bytes per launch / median eager launch duration against the roof its arithmetic intensity puts it under"""
         L = prog.layers[k]
         flops = 2.0 * L.macs * B
-        fam = kernel_family(L, k in wl_set)
-        wino = "yl_conv_wino_kernel" in fam
+        fam = kernel_family(L, k in wl_set, tuple(prog.slots[L.out_slot][:2]), B)
+        wino = "yl_conv_wino" in fam
         flops_direct = flops
         if wino:                  # Winograd F(2x2,3x3) executes 16 multiplications where the direct conv has 36
             flops = flops * 16.0 / 36.0
