@@ -348,7 +348,7 @@ def kernel_family(L, winograd=False, out_hw=None, batch=1):
     oh, ow = out_hw if out_hw else (0, 0)
     if winograd and wino_eligible(L):
         th, tw = (oh + 1) // 2, (ow + 1) // 2
-        if kb >= 4 and nt >= 3 and th * tw * 10 >= -(-th // 4) * -(-tw // 4) * 16 * 8:
+        if kb >= 4 and nt >= 3 and th * tw * 100 >= -(-th // 4) * -(-tw // 4) * 16 * 65:
             return "yl_conv_wino2_kernel"
         return "yl_conv_wino_kernel"
     if L.dw_k == 0:

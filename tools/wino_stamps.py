@@ -12,7 +12,8 @@ from yololite_amd.program import synth_state_dict, zoo_meta
 from bench import synth_images
 dv = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 lib = _lib.load()
-meta = zoo_meta("yololite_m", 80, 640)
+MODEL = os.environ.get("STAMP_MODEL", "yololite_m")
+meta = zoo_meta(MODEL, 80, 640)
 m = ya.build_model_from_meta(meta); m.load_state_dict(synth_state_dict(meta, seed=1)); m.to("cuda:0")
 ctx = m._ctx_for(640)
 ctx.set_option("streams", 1); ctx.set_option("dev_select", dv)
@@ -25,7 +26,8 @@ buf = (C.c_ulonglong * n)()
 lib.yl_debug_wino_stamps.argtypes = [C.c_void_p]
 assert lib.yl_debug_wino_stamps(buf) == 0
 t = np.array(buf[:], dtype=np.float64).reshape(256, 8, 64)
-names = ["m-tile 0 (B + 24 MFMAs + U request)", "m-tile 1", "m-tile 2", "m-tile 3: reads, B -> barrier", "barrier", "window request + next reads", "m-tile 3 MFMAs -> next block"]
+names = (["m-tile 0 (B + 24 MFMAs + U request)", "m-tile 1", "m-tile 2", "m-tile 3: reads, B -> barrier", "barrier", "window request + next reads", "m-tile 3 MFMAs -> next block"]
+         if MODEL.startswith("yololite") else ["wait + barrier", "requests", "group 0 (+ taps 0-2)", "group 1 (+ taps 3-5)", "group 2 (+ taps 6-8, act)", "group 3", "-> next block"])
 NS = 7
 for blk in (0, 100):
     for w in range(8):

@@ -91,7 +91,7 @@ extern "C" int yl_debug_dwc_stamps(void* host) {
 #else
 #define DWC_STAMP(i) do {} while (0)
 #endif
-// the same aid for yl_conv_wino2_kernel (-DYL_WINO_STAMP=<Cin>; tools/wino_stamps.py): 7 stamps per k-block of the second item
+// the same aid for yl_conv_wino2_kernel / yl_conv_dwl_kernel (-DYL_WINO_STAMP=<Cin>; tools/wino_stamps.py): 7 stamps per k-block of the second item
 #ifdef YL_WINO_STAMP
 __device__ unsigned long long yl_wino_stamps[256 * 8 * 64];
 #define WINO_STAMP(i)                                                                                            \
@@ -1942,7 +1942,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
     return yl_actc(xq, dw_act, dlo, dhi);
   };
 
-  for (int item = band0 + slot; item < band1; item += per) {
+  for (int item = band0 + slot, wi = 0; item < band1; item += per, ++wi) {   // (wi: the stamp builds' item counter)
     // the two windows of the item, the lane's output pixel, the lane's copy sources
     YlPix px[1];
     {
@@ -2018,12 +2018,15 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
       // the wave's own copies first: the compiler's wait-count pass does not carry the LDS-DMA requests of the previous
       // iteration across the loop's back edge (the barrier here came out with lgkmcnt(0) only, and two runs of edge_m at
       // B = 32 differed in a few bits)
+      WINO_STAMP(kb * 7 + 0);
       __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
       __syncthreads();
+      WINO_STAMP(kb * 7 + 1);
       if (MODE == 0) {
         issue_win(kb + 2, kb & 1);
         issue_wts(kb + 2, wb >= 1 ? wb - 1 : 2);                  // (wb + 2) % 3
       }
+      WINO_STAMP(kb * 7 + 2);
       const int cc = (kb + 1) * 16 + 4 * kq;
       const int cs = cc < Cin ? cc : Cin - 4;
       const float* const tapw = dwl + cs;
@@ -2062,6 +2065,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
           if (c == 2) xn = yl_actc(xn, dw_act, dlo, dhi);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (c < 4) WINO_STAMP(kb * 7 + 3 + c);
       }
       xq[0] = xn;
       wb = wb1;
@@ -2882,7 +2886,7 @@ hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st) {
     const int TW = (p.OW + 1) >> 1, TH = (p.OH + 1) >> 1;
     const int MX = (TW + 3) >> 2, MY = (TH + 3) >> 2;
     const long MTOT = (long)p.B * MX * MY;
-    if ((long)TW * TH * 10 >= (long)MX * MY * 16 * 8) {           // >= 80 % of the m-tiles' Winograd tiles exist
+    if ((long)TW * TH * 100 >= (long)MX * MY * 16 * 65) {         // >= 65 % of the m-tiles' Winograd tiles exist (20 x 20: 69 %, 0.232 -> 0.205 ms)
       const int pad3 = (p.NTtot + 2) / 3 * 3, pad4 = (p.NTtot + 3) / 4 * 4;
       int nt = pad3 <= pad4 ? 3 : 4;
       // 4 m-tiles halve the U bytes per MFMA (80 x 80: 1.79 against 1.95 ms) when there are >= 3 items per CU; with 4
