@@ -1493,6 +1493,18 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
     f32x4 we[KBI], wn[KBI];
 #pragma unroll
     for (int kbi = 0; kbi < KBI; ++kbi) wn[kbi] = w2g[((size_t)kbi * KB + 0) * 64 + lane];
+    // FPN lateral: the addend of slab kb + 1 (the nearest-upsampled coarser level at the lane's halo pixels) is requested
+    // one slab ahead like the expansion weights -- requested where it is used, every slab began with a wait for a
+    // fragment-shaped load from L2 in front of its first MFMA (it initialises the accumulator)
+    // (one register set: m-tile j's addend of slab kb + 1 is requested right behind the MFMAs that consumed slab kb's)
+    f32x4 un[HMW];
+    auto load_up = [&](int kb, int j) {
+      return yl_ld4((h_in[j] && kb * 16 + 4 * kq < Cmid) ? up + uoff[j] + kb * 16 : p.zeros);
+    };
+    if (up) {
+#pragma unroll
+      for (int j = 0; j < HMW; ++j) un[j] = load_up(0, j);
+    }
     for (int kb = 0; kb < KB; ++kb, ++gs) {
       const int buf = (int)(gs & 1u);
 #pragma unroll
@@ -1507,17 +1519,15 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
 #pragma unroll
       for (int j = 0; j < HMW; ++j) {
         f32x4 e[1][1] = {{{0.f, 0.f, 0.f, 0.f}}};
-        if (up) {       // FPN lateral: the nearest-upsampled coarser level initialises the accumulator (the order of
-                        // the stand-alone lateral conv: (addend + products) + bias)
-          const float* us = up + uoff[j] + kb * 16;
-          e[0][0] = yl_ld4((h_in[j] && kb * 16 + 4 * kq < Cmid) ? us : p.zeros);
-        }
+        if (up) e[0][0] = un[j];   // FPN lateral: the nearest-upsampled coarser level initialises the accumulator (the order
+                                   // of the stand-alone lateral conv: (addend + products) + bias)
 #pragma unroll
         for (int kbi = 0; kbi < KBI; ++kbi) {
           const f32x4 wq1[1] = {we[kbi]};
           const f32x4 xq1[1] = {xh[j][kbi]};
           yl_mma_step<1, 1>(wq1, xq1, e);
         }
+        if (up && kb + 1 < KB) un[j] = load_up(kb + 1, j);
         const f32x4 v = yl_sel4(h_in[j], yl_actc(e[0][0] + eb, act2, elo, ehi));   // zero padding of the EXPANDED tensor
         if (h_ok[j]) *reinterpret_cast<f32x4*>(sb + h_lo[j]) = v;
       }
