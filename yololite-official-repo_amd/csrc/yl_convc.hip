@@ -91,12 +91,16 @@ extern "C" int yl_debug_dwc_stamps(void* host) {
 #else
 #define DWC_STAMP(i) do {} while (0)
 #endif
-// the same aid for yl_conv_wino2_kernel / yl_conv_dwl_kernel (-DYL_WINO_STAMP=<Cin>; tools/wino_stamps.py): 7 stamps per k-block of the second item
+// the same aid for yl_conv_wino2_kernel / yl_conv_dwl_kernel / yl_ir_kernel (-DYL_WINO_STAMP=<Cin> [-DYL_STAMP_OH=<min grid>];
+// tools/wino_stamps.py, tools/ir_stamps.py): stamps per k-block of the workgroup's second item
 #ifdef YL_WINO_STAMP
+#ifndef YL_STAMP_OH
+#define YL_STAMP_OH 80
+#endif
 __device__ unsigned long long yl_wino_stamps[256 * 8 * 64];
 #define WINO_STAMP(i)                                                                                            \
   do {                                                                                                           \
-    if (p.Cin == YL_WINO_STAMP && p.OH >= 80 && lane == 0 && blockIdx.x < 256 && wi == 1 && (i) < 64)              \
+    if (p.Cin == YL_WINO_STAMP && p.OH >= YL_STAMP_OH && lane == 0 && blockIdx.x < 256 && wi == 1 && (i) < 64)     \
       yl_wino_stamps[((size_t)blockIdx.x * 8 + wave) * 64 + (i)] = __builtin_readcyclecounter();                \
   } while (0)
 extern "C" int yl_debug_wino_stamps(void* host) {
@@ -1450,7 +1454,7 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
   if (tile < tend) load_proj(0, 0);
   __syncthreads();
 
-  for (; tile < tend; tile += tstride) {
+  for (int wi = 0; tile < tend; tile += tstride, ++wi) {             // (wi: the stamp builds' tile counter)
     const int b = tile / tiles_img;
     const int trem = tile - b * tiles_img;
     const int tyi = trem / twn, txi = trem - tyi * twn;
@@ -1513,6 +1517,7 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
 #pragma unroll
         for (int kbi = 0; kbi < KBI; ++kbi) wn[kbi] = w2g[((size_t)kbi * KB + kb + 1) * 64 + lane];
       }
+      WINO_STAMP(kb * 5 + 0);
       // ---- E: expansion slab on the wave's halo m-tiles -> LDS
       const f32x4 eb = yl_ld4(b2l + kb * 16 + 4 * kq);
       float* sb = slab + buf * SLAB;
@@ -1531,7 +1536,9 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
         const f32x4 v = yl_sel4(h_in[j], yl_actc(e[0][0] + eb, act2, elo, ehi));   // zero padding of the EXPANDED tensor
         if (h_ok[j]) *reinterpret_cast<f32x4*>(sb + h_lo[j]) = v;
       }
+      WINO_STAMP(kb * 5 + 1);
       __syncthreads();                 // slab `buf` complete; the projection weights of this slab have landed
+      WINO_STAMP(kb * 5 + 2);
       if (kb + 1 < KB) load_proj(kb + 1, buf ^ 1);
       else if (tile + tstride < tend) load_proj(0, buf ^ 1);        // first slab of the workgroup's next tile
       // ---- D: depthwise on the slab -> B fragments
@@ -1557,6 +1564,7 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
       for (int dy = 0; dy < DK; ++dy) tap_row(dy);                   // one tap row at a time bounds the register footprint
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_actc(xq[mt], dw_act, dlo, dhi);
+      WINO_STAMP(kb * 5 + 3);
       // channel tail (c >= Cmid): the packed projection weights of those k slots are zero, no select needed
       // ---- P: projection
       f32x4 wq[NT];
@@ -1564,7 +1572,12 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wq[nt] = wrow[nt * 64];
       yl_mma_step<NT, MT>(wq, xq, acc);
+#ifdef YL_WINO_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      WINO_STAMP(kb * 5 + 4);
     }
+    WINO_STAMP(KB * 5);
     if (!pre_add && (p.res || YL_SMOOTH(p.act))) yl_epi_generic<NT, MT>(p, acc, px, 0, kq);
     else yl_epi_fast<NT, MT>(p, acc, px, 0, kq, lo, hi, true);
   }
