@@ -123,6 +123,30 @@ def test_fused_block_query_is_the_librarys_own_table():
     assert n_dw3 > n_all                                # "dw3": the 5x5 depthwise convs stay separate launches everywhere
 
 
+def test_bench_kernel_labels_follow_the_launchers_selection():
+    """bench.kernel_family names the kernel the dispatcher picks for a layer (the `kernel` string of the roofline object).  The
+    round-5 kernels work on 8 x 8-pixel windows / 4 x 4-tile m-tiles and take a layer only where the grid fills them
+    (yl_launch_conv_wino / yl_launch_conv_dwk, yl_convc.hip): pinned here for yololite_m at the benchmark's shape so that the
+    label cannot drift from the launcher unnoticed (round 5: yl_conv_dws_kernel had taken over layers whose label said
+    yl_conv_dwk_kernel)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    meta = zoo_meta("yololite_m", 80, 640)
+    prog = build_program(meta, synth_state_dict(meta, seed=1))
+    wl = bench.wino_layers(prog, 1)
+    fam = {}
+    for k, L in enumerate(prog.layers):
+        hw = tuple(prog.slots[L.out_slot][:2])
+        fam.setdefault(bench.kernel_family(L, k in wl, hw, 32), []).append(hw[0])
+    assert sorted(fam["yl_conv_wino2_kernel"]) == [20, 20, 40, 40, 80, 80]       # every FPN 3x3 conv (20 x 20 fills 69 %)
+    assert sorted(fam["yl_conv_dwl_kernel"]) == [40, 40, 80, 80]                 # head trunks at 80 x 80 and 40 x 40
+    assert sorted(fam["yl_conv_dwk_kernel"]) == [20, 20]                         # ... the 20 x 20 ones keep the tap-load kernel
+    assert "yl_conv_wino_kernel" not in fam
+    # a batch too small for three windows per CU stays on the tap-load kernel
+    head80 = next(L for L in prog.layers if L.dw_k == 3 and L.cin == 328 and prog.slots[L.out_slot][0] == 80)
+    assert bench.kernel_family(head80, False, (80, 80), 4) == "yl_conv_dwk_kernel"
+
+
 def test_missing_weight_raises_and_meta_errors():
     meta = zoo_meta("edge_n", 3, 64)
     sd = synth_state_dict(meta)
