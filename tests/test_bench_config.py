@@ -219,6 +219,81 @@ def test_bench_configuration_edge_n_b64_parity(seed):
     _assert_all_safe_images(d1, c1, exp, ref_s, 0.4, range(64), what=f"edge_n B=64 seed {seed}", got_scores=got_s)
 
 
+@pytest.mark.parametrize("name,seg,B", [("edge_n", False, 64), ("yololite_m", False, 32), ("edge_m", True, 32),
+                                        ("yololite_m_v2", False, 32)])
+def test_bench_schedule_two_lanes_graph_full_size_parity(name, seg, B):
+    """The schedule `python bench.py` times: serving.ServingPipeline with 2 lanes x 1 chunk stream x
+    hipGraph replay -- un-chunked full-batch launches of two cloned contexts CO-RESIDENT on the chip, persistent grids of
+    one lane next to the other lane's -- at the benchmark's full size, over 8 submissions of two different resident
+    batches.  The submission order A B B A A B A B sends both batches through both lanes, as capture and as replay.
+    Every handed-back result (rows, counts, and for the seg model the prototype indices and the image-resolution masks
+    written on the lane) must be torch.equal to the eager one-stream call of the model's own context."""
+    from yololite_amd.serving import ServingPipeline
+    wl = bench.build_workload(name, 640, B, seed=1, seg=seg, dev=DEV)
+    ctx, xa = wl["ctx"], wl["x"]
+    xb = bench.synth_images(B, 640, seed=4321).to(DEV)
+    mo = bench.MAX_OUT
+    ctx.set_option("graph", 0); ctx.set_option("streams", 1)
+    want = {}
+    for key, x in (("a", xa), ("b", xb)):
+        r = ctx.predict(x, _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo, want_idx=seg)
+        r = tuple(t.clone() for t in r)
+        masks = None
+        if seg:
+            masks = ctx.masks_image(r[0], r[1], r[2], packed=True)
+            masks = masks.clone() if isinstance(masks, torch.Tensor) else tuple(m.clone() for m in masks)
+        want[key] = (r, masks)
+        assert int(r[1].min()) >= 20 and int(r[1].max()) <= mo
+    assert not torch.equal(want["a"][0][1], want["b"][0][1])              # two different batches
+    before = {k: ctx.get_option(k) for k in ("graph", "streams")}
+    pipe = ServingPipeline(ctx, lanes=2, streams_per_lane=1, graph=True)
+    assert {k: ctx.get_option(k) for k in before} == before              # the caller's context is left alone (ADVICE r05)
+    assert all(c.handle.value != ctx.handle.value for c in pipe.ctxs)
+    order = "abbaabab"
+    xs = {"a": xa, "b": xb}
+    row = S_ = 640
+    arenas = [torch.empty((B * mo * S_ * ((S_ + 31) // 32) * 4,), device=DEV, dtype=torch.uint8) if seg else None
+              for _ in range(2)]
+    outs = [(torch.empty((B, mo, 6), device=DEV), torch.empty((B,), device=DEV, dtype=torch.int32)) for _ in range(2)]
+
+    def work_for(key):
+        def work(c, k):
+            r = c.predict(xs[key], _lib.POST_MAIN, 0.4, 0.5, per_class_cap=300, max_out=mo, out=outs[k], want_idx=seg)
+            if seg:
+                return tuple(r) + (c.masks_image(r[0], r[1], r[2], packed=True, arena=arenas[k]),)
+            return tuple(r)
+        return work
+
+    def check(key, r):
+        (d0, c0, *rest0), m0 = want[key]
+        cn = c0.cpu().numpy()
+        assert torch.equal(r[1], c0), key
+        for b in range(B):
+            assert torch.equal(r[0][b, :cn[b]], d0[b, :cn[b]]), (key, b)
+        if seg:
+            assert torch.equal(r[2], rest0[0]), key
+            got_m = r[3]
+            if isinstance(m0, torch.Tensor):
+                n = min(m0.numel(), got_m.numel()) if isinstance(got_m, torch.Tensor) else 0
+                assert isinstance(got_m, torch.Tensor) and torch.equal(got_m.view(-1)[:m0.numel()], m0.view(-1)), key
+            else:
+                for u, v in zip(m0, got_m):
+                    if isinstance(u, torch.Tensor):
+                        assert torch.equal(v.view(-1)[:u.numel()], u.view(-1)), key
+
+    handed = []
+    for i, key in enumerate(order):
+        r = pipe.run(work_for(key))
+        if r is not None:
+            # the hand-back is ordered on the current stream; compare before the lane's buffers are written again
+            check(order[i - 2], r)
+            handed.append(order[i - 2])
+    for j, r in enumerate(pipe.flush()):
+        check(order[len(order) - 2 + j], r)
+        handed.append(order[len(order) - 2 + j])
+    assert "".join(handed) == order
+
+
 @pytest.mark.parametrize("name,seg,seed", [("yololite_m", False, 1), ("edge_m", True, 1), ("yololite_m", False, 2),
                                            ("edge_m", True, 2), ("yololite_m_v2", False, 1)])
 def test_full_size_configs_3_and_4(name, seg, seed):

@@ -179,6 +179,211 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
 }
 
 // ------------------------------------------------------------------------------------------------
+// yl_conv_dpw_kernel (round 6): the same chain, same arithmetic, with the depthwise INPUT WINDOW IN LDS.  The kernel above
+// fetches nine float4 taps per lane and 16-channel block straight from L1/L2 in the MFMA lane layout (lane = channel
+// group * 16 + pixel): the four lanes of a quad sit on four pixels = four cache lines, so every tap load keeps the CU's
+// texture addresser busy for 64 cycles -- 8 waves x 9 loads x 64 cycles = 4608 addresser cycles per block round against
+// 2 x 1536 MFMA cycles per SIMD: the launch is bound by the addresser (0.19 ms of its 0.27), not by the matrix pipe.
+// Here (the recipe of yl_conv_wino2_kernel / yl_conv_dwl_kernel, kept wave-autonomous: no barrier in the loop):
+//   window   the 6 x 6 input pixels under a wave's 4 x 4 tile, one 16-channel block at a time (64 B per pixel), land in a
+//            wave-private LDS ring of NBUF buffers by THREE asynchronous LDS-DMA copies per block whose quads read the 64
+//            contiguous bytes of ONE pixel (16 addresser cycles each; 18 copies per tile instead of 54 fragment loads;
+//            out-of-image pixels read the zero buffer); the k-blocks of consecutive tiles form ONE stream: the copies of
+//            block g + NBUF + 1 go out as soon as the taps of block g + 1 have been read, so the next tile's first blocks
+//            are in flight under this tile's second GEMM and decode;
+//   B        the lane's nine taps by ds_read_b128 from the window: slot = 4 P + (q ^ 2 (y & 1)), P = 6 y + x, q = channel
+//            quad -- one LDS lane group of a read holds pixel rows {a, a + 3} with one channel quad and {a + 1, a + 2} with
+//            its neighbour: the four pixels of a row segment differ in P mod 4, the two rows of a quad differ in y & 1, the
+//            two quads in bit 0 -> 16 different 16-byte bank groups, conflict-free for every tap;
+//   order    per block the 4 NT1 MFMAs run in groups of two n-tiles; in front of a group the wave issues the LDS reads it
+//            needs next (the following group's A fragments, three taps + tap weights of the NEXT block's B), behind it the
+//            fma chain of those taps -- no LDS round trip is waited for in front of an MFMA.
+// Same tap order, fma chain, k order and epilogue as yl_conv_dpp_kernel: BIT-IDENTICAL to it ("dev_select" bit 16 keeps
+// the tap-load kernel; tests/test_gpu_parity.py).
+#ifndef DPW_NW
+#define DPW_NW 8
+#endif
+template <int KB /*Cin/16*/, int NT1 /*trunk n-tiles*/, int NT3 /*head-output n-tiles*/>
+__global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(YlConvMulti mp) {
+  int yl_k = 0;
+  if (mp.n > 1 && (int)blockIdx.x >= mp.p[1].blk0) yl_k = 1;
+  if (mp.n > 2 && (int)blockIdx.x >= mp.p[2].blk0) yl_k = 2;
+  if (mp.n > 3 && (int)blockIdx.x >= mp.p[3].blk0) yl_k = 3;
+  const YlConvP& p = mp.p[yl_k];
+  const int bx = (int)blockIdx.x - p.blk0, gx = p.nblk;
+  constexpr int Cin = KB * 16;
+  constexpr int NBUF = (KB % 3 == 0) ? 3 : 2;                        // ring of window buffers (KB % NBUF == 0)
+  constexpr int WSL = 192;                                           // float4 slots per buffer: three copies, 144 used
+  constexpr int G = NT1 / 2;                                         // MFMA groups of two n-tiles per block
+  constexpr int TPG = (9 + G - 1) / G;                               // taps whose reads ride in front of one group
+  static_assert(NT1 % 2 == 0 && KB % NBUF == 0 && NBUF + 1 <= KB, "yl_conv_dpw_kernel shape");
+  extern __shared__ __attribute__((aligned(16))) float dpp_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  f32x4* w1l = reinterpret_cast<f32x4*>(dpp_lds);                    // [KB][NT1][64] float4
+  f32x4* w3l = w1l + KB * NT1 * 64;                                  // [NT1][NT3][64] float4
+  float* dwl = reinterpret_cast<float*>(w3l + NT1 * NT3 * 64);       // [9][Cin] taps, [Cin] depthwise bias
+  float* b1l = dwl + 10 * Cin;                                       // [NT1 * 16] trunk bias (zero padded)
+  float* b3l = b1l + NT1 * 16;                                       // [NT3 * 16] head-output bias (zero padded)
+  f32x4* const winl = reinterpret_cast<f32x4*>(b3l + NT3 * 16) + wave * (NBUF * WSL);   // the wave's window ring
+  {
+    const f32x4* g1 = reinterpret_cast<const f32x4*>(p.wp);
+    for (int r = wave; r < KB * NT1; r += DPW_NW) yl_glds16(g1 + r * 64 + lane, w1l + r * 64);
+    const f32x4* g3 = reinterpret_cast<const f32x4*>(p.w3p);
+    for (int r = wave; r < NT1 * NT3; r += DPW_NW) yl_glds16(g3 + r * 64 + lane, w3l + r * 64);
+    yl_glds_floats(p.dw_w, dwl, 9 * Cin, tid, DPW_NW * 64);
+    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + 9 * Cin, Cin, tid, DPW_NW * 64);
+    else for (int i = tid; i < Cin; i += DPW_NW * 64) dwl[9 * Cin + i] = 0.0f;
+    yl_glds_floats(p.bias, b1l, NT1 * 16, tid, DPW_NW * 64);
+    yl_glds_floats(p.b3, b3l, NT3 * 16, tid, DPW_NW * 64);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int H = p.H, W = p.W, OW = p.OW, OH = p.OH;                  // depthwise stride 1, pad 1: H == OH
+  const int tw = OW >> 2, th = OH >> 2;
+  const int tiles_img = tw * th;
+  const int ntiles = p.B * tiles_img;
+  int r0, r1;                                                        // XCD bands, see yl_conv_dpp_kernel
+  {
+    const int x = bx & 7, j = bx >> 3, nj = gx >> 3;
+    const long b0 = ((long)ntiles * x) >> 3, b1 = ((long)ntiles * (x + 1)) >> 3;
+    r0 = (int)(b0 + ((b1 - b0) * j) / nj);
+    r1 = (int)(b0 + ((b1 - b0) * (j + 1)) / nj);
+  }
+  const float* const xin = p.x;
+  const float lo1 = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi1 = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float dlo = (p.dw_act == YL_ACT_RELU || p.dw_act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float* const tapw = dwl + 4 * kq;                            // tap t of block kb: tapw[t * Cin + kb * 16]
+  // copy role of the lane in copy j: slot 64 j + lane = (pixel P = y * 6 + x of the window, stored quad)
+  int cy[3], cx[3], cq[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int s = 64 * j + lane, P = s >> 2;
+    cy[j] = P / 6; cx[j] = P - 6 * cy[j];
+    cq[j] = s < 144 ? ((s & 3) ^ ((cy[j] & 1) << 1)) : -1;
+  }
+  // compute role: tap (dy, dx) of the lane's pixel (sy, sx) sits at slot tb[(sy + dy) & 1 ...] + 24 dy + 4 dx
+  const int sy = pl >> 2, sx = pl & 3;
+  const f32x4* const tb0 = winl + 4 * (6 * sy + sx) + (kq ^ ((sy & 1) << 1));          // rows sy, sy + 2
+  const f32x4* const tb1 = winl + 4 * (6 * sy + sx) + (kq ^ (((sy + 1) & 1) << 1));    // row sy + 1
+  auto tap_at = [&](int buf, int tap) -> f32x4 {
+    const f32x4* const b = (tap / 3) == 1 ? tb1 : tb0;
+    return b[buf * WSL + 24 * (tap / 3) + 4 * (tap % 3)];
+  };
+
+  struct Src { const float* s[3]; };
+  auto setup = [&](int tile, Src& src, YlPix& px) {
+    const bool tv = tile < r1;
+    const int tc = tv ? tile : r1 - 1;
+    const int b = tc / tiles_img;
+    const int trem = tc - b * tiles_img;
+    const int tyi = trem / tw, txi = trem - tyi * tw;
+    px.b = b; px.oy = 4 * tyi + sy; px.ox = 4 * txi + sx; px.valid = tv;
+    px.lin = ((size_t)b * OH + px.oy) * OW + px.ox;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int gy = 4 * tyi - 1 + cy[j], gxx = 4 * txi - 1 + cx[j];
+      const bool in = tv && cq[j] >= 0 && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+      src.s[j] = in ? xin + (((long)b * H + gy) * W + gxx) * Cin + 4 * cq[j] : p.zeros;
+    }
+  };
+  auto request = [&](const Src& src, int kb, int buf) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) yl_glds16(src.s[j] + kb * 16, winl + buf * WSL + j * 64);
+  };
+
+  Src cs, ns;
+  YlPix pxc, pxn;
+  int tile = r0 + wave;
+  setup(tile, cs, pxc);
+#pragma unroll
+  for (int kb = 0; kb < NBUF; ++kb) request(cs, kb, kb);
+  f32x4 xq[1];
+  {
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (NBUF - 1)));           // vmcnt(3 (NBUF - 1)): block 0 has landed
+    f32x4 q = *reinterpret_cast<const f32x4*>(tapw + 9 * Cin);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) q = yl_fma4(tap_at(0, tap), *reinterpret_cast<const f32x4*>(tapw + tap * Cin), q);
+    xq[0] = yl_clamp4(q, dlo, dhi);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    request(cs, NBUF, 0);
+  }
+  while (tile < r1) {
+    const int next = tile + DPW_NW;
+    setup(next, ns, pxn);
+    f32x4 acc1[1][NT1];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) acc1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      // block kb is multiplied; B of block kb + 1 (the next tile's block 0 behind the last one) is built beside it
+      constexpr int dummy = 0; (void)dummy;
+      const int kbn = (kb + 1) % KB, bufn = (kb + 1) % NBUF;
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (NBUF - 1)));         // the window of block kb + 1 has landed
+      f32x4 wq[2][2];
+      wq[0][0] = w1l[(kb * NT1 + 0) * 64 + lane];
+      wq[0][1] = w1l[(kb * NT1 + 1) * 64 + lane];
+      f32x4 xn = *reinterpret_cast<const f32x4*>(tapw + 9 * Cin + kbn * 16);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        f32x4 tx[TPG], tv[TPG];
+        if (g + 1 < G) {
+          wq[(g + 1) & 1][0] = w1l[(kb * NT1 + 2 * g + 2) * 64 + lane];
+          wq[(g + 1) & 1][1] = w1l[(kb * NT1 + 2 * g + 3) * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < TPG; ++t)
+          if (g * TPG + t < 9) {
+            tx[t] = tap_at(bufn, g * TPG + t);
+            tv[t] = *reinterpret_cast<const f32x4*>(tapw + (g * TPG + t) * Cin + kbn * 16);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          acc1[0][2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[g & 1][0][st], xq[0][st], acc1[0][2 * g], 0, 0, 0);
+          acc1[0][2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[g & 1][1][st], xq[0][st], acc1[0][2 * g + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TPG; ++t)
+          if (g * TPG + t < 9) xn = yl_fma4(tx[t], tv[t], xn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      xq[0] = yl_clamp4(xn, dlo, dhi);
+      // the buffer of block kb + 1 is free (its taps are in registers): it takes block kb + 1 + NBUF of the stream
+      if (kb + 1 + NBUF < KB) request(cs, kb + 1 + NBUF, bufn);
+      else request(ns, kb + 1 + NBUF - KB, bufn);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // trunk epilogue in registers: D fragment of n-tile nt = B fragment of k-block nt of the head-output GEMM
+    f32x4 acc3[1][NT3];
+#pragma unroll
+    for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NT1; ++kb) {
+      f32x4 hq[1];
+      hq[0] = yl_clamp4(acc1[0][kb] + *reinterpret_cast<const f32x4*>(b1l + kb * 16 + 4 * kq), lo1, hi1);
+      f32x4 wq[NT3];
+#pragma unroll
+      for (int nt = 0; nt < NT3; ++nt) wq[nt] = w3l[(kb * NT3 + nt) * 64 + lane];
+      yl_mma_step<NT3, 1>(wq, hq, acc3);
+      asm volatile("" ::: "memory");
+    }
+    const YlPix pxd[1] = {pxc};
+#pragma unroll
+    for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += *reinterpret_cast<const f32x4*>(b3l + nt * 16 + 4 * kq);
+    yl_epi_decode<NT3, 1, true>(p, acc3, pxd, 0, kq, lane);
+    tile = next;
+    cs = ns; pxc = pxn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no copy may land in LDS after the wave has ended
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same chain with a STORE epilogue and a wide middle: depthwise 3x3 (+act) -> 1x1 expand (+act) -> 1x1 project
 // (+bias, +residual) -- MobileNetV4 UIB blocks with a start depthwise and no middle one (edge_n blocks.2.5: 48 -> 192 ->
 // 48 at 40x40; timm `uir`, /root/reference/scripts/model/model_v2.py:79-121 consumes the features).  Before: two launches
@@ -566,9 +771,14 @@ bool yl_dpp_supported(int cin, int cout, int c3, int oh, int ow) {
 template <int KB, int NT1, int NT3>
 static hipError_t dpp_go(const YlConvP* ps, int n, hipStream_t st, bool attr_only) {
   const size_t lds = dpp_lds_bytes(KB, NT1, NT3);
-  if (attr_only)
+  const size_t ldsw = lds + (size_t)DPW_NW * ((KB % 3 == 0) ? 3 : 2) * 192 * 16;     // + the waves' window rings
+  if (attr_only) {
+    const hipError_t e = hipFuncSetAttribute((const void*)yl_conv_dpw_kernel<KB, NT1, NT3>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)yl_conv_dpp_kernel<KB, NT1, NT3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds);
+  }
   YlConvMulti m;
   m.n = n;
   long total = 0;
@@ -587,7 +797,11 @@ static hipError_t dpp_go(const YlConvP* ps, int n, hipStream_t st, bool attr_onl
     m.p[k].nblk = (int)nb;
     at += (int)nb;
   }
-  hipLaunchKernelGGL((yl_conv_dpp_kernel<KB, NT1, NT3>), dim3((unsigned)at), dim3(DPP_NW * 64), lds, st, m);
+  // window-in-LDS form (round 6): depthwise pad 1 on every side; "dev_select" bit 16 keeps the tap-load kernel
+  bool win = !(ps[0].dev & YL_DEV_DPW_OFF) && DPW_NW == DPP_NW;
+  for (int k = 0; k < n; ++k) win = win && ps[k].dw_pad_t == 1 && ps[k].dw_pad_l == 1;
+  if (win) hipLaunchKernelGGL((yl_conv_dpw_kernel<KB, NT1, NT3>), dim3((unsigned)at), dim3(DPW_NW * 64), ldsw, st, m);
+  else hipLaunchKernelGGL((yl_conv_dpp_kernel<KB, NT1, NT3>), dim3((unsigned)at), dim3(DPP_NW * 64), lds, st, m);
   return hipGetLastError();
 }
 

@@ -142,6 +142,7 @@ struct YlConvP {
 #define YL_DEV_WINO_SHAPE(d) (((d) >> 12) & 3u) // yl_conv_wino2_kernel item shape: 0 auto, 1 (4,4), 2 (2,7), 3 two m-tiles
 #define YL_DEV_DWL_OFF (1u << 14)      // depthwise 3x3 -> wide 1x1: yl_conv_dwk_kernel (taps from L1/L2) instead of yl_conv_dwl_kernel
 #define YL_DEV_DWL_ALL (1u << 15)      // ... yl_conv_dwl_kernel on every grid it supports (partial windows, few items: the bitwise test)
+#define YL_DEV_DPW_OFF (1u << 16)      // fused head launch: yl_conv_dpp_kernel (taps from L1/L2) instead of yl_conv_dpw_kernel (window in LDS)
 
 // squeeze-excite gate (yl_se.hip): fixed-order two-pass spatial mean + the two FCs + sigmoid
 struct YlSeP {

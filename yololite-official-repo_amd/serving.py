@@ -7,11 +7,13 @@ with a join -- back-to-back calls on one context therefore never overlap the lat
 compute-bound head of batch i+1.  `ServingPipeline` keeps `lanes` contexts of the same model (yl_clone: shared weights,
 own arenas / workspaces / graphs) and `lanes` HIP streams; `submit(x)` runs the COMPLETE yl_predict of that batch on lane
 i % lanes and returns the lane's previous result (like dist.DetGatherer.gather()); `flush()` drains.  Every batch is
-processed by exactly the kernels of a plain call, so results are bitwise those of `ctx.predict` (tests/test_bench_config.py).
+processed by exactly the kernels of a plain call, so results are bitwise those of `ctx.predict`
+(tests/test_gpu_parity.py::test_serving_pipeline_*; at the benchmark's full sizes and its exact schedule -- 2 lanes x 1 stream x
+hipGraph replay -- tests/test_bench_config.py::test_bench_schedule_two_lanes_graph_full_size_parity).
 
-Measured (edge_n 640x640 B=64, hipGraph replay): one context, two chunk streams, calls back to back: 39.9 k images/s;
-2 lanes x 1 stream: 44.0 k; 3 / 4 lanes: 42.3 / 43.1 k; 2 lanes x 2 chunk streams: 39.7-42.3 k
-(gpurun_out of tools/pipeline_probe.py, profiles/r05_pipeline_probe.txt).
+Measured (edge_n 640x640 B=64, hipGraph replay; tools/pipeline_probe.py, output kept as profiles/r06_pipeline_probe.txt):
+one context, two chunk streams, calls back to back against 2 / 3 / 4 lanes x 1 stream and 2 lanes x 2 chunk streams --
+2 lanes of un-chunked launches are the optimum on every benchmarked configuration.
 """
 from __future__ import annotations
 
@@ -25,15 +27,18 @@ from .model import HipContext
 
 class ServingPipeline:
     def __init__(self, ctx: HipContext, lanes: int = 2, streams_per_lane: int = 1, graph: bool = True, timing: bool = False):
-        """ctx: the model's context (model._ctx_for(img_size)); it becomes lane 0, the others are clones.
-        streams_per_lane: internal chunk streams of every lane ("streams" option; 1 = un-chunked full-batch launches,
-        measured best with >= 2 lanes).  timing: keep (start, done) HIP-event pairs of every submission (`events`)."""
+        """ctx: the model's context (model._ctx_for(img_size)).  EVERY lane is a clone of it (yl_clone: the packed weights are
+        shared, options copied as they are now), lane 0 included: the caller's context keeps its own `streams` / `graph`
+        settings and arenas, so plain ctx.predict calls behave the same before, during and after the pipeline's life
+        (ADVICE r05).  streams_per_lane: internal chunk streams of every lane ("streams" option; 1 = un-chunked full-batch
+        launches, measured best with >= 2 lanes).  timing: keep (start, done) HIP-event pairs of every submission (`events`)."""
         if lanes < 1:
             raise ValueError("lanes >= 1")
         self.lanes = int(lanes)
-        ctx.set_option("streams", int(streams_per_lane))
-        ctx.set_option("graph", 1 if graph else 0)
-        self.ctxs: List[HipContext] = [ctx] + [ctx.clone() for _ in range(self.lanes - 1)]
+        self.ctxs: List[HipContext] = [ctx.clone() for _ in range(self.lanes)]
+        for c in self.ctxs:
+            c.set_option("streams", int(streams_per_lane))
+            c.set_option("graph", 1 if graph else 0)
         self.device = ctx.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
         self._res: List[Optional[tuple]] = [None] * self.lanes
