@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
   }
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
-  if (DEC) { yl_epi_decode<NTW, MT>(p, acc, px, nt0, kq, lane); return; }   // head output under yl_predict (one wave = whole rows)
+  if (DEC) { yl_epi_decode<NTW, MT, false, true>(p, acc, px, 0, kq, lane); return; }   // (nchunk == 1: nt0 == 0)
+    // head output under yl_predict (one wave = whole rows)
   if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NTW, MT>(p, acc, px, nt0, kq);
   else yl_epi_fast<NTW, MT>(p, acc, px, nt0, kq, lo, hi, true);
 }

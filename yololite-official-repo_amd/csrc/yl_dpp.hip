@@ -173,7 +173,7 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
     const YlPix pxd[1] = {pxc};
 #pragma unroll
     for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += *reinterpret_cast<const f32x4*>(b3l + nt * 16 + 4 * kq);
-    yl_epi_decode<NT3, 1, true>(p, acc3, pxd, 0, kq, lane);
+    yl_epi_decode<NT3, 1, true, true>(p, acc3, pxd, 0, kq, lane);
     tile = next;
   }
 }
@@ -203,6 +203,9 @@ __global__ __launch_bounds__(DPP_NW * 64, DPP_WPE) void yl_conv_dpp_kernel(YlCon
 #ifndef DPW_NW
 #define DPW_NW 8
 #endif
+#ifndef DPW_ABL
+#define DPW_ABL 0                      // VARIANT BUILDS ONLY (tools/build_variant.sh ... -DDPW_ABL=<bits>; results WRONG, timing only):
+#endif                                 // 1 no decode, 2 no second GEMM, 4 no first-GEMM MFMAs, 8 no window copies, 16 no tap reads / fma, 32 no per-tile setup
 template <int KB /*Cin/16*/, int NT1 /*trunk n-tiles*/, int NT3 /*head-output n-tiles*/>
 __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(YlConvMulti mp) {
   int yl_k = 0;
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     }
   };
   auto request = [&](const Src& src, int kb, int buf) {
+    if (DPW_ABL & 8) return;
 #pragma unroll
     for (int j = 0; j < 3; ++j) yl_glds16(src.s[j] + kb * 16, winl + buf * WSL + j * 64);
   };
@@ -312,45 +316,58 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     request(cs, NBUF, 0);
   }
+  // A fragments: two register sets of two n-tiles that alternate from MFMA group to MFMA group (K * G groups per tile, an even
+  // number: the set of a tile's first group is always set 0); the fragments of a group are read one group ahead, across
+  // block and tile boundaries, so that no MFMA waits for the LDS read issued in front of it
+  static_assert((KB * G) % 2 == 0, "A-fragment register sets alternate per group");
+  f32x4 wq[2][2];
+  wq[0][0] = w1l[0 * 64 + lane];
+  wq[0][1] = w1l[1 * 64 + lane];
   while (tile < r1) {
     const int next = tile + DPW_NW;
+    if (DPW_ABL & 32) { ns = cs; pxn = pxc; pxn.valid = next < r1; } else
     setup(next, ns, pxn);
     f32x4 acc1[1][NT1];
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) acc1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 w3q[2][NT3];                                               // head-output A fragments: two sets, one k-block ahead
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       // block kb is multiplied; B of block kb + 1 (the next tile's block 0 behind the last one) is built beside it
-      constexpr int dummy = 0; (void)dummy;
       const int kbn = (kb + 1) % KB, bufn = (kb + 1) % NBUF;
       __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * (NBUF - 1)));         // the window of block kb + 1 has landed
-      f32x4 wq[2][2];
-      wq[0][0] = w1l[(kb * NT1 + 0) * 64 + lane];
-      wq[0][1] = w1l[(kb * NT1 + 1) * 64 + lane];
       f32x4 xn = *reinterpret_cast<const f32x4*>(tapw + 9 * Cin + kbn * 16);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
+        const int cur = (kb * G + g) & 1;
         f32x4 tx[TPG], tv[TPG];
         if (g + 1 < G) {
-          wq[(g + 1) & 1][0] = w1l[(kb * NT1 + 2 * g + 2) * 64 + lane];
-          wq[(g + 1) & 1][1] = w1l[(kb * NT1 + 2 * g + 3) * 64 + lane];
+          wq[cur ^ 1][0] = w1l[(kb * NT1 + 2 * g + 2) * 64 + lane];
+          wq[cur ^ 1][1] = w1l[(kb * NT1 + 2 * g + 3) * 64 + lane];
+        } else if (kb + 1 < KB) {
+          wq[cur ^ 1][0] = w1l[((kb + 1) * NT1 + 0) * 64 + lane];
+          wq[cur ^ 1][1] = w1l[((kb + 1) * NT1 + 1) * 64 + lane];
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT3; ++nt) w3q[0][nt] = w3l[(0 * NT3 + nt) * 64 + lane];
         }
 #pragma unroll
         for (int t = 0; t < TPG; ++t)
-          if (g * TPG + t < 9) {
+          if (g * TPG + t < 9 && !(DPW_ABL & 16)) {
             tx[t] = tap_at(bufn, g * TPG + t);
             tv[t] = *reinterpret_cast<const f32x4*>(tapw + (g * TPG + t) * Cin + kbn * 16);
           }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          acc1[0][2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[g & 1][0][st], xq[0][st], acc1[0][2 * g], 0, 0, 0);
-          acc1[0][2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[g & 1][1][st], xq[0][st], acc1[0][2 * g + 1], 0, 0, 0);
+        for (int st = 0; st < ((DPW_ABL & 4) ? 0 : 4); ++st) {
+          acc1[0][2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[cur][0][st], xq[0][st], acc1[0][2 * g], 0, 0, 0);
+          acc1[0][2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[cur][1][st], xq[0][st], acc1[0][2 * g + 1], 0, 0, 0);
         }
+        if (DPW_ABL & 4) { acc1[0][2 * g] += wq[cur][0] * xq[0]; acc1[0][2 * g + 1] += wq[cur][1] * xq[0]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TPG; ++t)
-          if (g * TPG + t < 9) xn = yl_fma4(tx[t], tv[t], xn);
+          if (g * TPG + t < 9 && !(DPW_ABL & 16)) xn = yl_fma4(tx[t], tv[t], xn);
         __builtin_amdgcn_sched_barrier(0);
       }
       xq[0] = yl_clamp4(xn, dlo, dhi);
@@ -367,16 +384,27 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     for (int kb = 0; kb < NT1; ++kb) {
       f32x4 hq[1];
       hq[0] = yl_clamp4(acc1[0][kb] + *reinterpret_cast<const f32x4*>(b1l + kb * 16 + 4 * kq), lo1, hi1);
-      f32x4 wq[NT3];
+      if (kb + 1 < NT1) {
 #pragma unroll
-      for (int nt = 0; nt < NT3; ++nt) wq[nt] = w3l[(kb * NT3 + nt) * 64 + lane];
-      yl_mma_step<NT3, 1>(wq, hq, acc3);
-      asm volatile("" ::: "memory");
+        for (int nt = 0; nt < NT3; ++nt) w3q[(kb + 1) & 1][nt] = w3l[((kb + 1) * NT3 + nt) * 64 + lane];
+      } else {                                                       // the next tile's first group
+        wq[0][0] = w1l[0 * 64 + lane];
+        wq[0][1] = w1l[1 * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (DPW_ABL & 2) { for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += w3q[kb & 1][nt] * hq[0]; } else
+      yl_mma_step<NT3, 1>(w3q[kb & 1], hq, acc3);
+      __builtin_amdgcn_sched_barrier(0);
     }
     const YlPix pxd[1] = {pxc};
 #pragma unroll
     for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += *reinterpret_cast<const f32x4*>(b3l + nt * 16 + 4 * kq);
-    yl_epi_decode<NT3, 1, true>(p, acc3, pxd, 0, kq, lane);
+    if (DPW_ABL & 1) {
+      f32x4 t = acc3[0][0];
+      for (int nt = 1; nt < NT3; ++nt) t += acc3[0][nt];
+      if (kq == 0 && pxd[0].valid) p.dec_scores[(size_t)pxd[0].b * p.dec_N + p.dec_off + pxd[0].oy * p.OW + pxd[0].ox] = t.x + t.y + t.z + t.w;
+    } else
+    yl_epi_decode<NT3, 1, true, true>(p, acc3, pxd, 0, kq, lane);
     tile = next;
     cs = ns; pxc = pxn;
   }
