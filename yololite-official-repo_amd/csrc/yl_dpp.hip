@@ -216,7 +216,7 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
   const int bx = (int)blockIdx.x - p.blk0, gx = p.nblk;
   constexpr int Cin = KB * 16;
   constexpr int NBUF = (KB % 3 == 0) ? 3 : 2;                        // ring of window buffers (KB % NBUF == 0)
-  constexpr int WSL = 192;                                           // float4 slots per buffer: three copies, 144 used
+  constexpr int WSL = DPW_NW > 8 ? 144 : 192;                        // float4 slots per buffer: three copies, 144 used (12 waves: the third copy is 16 lanes wide)
   constexpr int G = NT1 / 2;                                         // MFMA groups of two n-tiles per block
   constexpr int TPG = (9 + G - 1) / G;                               // taps whose reads ride in front of one group
   static_assert(NT1 % 2 == 0 && KB % NBUF == 0 && NBUF + 1 <= KB, "yl_conv_dpw_kernel shape");
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
   auto request = [&](const Src& src, int kb, int buf) {
     if (DPW_ABL & 8) return;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) yl_glds16(src.s[j] + kb * 16, winl + buf * WSL + j * 64);
+    for (int j = 0; j < 3; ++j)
+      if (j < 2 || WSL == 192 || lane < 16) yl_glds16(src.s[j] + kb * 16, winl + buf * WSL + j * 64);
   };
 
   Src cs, ns;
@@ -330,7 +331,6 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     f32x4 acc1[1][NT1];
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) acc1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 w3q[2][NT3];                                               // head-output A fragments: two sets, one k-block ahead
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       // block kb is multiplied; B of block kb + 1 (the next tile's block 0 behind the last one) is built beside it
@@ -347,9 +347,9 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
         } else if (kb + 1 < KB) {
           wq[cur ^ 1][0] = w1l[((kb + 1) * NT1 + 0) * 64 + lane];
           wq[cur ^ 1][1] = w1l[((kb + 1) * NT1 + 1) * 64 + lane];
-        } else {
-#pragma unroll
-          for (int nt = 0; nt < NT3; ++nt) w3q[0][nt] = w3l[(0 * NT3 + nt) * 64 + lane];
+        } else {                                                     // the head-output GEMM's first group
+          wq[cur ^ 1][0] = w3l[0 * 64 + lane];
+          wq[cur ^ 1][1] = w3l[1 * 64 + lane];
         }
 #pragma unroll
         for (int t = 0; t < TPG; ++t)
@@ -380,21 +380,33 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     f32x4 acc3[1][NT3];
 #pragma unroll
     for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_assert(NT3 % 2 == 0 && (KB * G + NT1 * (NT3 / 2)) % 2 == 0, "A-fragment register sets alternate per group");
 #pragma unroll
     for (int kb = 0; kb < NT1; ++kb) {
       f32x4 hq[1];
       hq[0] = yl_clamp4(acc1[0][kb] + *reinterpret_cast<const f32x4*>(b1l + kb * 16 + 4 * kq), lo1, hi1);
-      if (kb + 1 < NT1) {
 #pragma unroll
-        for (int nt = 0; nt < NT3; ++nt) w3q[(kb + 1) & 1][nt] = w3l[((kb + 1) * NT3 + nt) * 64 + lane];
-      } else {                                                       // the next tile's first group
-        wq[0][0] = w1l[0 * 64 + lane];
-        wq[0][1] = w1l[1 * 64 + lane];
+      for (int g = 0; g < NT3 / 2; ++g) {                            // groups of two n-tiles, A fragments one group ahead
+        const int cur = (KB * G + kb * (NT3 / 2) + g) & 1;
+        if (g + 1 < NT3 / 2) {
+          wq[cur ^ 1][0] = w3l[(kb * NT3 + 2 * g + 2) * 64 + lane];
+          wq[cur ^ 1][1] = w3l[(kb * NT3 + 2 * g + 3) * 64 + lane];
+        } else if (kb + 1 < NT1) {
+          wq[cur ^ 1][0] = w3l[((kb + 1) * NT3 + 0) * 64 + lane];
+          wq[cur ^ 1][1] = w3l[((kb + 1) * NT3 + 1) * 64 + lane];
+        } else {                                                     // the next tile's first group
+          wq[cur ^ 1][0] = w1l[0 * 64 + lane];
+          wq[cur ^ 1][1] = w1l[1 * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (DPW_ABL & 2) { acc3[0][2 * g] += wq[cur][0] * hq[0]; acc3[0][2 * g + 1] += wq[cur][1] * hq[0]; } else
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          acc3[0][2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[cur][0][st], hq[0][st], acc3[0][2 * g], 0, 0, 0);
+          acc3[0][2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[cur][1][st], hq[0][st], acc3[0][2 * g + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (DPW_ABL & 2) { for (int nt = 0; nt < NT3; ++nt) acc3[0][nt] += w3q[kb & 1][nt] * hq[0]; } else
-      yl_mma_step<NT3, 1>(w3q[kb & 1], hq, acc3);
-      __builtin_amdgcn_sched_barrier(0);
     }
     const YlPix pxd[1] = {pxc};
 #pragma unroll
@@ -799,7 +811,7 @@ bool yl_dpp_supported(int cin, int cout, int c3, int oh, int ow) {
 template <int KB, int NT1, int NT3>
 static hipError_t dpp_go(const YlConvP* ps, int n, hipStream_t st, bool attr_only) {
   const size_t lds = dpp_lds_bytes(KB, NT1, NT3);
-  const size_t ldsw = lds + (size_t)DPW_NW * ((KB % 3 == 0) ? 3 : 2) * 192 * 16;     // + the waves' window rings
+  const size_t ldsw = lds + (size_t)DPW_NW * ((KB % 3 == 0) ? 3 : 2) * (DPW_NW > 8 ? 144 : 192) * 16;   // + the waves' window rings
   if (attr_only) {
     const hipError_t e = hipFuncSetAttribute((const void*)yl_conv_dpw_kernel<KB, NT1, NT3>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
@@ -807,27 +819,28 @@ static hipError_t dpp_go(const YlConvP* ps, int n, hipStream_t st, bool attr_onl
     return hipFuncSetAttribute((const void*)yl_conv_dpp_kernel<KB, NT1, NT3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds);
   }
+  // window-in-LDS form (round 6): depthwise pad 1 on every side; "dev_select" bit 16 keeps the tap-load kernel
+  bool win = !(ps[0].dev & YL_DEV_DPW_OFF);
+  for (int k = 0; k < n; ++k) win = win && ps[k].dw_pad_t == 1 && ps[k].dw_pad_l == 1;
+  const int nw = win ? DPW_NW : DPP_NW;
   YlConvMulti m;
   m.n = n;
   long total = 0;
   for (int k = 0; k < n; ++k) { m.p[k] = ps[k]; total += (long)ps[k].B * (ps[k].OH >> 2) * (ps[k].OW >> 2); }
-  // one workgroup per CU (8 waves, two per SIMD), dealt to the problems in proportion to their tiles in multiples of 8
-  // (XCD-aligned ranges); a launch smaller than that gets one workgroup per 8 tiles
-  const int budget = YL_NUM_CU * (DPP_WPE * 4 / DPP_NW);
+  // one workgroup per CU, dealt to the problems in proportion to their tiles in multiples of 8 (XCD-aligned ranges); a
+  // launch smaller than that gets one workgroup per `nw` tiles
+  const int budget = YL_NUM_CU;
   int at = 0;
   for (int k = 0; k < n; ++k) {
     const long t = (long)ps[k].B * (ps[k].OH >> 2) * (ps[k].OW >> 2);
     long nb = (t * budget + total / 2) / total;
-    if (nb > (t + DPP_NW - 1) / DPP_NW) nb = (t + DPP_NW - 1) / DPP_NW;
+    if (nb > (t + nw - 1) / nw) nb = (t + nw - 1) / nw;
     nb = (nb + 4) / 8 * 8;
     if (nb < 8) nb = 8;
     m.p[k].blk0 = at;
     m.p[k].nblk = (int)nb;
     at += (int)nb;
   }
-  // window-in-LDS form (round 6): depthwise pad 1 on every side; "dev_select" bit 16 keeps the tap-load kernel
-  bool win = !(ps[0].dev & YL_DEV_DPW_OFF) && DPW_NW == DPP_NW;
-  for (int k = 0; k < n; ++k) win = win && ps[k].dw_pad_t == 1 && ps[k].dw_pad_l == 1;
   if (win) hipLaunchKernelGGL((yl_conv_dpw_kernel<KB, NT1, NT3>), dim3((unsigned)at), dim3(DPW_NW * 64), ldsw, st, m);
   else hipLaunchKernelGGL((yl_conv_dpp_kernel<KB, NT1, NT3>), dim3((unsigned)at), dim3(DPP_NW * 64), lds, st, m);
   return hipGetLastError();
