@@ -198,6 +198,17 @@ yl_status yl_create(const yl_model_desc* desc, int32_t device_id, yl_ctx** out);
  * back-to-back calls on one context).  The reference has no counterpart (one model object, one call at
  * a time: tools/infer.py:435-516); this is the C form of serving.ServingPipeline.  ABI v4.                          */
 yl_status yl_clone(const yl_ctx* src, yl_ctx** out);
+/* Do kernels on HIP streams `a` and `b` of device `device_id` RUN CONCURRENTLY?  ROCm hands every stream one of
+ * GPU_MAX_HW_QUEUES hardware queues when it is created, round-robin over the streams the PROCESS has created so far (idle and
+ * destroyed ones included), and two streams on one queue serialise.  Measured on MI355X / ROCm 7.2 (round 6): the same
+ * two-batches-in-flight loop runs at 46.3 k or at 39 k images/s, and back-to-back calls on a two-stream context at 42.5 k or
+ * 27.9 k, depending only on how many streams had been created before -- so neither the library nor a host can pick "a second
+ * stream" blindly.  The probe launches a CHAIN of eight dependent 25 us spin kernels (one wave each) on each stream, interleaved,
+ * and reads the wall clock: *overlap = 1 when both chains finished in less than 1.5 chain times (a good pair: ~231 us, an
+ * aliasing pair: ~465 us; lone kernels overlap on every pair and show nothing).  Both streams are synchronised by the call; not capturable.  The library uses
+ * it for its own chunk streams (a candidate that does not overlap the caller's stream and its siblings is replaced); a serving
+ * host uses it for its per-batch streams (serving.ServingPipeline does).  `a` / `b`: hipStream_t, NULL = the null stream.  */
+yl_status yl_streams_overlap(int32_t device_id, void* a, void* b, int32_t* overlap);
 void yl_destroy(yl_ctx* ctx);
 const char* yl_strerror(yl_status s);
 const char* yl_last_error(const yl_ctx* ctx);   /* detail of the last failure on this context     */

@@ -1203,6 +1203,72 @@ def test_ir_fusion_is_bitwise_the_two_launch_form(S, B):
         assert torch.equal(a, r)
 
 
+@pytest.mark.parametrize("S,B", [(640, 3), (384, 2), (128, 5), (96, 7)])
+def test_window_in_lds_head_kernel_is_bitwise_the_tap_load_kernel(S, B):
+    """yl_conv_dpw_kernel (round 6: the head launch with the depthwise input windows in wave-private LDS rings, copied by
+    LDS-DMA) against yl_conv_dpp_kernel ("dev_select" bit 16: nine fragment-shaped tap loads per block): same tap order, fma
+    chain, k order and decode epilogue -> the same BITS in every detection row, main and eval post modes.  128 / 96: every
+    tile touches the image border (the zero-buffer sources of the window copies); B = 5 / 7: tile counts that are not a
+    multiple of the workgroup's waves (the trailing waves run the loop on zero-source windows)."""
+    meta = zoo_meta("edge_n", 80, S)
+    sd = synth_state_dict(meta, seed=1, head_noise=2.0)
+    m = _hip_for(meta, sd)
+    ctx = m._ctx_for(S)
+    x = _x(B, S, seed=61).to(DEV)
+    res = {}
+    try:
+        for dv in (_lib.DEV_DPW_OFF, 0):
+            ctx.set_option("dev_select", dv)
+            for mode, conf, iou, cap in ((_lib.POST_MAIN, 0.02, 0.5, 300), (_lib.POST_EVAL, 0.001, 0.65, 0)):
+                mo = 1024 if mode == _lib.POST_MAIN else ctx.N
+                d, c = ctx.predict(x, mode, conf, iou, per_class_cap=cap, max_out=mo)
+                res[(dv, mode)] = (d.cpu().numpy().copy(), c.cpu().numpy().copy())
+    finally:
+        ctx.set_option("dev_select", 0)
+    for mode in (_lib.POST_MAIN, _lib.POST_EVAL):
+        d0, c0 = res[(_lib.DEV_DPW_OFF, mode)]
+        d1, c1 = res[(0, mode)]
+        assert np.array_equal(c0, c1) and int(c0.sum()) > 0
+        for i in range(B):
+            assert np.array_equal(d0[i, :c0[i]].view(np.uint32), d1[i, :c1[i]].view(np.uint32)), (mode, i)
+
+
+def test_stream_overlap_probe_and_pipeline_lane_streams():
+    """yl_streams_overlap (round 6): ROCm hands a stream its hardware queue at creation, round-robin over every stream the
+    process has created, and two streams whose queues alias serialise their kernel chains (46 k -> 39 k images/s).  The probe
+    must (a) answer for any pair, (b) say 0 for a stream against ITSELF (one in-order queue: the two chains cannot overlap),
+    (c) be what ServingPipeline picks its lane streams by: after a varying number of throw-away streams the lanes still
+    overlap each other and the submitting stream."""
+    import ctypes as C
+    from yololite_amd.serving import ServingPipeline
+    lib = _lib.load()
+    r = C.c_int32(-1)
+    s0 = torch.cuda.Stream(device=DEV)
+    assert lib.yl_streams_overlap(0, C.c_void_p(s0.cuda_stream), C.c_void_p(s0.cuda_stream), C.byref(r)) == _lib.YL_OK
+    assert r.value == 0
+    assert lib.yl_streams_overlap(0, None, C.c_void_p(s0.cuda_stream), C.byref(r)) == _lib.YL_OK and r.value in (0, 1)
+    assert lib.yl_streams_overlap(0, None, None, None) != _lib.YL_OK
+    meta = zoo_meta("edge_n", 80, 128)
+    m = _hip_for(meta, synth_state_dict(meta, seed=3))
+    ctx = m._ctx_for(128)
+    hip = C.CDLL("libamdhip64.so")
+    junk = []
+    for extra in (0, 1, 2, 3):
+        for _ in range(extra):                       # shift the round-robin position of the next streams
+            h = C.c_void_p()
+            assert hip.hipStreamCreateWithFlags(C.byref(h), 1) == 0
+            junk.append(h)
+        pipe = ServingPipeline(ctx, lanes=2, streams_per_lane=1, graph=True)
+        a, b = pipe.streams
+        cur = torch.cuda.current_stream(torch.device(DEV))
+        for u, v in ((a, b), (a, cur), (b, cur)):
+            assert lib.yl_streams_overlap(0, C.c_void_p(u.cuda_stream), C.c_void_p(v.cuda_stream), C.byref(r)) == _lib.YL_OK
+            assert r.value == 1, (extra, u, v)
+        del pipe
+    for h in junk:
+        hip.hipStreamDestroy(h)
+
+
 @pytest.mark.parametrize("S,B,taken", [(640, 3, True), (384, 2, True), (128, 5, True), (352, 2, False)])
 def test_fused_head_launch_is_bitwise_and_never_writes_the_trunk_tensor(S, B, taken):
     """yl_conv_dpp_kernel (round 3): under yl_predict the head branches of edge_n -- depthwise 3x3 -> 1x1 trunk -> 1x1 head

@@ -94,6 +94,7 @@ _vpp = C.POINTER(C.c_void_p)
 SYMBOLS = [
     ("yl_create", C.c_int32, [C.POINTER(yl_model_desc), C.c_int32, C.POINTER(_vp)]),
     ("yl_clone", C.c_int32, [_vp, C.POINTER(_vp)]),
+    ("yl_streams_overlap", C.c_int32, [C.c_int32, _vp, _vp, C.POINTER(C.c_int32)]),
     ("yl_destroy", None, [_vp]),
     ("yl_strerror", C.c_char_p, [C.c_int32]),
     ("yl_last_error", C.c_char_p, [_vp]),

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -1033,14 +1034,79 @@ yl_status run_piece(yl_ctx* c, const Job& j, const Seg& sg, int b0, int bn, hipS
   return s;
 }
 
+// ---- stream / hardware-queue aliasing probe (yl_streams_overlap, include/yololite_hip.h)
+__global__ void yl_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();                       // 100 MHz constant clock
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// 1 = kernel CHAINS on a and b overlap, 0 = they serialise, -1 = HIP error.  Two rounds, the better one counts (a busy device
+// can only make a pair look serialised).  Measured (round 6): a good pair finishes two chains of 8 x 25 us in ~231 us, an aliasing
+// pair in ~465 us; with ONE 200 us kernel per stream both kinds finish in ~224 us -- lone kernels do not show the aliasing.
+int streams_overlap(hipStream_t a, hipStream_t b) {
+  const long long ticks = 20000;                             // 200 us
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+  hipLaunchKernelGGL(yl_spin_kernel, dim3(1), dim3(64), 0, a, 100LL);   // code object load / first-launch cost off the clock
+  hipLaunchKernelGGL(yl_spin_kernel, dim3(1), dim3(64), 0, b, 100LL);
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+  // CHAINS of dependent kernels, not one kernel per stream: two lone kernels overlap on any pair of streams; what a serving
+  // loop needs is that the command processor keeps dispatching stream b's chain while stream a's next kernel waits for its
+  // predecessor (two streams whose hardware queues share a pipe fail exactly there)
+  const int links = 8;
+  double best = 1e30;
+  for (int r = 0; r < 2; ++r) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < links; ++i) {
+      hipLaunchKernelGGL(yl_spin_kernel, dim3(1), dim3(64), 0, a, ticks / links);
+      hipLaunchKernelGGL(yl_spin_kernel, dim3(1), dim3(64), 0, b, ticks / links);
+    }
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (us < best) best = us;
+  }
+  return best < 1.5 * 200.0 ? 1 : 0;
+}
+
+// a new non-blocking stream whose kernels overlap those of every stream in `others` (up to 12 candidates: the hardware-queue
+// assignment walks round-robin with the streams created; the rejected ones are destroyed afterwards -- destroying one right
+// away would hand the same queue to the next candidate's successor).  Falls back to the last candidate.
+yl_status make_overlapping_stream(yl_ctx* c, const hipStream_t* others, int n, hipStream_t* out) {
+  std::vector<hipStream_t> rejected;
+  hipStream_t s = nullptr;
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    HIPCHK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) ok = streams_overlap(others[i], s) != 0;
+    if (ok || attempt == 11) break;
+    rejected.push_back(s);
+    s = nullptr;
+  }
+  for (hipStream_t r : rejected) hipStreamDestroy(r);
+  *out = s;
+  return YL_OK;
+}
+
 // Only the streams this job needs (round 6): n - 1 chunk streams, side streams only under the "lanes" option.  A context
 // used to create all seven at its first call; ROCm hands streams to the GPU_MAX_HW_QUEUES hardware queues as they appear,
 // and with two cloned contexts per serving pipeline (14 idle streams) the two LANE streams of the pipeline ended up
 // sharing a queue: 38.6 k instead of 44.9 k images/s (edge_n B=64, two batches in flight).  A one-stream context now
 // creates no stream at all.
-yl_status ensure_streams(yl_ctx* c, int n) {
+yl_status ensure_streams(yl_ctx* c, int n, hipStream_t st) {
   for (int i = 0; i < 4 && i < n; ++i) {
-    if (i > 0 && !c->work[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));
+    if (i > 0 && !c->work[i]) {
+      // chunk stream i must run beside the caller's stream (chunk 0) and beside its siblings: probe, do not assume
+      hipStream_t others[4] = {st, nullptr, nullptr, nullptr};
+      int no = 1;
+      for (int k = 1; k < i; ++k) others[no++] = c->work[k];
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        HIPCHK(c, hipStreamCreateWithFlags(&c->work[i], hipStreamNonBlocking));   // caller is capturing: no probe possible
+      } else {
+        yl_status ms = make_overlapping_stream(c, others, no, &c->work[i]);
+        if (ms != YL_OK) return ms;
+      }
+    }
     if (i > 0 && !c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     if (!c->opt_lanes) continue;
     if (!c->side[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
@@ -1089,7 +1155,7 @@ yl_status submit(yl_ctx* c, const Job& j, hipStream_t st, bool allow_graph = tru
   const int n = chunks_for(c, j.B);
   Seg segs[3];
   const int nseg = plan_segments(c, j, n, segs);
-  yl_status s = ensure_streams(c, n);
+  yl_status s = ensure_streams(c, n, st);
   if (s != YL_OK) return s;
   if (!c->opt_graph || !allow_graph)
     return walk_plan(c, j, st, n, segs, nseg, [&](int g, int i, int b0, int bn, hipStream_t ws) -> yl_status {
@@ -1243,6 +1309,16 @@ yl_status yl_clone(const yl_ctx* src, yl_ctx** out) {
   c->opt_batch_levels = src->opt_batch_levels; c->opt_winograd = src->opt_winograd; c->opt_fuse_decode = src->opt_fuse_decode;
   c->opt_fuse_head = src->opt_fuse_head; c->opt_split_k = src->opt_split_k; c->opt_dev = src->opt_dev; c->opt_bf16 = src->opt_bf16;
   c->opt_lanes = src->opt_lanes;
+  return YL_OK;
+}
+
+yl_status yl_streams_overlap(int32_t device_id, void* a, void* b, int32_t* overlap) {
+  if (!overlap) return YL_ERR_INVALID;
+  *overlap = 0;
+  if (hipSetDevice(device_id) != hipSuccess) return YL_ERR_HIP;
+  const int r = streams_overlap((hipStream_t)a, (hipStream_t)b);
+  if (r < 0) return YL_ERR_HIP;
+  *overlap = r;
   return YL_OK;
 }
 

@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -40,12 +42,45 @@ class ServingPipeline:
             c.set_option("streams", int(streams_per_lane))
             c.set_option("graph", 1 if graph else 0)
         self.device = ctx.device
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
+        self.streams = self._pick_streams(ctx, self.lanes)
         self._res: List[Optional[tuple]] = [None] * self.lanes
         self._done = [torch.cuda.Event() for _ in range(self.lanes)]
         self._i = 0
         self.timing = bool(timing)
         self.events: List[tuple] = []
+
+    @staticmethod
+    def _pick_streams(ctx: HipContext, n: int):
+        """n HIP streams whose kernels really run beside each other and beside the submitting (current) stream.  ROCm gives a
+        stream its hardware queue at creation, round-robin over every stream the process has created; two lanes on one queue
+        serialise (measured: 46.3 k -> 39 k images/s on edge_n B=64, depending only on the number of streams created before
+        the pipeline).  yl_streams_overlap measures it; candidates that alias a chosen stream are passed over (they stay in
+        torch's stream pool)."""
+        dev = ctx.device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        cur = torch.cuda.current_stream(dev)
+
+        def overlap(a, b) -> bool:
+            r = C.c_int32(0)
+            _lib.check(ctx.lib.yl_streams_overlap(idx, C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), C.byref(r)),
+                       ctx.handle, "yl_streams_overlap")
+            return bool(r.value)
+
+        picked: List[torch.cuda.Stream] = []
+        last = None
+        for _ in range(24):
+            s = torch.cuda.Stream(device=dev)
+            last = s
+            if s.cuda_stream == cur.cuda_stream or any(s.cuda_stream == q.cuda_stream for q in picked):
+                continue
+            if all(overlap(s, q) for q in picked + [cur]):
+                picked.append(s)
+                if len(picked) == n:
+                    return picked
+        while len(picked) < n:                  # no clean set among the candidates: take what there is (still correct, slower)
+            picked.append(last if last is not None and all(last is not q for q in picked) else torch.cuda.Stream(device=dev))
+            last = None
+        return picked
 
     def run(self, fn, inputs=()):
         """Generic form: `fn(ctx, lane)` enqueues ONE batch's work (yl_predict and whatever follows it on the same context:
