@@ -278,3 +278,87 @@ def test_config5_shape_gloo_world8(tmp_path):
     outs = [p.communicate(timeout=400)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+_WORKER_LANES = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import yololite_amd
+from yololite_amd import dist as ydist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+B, max_out, steps, K = 64, 1024, 7, 2            # bench.py --gpus 2 --in-flight 2: B images per rank, packed rows of 1024
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=rank, world_size=world)
+def shard_result(step, r):                        # what rank r's yl_predict of step `step` leaves in its lane's gather slot
+    g = torch.Generator().manual_seed(1000 * step + r)
+    d = torch.randn(B, max_out, 6, generator=g)
+    d[:, 0, 0] = torch.arange(r * B, (r + 1) * B, dtype=torch.float32) + 10000.0 * step
+    c = torch.randint(0, max_out + 1, (B,), generator=g, dtype=torch.int32)
+    return d, c
+gats = [ydist.DetGatherer(B, max_out, "cpu") for _ in range(K)]      # one gatherer per lane (bench.measure_predict: gats[k])
+issued = []                                        # (lane, slot) of every collective in issue order
+def check(views, step):
+    gd, gc = views
+    for r in range(world):
+        d, c = shard_result(step, r)
+        assert torch.equal(gd[r], d) and torch.equal(gc[r], c), (rank, step, r)
+    flat = gd.reshape(world * B, max_out, 6)[:, 0, 0]                # image i of the global batch is (i // B, i % B)
+    assert torch.equal(flat, torch.arange(world * B, dtype=torch.float32) + 10000.0 * step)
+for step in range(steps):
+    k = step % K                                   # ServingPipeline.run: step i on lane i % K
+    g = gats[k]
+    d, c = shard_result(step, rank)
+    g.dets.copy_(d); g.counts.copy_(c)            # lane_work: yl_predict(out=(gats[k].dets, gats[k].counts))
+    issued.append((k, g._k))
+    prev = g.gather()                              # ... return gats[k].gather(): the lane's previous exchange
+    assert (prev is None) == (step < K), (step, prev is None)
+    if prev is not None:
+        check(prev, step - K)
+for k in range(K):                                 # bench.block(): pipe.flush(); for g in gats: g.flush()
+    last = max(s for s in range(steps) if s % K == k)
+    check(gats[k].flush(), last)
+seqs = [None] * world
+dist.all_gather_object(seqs, issued)
+assert all(s == seqs[0] for s in seqs), seqs      # the collective issue order is the same on every rank
+assert issued == [(s % K, (s // K) % 2) for s in range(steps)]
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_bench_shape_two_lanes_two_gatherers_gloo_world2(tmp_path):
+    """the multi-GPU bench shape under --in-flight 2 on CPU -- two lanes, each with its OWN DetGatherer
+    (two slots each), 7 steps, two gloo ranks with 64 images and packed rows of 1024 each.  Step i writes lane i % 2's
+    current slot and starts its all-gather; what comes back is that lane's previous step, whole and in image order; the
+    order in which collectives are issued is identical on every rank (it is program order: lane i % 2, slot (i // 2) % 2);
+    the flush at the end of a timed block returns each lane's last step."""
+    script = tmp_path / "wl.py"
+    script.write_text(_WORKER_LANES)
+    port = 29400 + os.getpid() % 150
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(port)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=400)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+def test_linear_weight_stored_as_1x1_conv_is_accepted():
+    """timm's ConvNeXt variants with conv_mlp=True keep mlp.fc1 / fc2 as 1x1 Conv2d ([4c, c, 1, 1]) instead of
+    nn.Linear ([4c, c]); the builder takes either layout and packs the same layers."""
+    meta = make_meta(img_size=64, arch="YOLOLiteMS", backbone="oracle_tiny_cnx", num_classes=3, fpn_channels=16,
+                     depth_multiple=0.5, head_depth=1)
+    sd = dict(synth_state_dict(meta, seed=5))
+    build_program(meta, sd)                                   # materialises every key of the synthetic dict
+    sd = {k: np.asarray(v) for k, v in sd.items()}
+    p0 = build_program(meta, sd)
+    sd4 = {k: (v.reshape(v.shape + (1, 1)) if (k.endswith("mlp.fc1.weight") or k.endswith("mlp.fc2.weight")) else v)
+           for k, v in sd.items()}
+    assert any(v.ndim == 4 and k.endswith("mlp.fc1.weight") for k, v in sd4.items())
+    p1 = build_program(meta, sd4)
+    assert len(p0.layers) == len(p1.layers)
+    for a, b in zip(p0.layers, p1.layers):
+        for f in ("w", "b", "w2", "b2"):
+            u, v = getattr(a, f), getattr(b, f)
+            assert (u is None) == (v is None) and (u is None or np.array_equal(u, v)), (a.name, f)

@@ -2336,6 +2336,7 @@ static hipError_t dws_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
   const size_t lds = yl_dws_lds(NT * GW, DK, DS, NW);
   const int res = yl_resident_blocks_n(yl_conv_dws_kernel<NT, GW, DK, DS, NW>, NW * 64, lds);
   int gx = res & ~7;
+  if (gx < 8) gx = 8;                                            // (occupancy query below 8: never a grid of 0 -- ADVICE r05)
   while (gx > 8 && gx - 8 >= p.ntiles) gx -= 8;
   hipLaunchKernelGGL((yl_conv_dws_kernel<NT, GW, DK, DS, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
   return hipGetLastError();

@@ -65,7 +65,8 @@ class DetGatherer:
     asynchronous all_gather_into_tensor of that buffer into a preallocated [world, row] tensor and flips to the
     other slot, so the collective of step i overlaps the forward pass of step i+1 (no pack / unpack kernels, no
     host-blocking wait: on ROCm 7 a synchronous all_gather issued behind a busy compute stream costs ~0.7 ms,
-    the asynchronous one ~0.03 ms -- tools/ag_probe.py).  `gather()` returns the PREVIOUS step's result views
+    the asynchronous one ~0.03 ms -- measured in round 1 with a throw-away probe; tools/rccl_queue_probe.py is the
+    kept tool for RCCL next to the executor's streams).  `gather()` returns the PREVIOUS step's result views
     (None on the first call); `flush()` waits for everything in flight and returns the last one.
     Results: dets [world, b, max_out, 6], counts [world, b]; image i of the global batch is (i // b, i % b)."""
 

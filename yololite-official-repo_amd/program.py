@@ -355,6 +355,10 @@ class _Builder:
             raise KeyError(key)
         self.p.used_keys.add(key)
         a = np.asarray(self.sd[key], dtype=np.float64)
+        # a Linear weight [out, in] stored as a 1x1 Conv2d weight [out, in, 1, 1] (timm's ConvNeXt blocks with conv_mlp=True:
+        # the nano / pico / femto / atto variants, as recalled -- ADVICE r05) is the same matrix
+        if a.ndim == 4 and len(shape) == 2 and a.shape[2:] == (1, 1) and tuple(a.shape[:2]) == tuple(shape):
+            a = a.reshape(shape)
         if tuple(a.shape) != tuple(shape):
             raise ValueError(f"{key}: checkpoint shape {tuple(a.shape)} != expected {tuple(shape)}")
         return a
