@@ -473,6 +473,8 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
         ctx.set_option("mfma_bf16", 1)
     if args.f16:
         ctx.set_option("mfma_f16", 1)
+    if args.store_f16:
+        ctx.set_option("store_f16", 1)
     ctx.set_option("lanes", args.lanes)
     ctx.set_option("fuse_decode", args.fuse_decode)
     ctx.set_option("batch_levels", args.batch_levels)
@@ -736,8 +738,10 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
                    "images_per_sec_min": round(float(rates.min()), 1), "images_per_sec_median": round(float(rates[k_med]), 1),
                    "images_per_sec_max": round(float(rates.max()), 1), "images_per_sec_first": round(float(rates[0]), 1)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("bf16" if args.bf16 else "f16") + " operands / f32 accumulate and storage (reduced-precision mode, not the headline)"
-                 if (args.bf16 or args.f16) else "f32",
+        "dtype": ("f16 operands, f16 activation tensors in HBM / f32 accumulate, f32 weights, levels and prototypes (reduced-precision mode, not the headline)"
+                  if args.store_f16 else
+                  ("bf16" if args.bf16 else "f16") + " operands / f32 accumulate and storage (reduced-precision mode, not the headline)")
+                 if (args.bf16 or args.f16 or args.store_f16) else "f32",
         "options": {"winograd": int(args.winograd),
                     "winograd_layers": [prog.layers[i].name for i in sorted(wl_set)]},
         "data": "synthetic",
@@ -807,6 +811,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="side-stream lane for the coarse-level neck/head layers")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16-MFMA compute mode (f4; NOT the headline: reduced precision)")
     ap.add_argument("--f16", type=int, default=0, help="1: fp16-MFMA compute mode (the reference's fp16 autocast; NOT the headline)")
+    ap.add_argument("--store-f16", type=int, default=0, help="1: fp16 operands AND fp16 activation tensors in HBM (option store_f16: the "
+                    "storage side of the reference's fp16 autocast; NOT the headline)")
     ap.add_argument("--winograd", type=int, default=1, help="dense 3x3 stride-1 convs as Winograd F(2x2,3x3), 2.25x fewer MACs: "
                     "1 (library default) = every eligible layer, 2 = only the >= 64-channel ones on the largest grid (the finest "
                     "level's smooth block), 0 = direct convolution everywhere.  Score error vs the oracle measured equal for "
@@ -844,7 +850,7 @@ def main():
 
     out = measure_predict(args, args.model, args.batch, args.seg, dev, rank, world, gather=(world > 1 or force_coll),
                           min_seconds=args.min_seconds)
-    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and not args.f16 and args.winograd == 1
+    headline = (args.model == "edge_n" and args.batch == 64 and not args.seg and not args.bf16 and not args.f16 and not args.store_f16 and args.winograd == 1
                 and not args.stress and args.img == 640)
     want_other = args.other_configs == 1 or (args.other_configs == -1 and headline and world == 1 and not force_coll)
     if rank == 0:

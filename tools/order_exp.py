@@ -17,7 +17,7 @@ def get_args():
 from types import SimpleNamespace
 args = SimpleNamespace(gpus=1, steps=20, warmup=5, batch=64, model="edge_n", img=640, conf=0.4, iou=0.5, graph=1, no_cpu_baseline=True,
     fuse_dw="auto", fuse_stem=1, fuse_uib=0, seg=0, streams=0, in_flight=2, tile_m=0, layers=False, seed=-1, stress=0, nms_groups=0,
-    hybrid=0, batch_levels=1, fuse_decode=1, opt=[], lanes=0, bf16=0, f16=0, winograd=1, workload="predict", min_seconds=0.5,
+    hybrid=0, batch_levels=1, fuse_decode=1, opt=[], lanes=0, bf16=0, f16=0, store_f16=0, winograd=1, workload="predict", min_seconds=0.5,
     layer_reps=int(os.environ.get("LAYER_REPS", "15")), other_configs=0)
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 torch.zeros(1, device=dev)

@@ -30,6 +30,10 @@ UNITS = [   # (source, extra flags, object name)
     ("yl_convc.hip", ["-DYL_BF16=1", "-DYL_F16=1"], "yl_convc_f16.o"),
     ("yl_conv.hip", ["-DYL_BF16=1", "-DYL_F16=1"], "yl_conv_f16.o"),
     ("yl_stemblock.hip", ["-DYL_BF16=1", "-DYL_F16=1"], "yl_stemblock_f16.o"),
+    # fp16-STORAGE mode (option "store_f16", round 6): fp16 operands and fp16 activation tensors in HBM -- a fourth compilation
+    ("yl_convc.hip", ["-DYL_BF16=1", "-DYL_F16=1", "-DYL_F16S=1"], "yl_convc_f16s.o"),
+    ("yl_conv.hip", ["-DYL_BF16=1", "-DYL_F16=1", "-DYL_F16S=1"], "yl_conv_f16s.o"),
+    ("yl_stemblock.hip", ["-DYL_BF16=1", "-DYL_F16=1", "-DYL_F16S=1"], "yl_stemblock_f16s.o"),
     # reference-exact fp32 arithmetic in decode/NMS: no fused multiply-add contraction
     ("yl_post.hip", ["-ffp-contract=off"], "yl_post.o"),
     ("yl_pre.hip", ["-ffp-contract=off"], "yl_pre.o"),

@@ -356,8 +356,12 @@ void plan_slots(yl_ctx* c, bool reuse) {
   }
   for (size_t s = 0; s < NS; ++s) {
     Slot& t = c->slots[s];
-    t.sz = (size_t)t.h * t.w * t.c * sizeof(float);                   // images of a slot are contiguous (a multiple of 16 B)
     t.pinned = (int)s == c->proto_slot;
+    // fp16-storage mode ("store_f16"): activation tensors are fp16; the pinned prototypes (the mask kernels read them) and the
+    // squeeze-excite gates (yl_se.hip writes them, the gated 1x1 convs read them: fp32 [B][C] vectors) stay fp32
+    bool f32 = c->opt_bf16 != 3 || t.pinned;
+    for (size_t i = 0; i < NL && !f32; ++i) f32 = c->layers[i].d.op == YL_OP_SE && c->layers[i].d.out_slot == (int)s;
+    t.sz = (size_t)t.h * t.w * t.c * (f32 ? sizeof(float) : sizeof(_Float16));   // images of a slot are contiguous (a multiple of 8 B)
     if (last[s] < def[s]) last[s] = def[s] == INF ? -1 : def[s];     // produced, never consumed: live in its own group
   }
   struct Iv { size_t off, sz; int last; };
@@ -538,6 +542,7 @@ void layer_params(const yl_ctx* c, const DevLayer& L, int b0, int B, const float
     p.up = slot_ptr(d.up_slot);
     p.UH = c->slots[d.up_slot].h; p.UW = c->slots[d.up_slot].w;
   }
+  p.out_f32 = (c->opt_bf16 == 3 && (d.head_level >= 0 || d.out_slot == c->proto_slot)) ? 1 : 0;
   if (d.head_level >= 0) {
     const int l = d.head_level;
     const int ss = c->level_S[l] * c->level_S[l];
@@ -612,6 +617,15 @@ bool pair_fusable(const yl_ctx* c, size_t i, size_t lend, bool ignore_options) {
     if (reads_in || e.res_slot == t.out_slot || e.up_slot == t.out_slot) return false;
   }
   return true;
+}
+
+hipError_t conv_multi(const yl_ctx* c, const YlConvP* ps, int n, hipStream_t st) {
+  switch (c->opt_bf16) {
+    case 1: return yl_launch_conv_multi_bf16(ps, n, c->opt_tile_m, st);
+    case 2: return yl_launch_conv_multi_f16(ps, n, c->opt_tile_m, st);
+    case 3: return yl_launch_conv_multi_f16s(ps, n, c->opt_tile_m, st);
+    default: return yl_launch_conv_multi(ps, n, c->opt_tile_m, st);
+  }
 }
 
 yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* level_out, hipStream_t st,
@@ -731,11 +745,9 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
           m2.out = o.out + nd; m2.ldo = c->E;
         }
         const int n = (int)(gend - i);
-        hipError_t e = c->opt_bf16 == 1 ? yl_launch_conv_multi_bf16(pd, n, c->opt_tile_m, st)
-                       : c->opt_bf16 == 2 ? yl_launch_conv_multi_f16(pd, n, c->opt_tile_m, st) : yl_launch_conv_multi(pd, n, c->opt_tile_m, st);
+        hipError_t e = conv_multi(c, pd, n, st);
         if (e == hipSuccess)
-          e = c->opt_bf16 == 1 ? yl_launch_conv_multi_bf16(pm, n, c->opt_tile_m, st)
-              : c->opt_bf16 == 2 ? yl_launch_conv_multi_f16(pm, n, c->opt_tile_m, st) : yl_launch_conv_multi(pm, n, c->opt_tile_m, st);
+          e = conv_multi(c, pm, n, st);
         if (e != hipSuccess) {
           char b[256];
           snprintf(b, sizeof(b), "layers %zu..%zu split head launch failed: %s", i, gend - 1, hipGetErrorString(e));
@@ -748,9 +760,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
     if (gend - i > 1) {
       YlConvP ps[4];
       for (size_t q = i; q < gend; ++q) params(q, ps[q - i]);
-      const hipError_t e = c->opt_bf16 == 1 ? yl_launch_conv_multi_bf16(ps, (int)(gend - i), c->opt_tile_m, st)
-                           : c->opt_bf16 == 2 ? yl_launch_conv_multi_f16(ps, (int)(gend - i), c->opt_tile_m, st)
-                                              : yl_launch_conv_multi(ps, (int)(gend - i), c->opt_tile_m, st);
+      const hipError_t e = conv_multi(c, ps, (int)(gend - i), st);
       if (e != hipSuccess) {
         char b[256];
         snprintf(b, sizeof(b), "layers %zu..%zu batched launch failed: %s", i, gend - 1, hipGetErrorString(e));
@@ -790,6 +800,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         int ch = 0;                                          // the chunk arena these images live in
         while (ch + 1 < c->plan_n && b0 >= c->plan_b0[ch + 1]) ++ch;
         sp.partial = c->se_scratch[ch] + (size_t)(b0 - c->plan_b0[ch]) * c->se_unit;
+        if (c->opt_bf16 == 3 && !pooled) return fail(c, YL_ERR_UNSUPPORTED, "store_f16: squeeze-excite pooling needs the pooled depthwise launch in front of it");
         e = yl_launch_se(sp, pooled, ls);
         break;
       }
@@ -797,7 +808,7 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         // feeding a squeeze-excite gate next (efficientnetv2 MBConv): pool in the same launch
         pooled_slot = -1;
         if (i + 1 < lend && c->layers[i + 1].d.op == YL_OP_SE && c->layers[i + 1].d.in_slot == d.out_slot && d.res_slot < 0 &&
-            !c->opt_bf16 && !(c->opt_dev & YL_DEV_DW_TILE_OFF)) {
+            (!c->opt_bf16 || c->opt_bf16 == 3) && !(c->opt_dev & YL_DEV_DW_TILE_OFF)) {
           const int wpi = yl_dw_pool_wpi(d.k, d.stride, d.cin, d.cout, c->layers[i].out_h, c->layers[i].out_w);
           if (wpi > 0 && c->se_unit >= (size_t)wpi * d.cin) {
             int ch = 0;
@@ -807,10 +818,11 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
             pooled_slot = d.out_slot; pooled_P = wpi;
           }
         }
-        e = yl_launch_dw(p, ls);
+        e = c->opt_bf16 == 3 ? yl_launch_dw_f16s(p, ls) : yl_launch_dw(p, ls);
         break;
       }
       case YL_OP_POOL: case YL_OP_COPY: case YL_OP_LN: case YL_OP_GRN: case YL_OP_NHWC4: {
+        if (c->opt_bf16 == 3) return fail(c, YL_ERR_UNSUPPORTED, "store_f16: the element-wise ops of the hgnetv2 / convnextv2 backbones are fp32-storage only");
         const DevLayer& L = c->layers[i];
         YlOpP q;
         memset(&q, 0, sizeof(q));
@@ -829,16 +841,19 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
         e = yl_launch_op(d.op, q, ls);
         break;
       }
-      case YL_OP_STEM: e = yl_launch_stem(p, ls); break;
+      case YL_OP_STEM: e = c->opt_bf16 == 3 ? yl_launch_stem_f16s(p, ls) : yl_launch_stem(p, ls); break;
       case YL_OP_CONV:
         e = c->opt_bf16 == 1 ? yl_launch_conv_bf16(p, c->opt_tile_m, ls)
-            : c->opt_bf16 == 2 ? yl_launch_conv_f16(p, c->opt_tile_m, ls) : yl_launch_conv(p, c->opt_tile_m, ls);
+            : c->opt_bf16 == 2 ? yl_launch_conv_f16(p, c->opt_tile_m, ls)
+            : c->opt_bf16 == 3 ? yl_launch_conv_f16s(p, c->opt_tile_m, ls) : yl_launch_conv(p, c->opt_tile_m, ls);
         break;
       case YL_OP_STEMBLOCK:
-        e = c->opt_bf16 == 1 ? yl_launch_stemblock_bf16(p, ls) : c->opt_bf16 == 2 ? yl_launch_stemblock_f16(p, ls) : yl_launch_stemblock(p, ls);
+        e = c->opt_bf16 == 1 ? yl_launch_stemblock_bf16(p, ls) : c->opt_bf16 == 2 ? yl_launch_stemblock_f16(p, ls)
+            : c->opt_bf16 == 3 ? yl_launch_stemblock_f16s(p, ls) : yl_launch_stemblock(p, ls);
         break;
-      default: e = yl_launch_dw(p, ls); break;
+      default: e = c->opt_bf16 == 3 ? yl_launch_dw_f16s(p, ls) : yl_launch_dw(p, ls); break;
     }
+    if (e == hipSuccess && YL_ACT_POSTPASS(d.act) && c->opt_bf16 == 3) return fail(c, YL_ERR_UNSUPPORTED, "store_f16: GELU / ReLU + affine passes are fp32-storage only");
     if (e == hipSuccess && YL_ACT_POSTPASS(d.act)) {
       // GELU / ReLU + learnable affine (+ the residual behind it): element-wise pass over the layer's output, in place
       const DevLayer& L = c->layers[i];
@@ -1336,7 +1351,8 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     if (yl_post_init() != hipSuccess || yl_conv_init() != hipSuccess || yl_stemblock_init() != hipSuccess ||
         yl_conv_init_bf16() != hipSuccess || yl_stemblock_init_bf16() != hipSuccess || yl_convc_init() != hipSuccess ||
         yl_convc_init_bf16() != hipSuccess || yl_dpp_init() != hipSuccess || yl_conv_init_f16() != hipSuccess ||
-        yl_stemblock_init_f16() != hipSuccess || yl_convc_init_f16() != hipSuccess)
+        yl_stemblock_init_f16() != hipSuccess || yl_convc_init_f16() != hipSuccess || yl_conv_init_f16s() != hipSuccess ||
+        yl_stemblock_init_f16s() != hipSuccess || yl_convc_init_f16s() != hipSuccess)
       return YL_ERR_HIP;
     g_inited[device_id] = true;
   }
@@ -1656,8 +1672,13 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
 yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!c || !name) return YL_ERR_INVALID;
   if (!strcmp(name, "graph")) { c->opt_graph = value ? 1 : 0; drop_graph(c); return YL_OK; }
-  if (!strcmp(name, "mfma_bf16")) { c->opt_bf16 = value ? 1 : (c->opt_bf16 == 1 ? 0 : c->opt_bf16); drop_graph(c); return YL_OK; }
-  if (!strcmp(name, "mfma_f16")) { c->opt_bf16 = value ? 2 : (c->opt_bf16 == 2 ? 0 : c->opt_bf16); drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "mfma_bf16")) { if (c->opt_bf16 == 3) free_act(c); c->opt_bf16 = value ? 1 : (c->opt_bf16 == 1 ? 0 : c->opt_bf16); drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "mfma_f16")) { if (c->opt_bf16 == 3) free_act(c); c->opt_bf16 = value ? 2 : (c->opt_bf16 == 2 ? 0 : c->opt_bf16); drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "store_f16")) {      // fp16 operands AND fp16 activation tensors in HBM (round 6): the arenas are re-planned
+    const int nv = value ? 3 : (c->opt_bf16 == 3 ? 0 : c->opt_bf16);
+    if ((nv == 3) != (c->opt_bf16 == 3)) free_act(c);
+    c->opt_bf16 = nv; drop_graph(c); return YL_OK;
+  }
   if (!strcmp(name, "nms_groups")) { c->opt_nms_groups = value < 0 ? 0 : (value > YL_NMS_GROUPS ? YL_NMS_GROUPS : value); drop_graph(c); return YL_OK; }
   if (!strcmp(name, "time_split")) {
     // (no drop_graph: the setting is part of the graph key -- a serving loop toggles it per call, api.YoloLite.predict)
@@ -1685,7 +1706,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
 yl_status yl_get_option(const yl_ctx* c, const char* name, int32_t* value) {
   if (!c || !name || !value) return YL_ERR_INVALID;
   const struct { const char* n; int v; } tab[] = {
-      {"graph", c->opt_graph}, {"mfma_bf16", c->opt_bf16 == 1}, {"mfma_f16", c->opt_bf16 == 2}, {"nms_groups", c->opt_nms_groups}, {"time_split", c->opt_time_split},
+      {"graph", c->opt_graph}, {"mfma_bf16", c->opt_bf16 == 1}, {"mfma_f16", c->opt_bf16 == 2}, {"store_f16", c->opt_bf16 == 3}, {"nms_groups", c->opt_nms_groups}, {"time_split", c->opt_time_split},
       {"pre_norm", c->opt_pre_norm}, {"reuse_slots", c->opt_reuse}, {"hybrid", c->opt_hybrid}, {"batch_levels", c->opt_batch_levels},
       {"fuse_decode", c->opt_fuse_decode}, {"fuse_head", c->opt_fuse_head}, {"winograd", c->opt_winograd}, {"lanes", c->opt_lanes},
       {"tile_m", c->opt_tile_m}, {"streams", c->opt_streams}, {"dev_select", c->opt_dev}, {"split_k", c->opt_split_k}};
@@ -1770,6 +1791,7 @@ yl_status yl_read_slot(yl_ctx* c, int32_t slot, int32_t B, float* dst, void* str
   if (B > c->act_batch || c->plan_n < 1) return fail(c, YL_ERR_STATE, "no forward of >= B images has produced this slot");
   HIPCHK(c, hipSetDevice(c->device));
   const Slot& s = c->slots[slot];
+  if (c->opt_bf16 == 3 && !s.pinned) return fail(c, YL_ERR_UNSUPPORTED, "store_f16: activation slots are fp16 (yl_read_slot hands out fp32)");
   // (with "reuse_slots" on, a tensor that is not an output of the network may have been overwritten by later layers)
   for (int i = 0; i < c->plan_n; ++i) {
     const int b0 = c->plan_b0[i], b1 = c->plan_b0[i + 1] < B ? c->plan_b0[i + 1] : B;

@@ -95,7 +95,7 @@ __device__ __forceinline__ f32x4 yl_fetch(const YlConvP& p, const YlPix& px, int
     f32x4 s = yl_ld4(dwl + p.dw_k * p.dw_k * p.Cin + cs);
     const int y0 = px.oy * p.dw_stride - p.dw_pad_t;
     const int x0 = px.ox * p.dw_stride - p.dw_pad_l;
-    const float* xb = p.x + (size_t)px.b * p.H * p.W * p.Cin + cs;
+    const yl_act_t* xb = p.x + (size_t)px.b * p.H * p.W * p.Cin + cs;
     const float* wb = dwl + cs;
     if (MODE == YL_CM_DW5) {
       // 5x5: one row of taps (5 loads) in flight at a time keeps the register footprint small
@@ -194,7 +194,7 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
     long rows = (long)p.M - (long)lin0;                         // valid pixels of this tile
     if (rows > MT * 16) rows = MT * 16;
     const int total = (int)rows * p.N;                          // floats; the run starts 16-B aligned
-    float* dst = p.out + lin0 * p.N;
+    float* dst = reinterpret_cast<float*>(p.out) + lin0 * p.N;   // (rows with N & 3: detection-level rows, fp32 in every unit)
     const int n4 = total >> 2;
     for (int i = lane; i < n4; i += 64)
       *reinterpret_cast<f32x4*>(dst + 4 * i) = *reinterpret_cast<const f32x4*>(stg + 4 * i);
@@ -206,7 +206,7 @@ __device__ __forceinline__ void yl_epi_scalar(const YlConvP& p, f32x4 (&acc)[MT]
   for (int mt = 0; mt < MT; ++mt) {
     if (!px[mt].valid) continue;
     const int cell = px[mt].oy * p.OW + px[mt].ox;
-    float* orow = p.out + (size_t)px[mt].b * p.out_bstride + (size_t)cell * p.N + 4 * kq;
+    float* orow = reinterpret_cast<float*>(p.out) + (size_t)px[mt].b * p.out_bstride + (size_t)cell * p.N + 4 * kq;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = (nt0 + nt) * 16 + 4 * kq;
@@ -413,11 +413,11 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 && MODE <= 1) ? YL_PW_WAVES : 3)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         if (!px[mt].valid) continue;
-        float* orow = p.out + px[mt].lin * p.C3;
+        yl_act_t* orow = p.out + px[mt].lin * p.C3;
 #pragma unroll
         for (int nt3 = 0; nt3 < 2; ++nt3) {
           const int n = nt3 * 16 + 4 * kq;
-          if (nt3 < NT3 && n < p.C3) *reinterpret_cast<f32x4*>(orow + n) = yl_clamp4(a3[mt][nt3] + yl_ld4(p.b3 + n), lo3, hi3);
+          if (nt3 < NT3 && n < p.C3) yl_st4(orow + n, yl_clamp4(a3[mt][nt3] + yl_ld4(p.b3 + n), lo3, hi3));
         }
       }
       continue;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
   // beyond num_records (image border, channel tail) returns 0 from the hardware range check -- no bounds
   // selects, no 64-bit address arithmetic in the loop.  The launcher guarantees the tensor is < 2 GiB.
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.x), 0, (int)((long)p.B * p.H * p.W * p.Cin * 4), 0x00020000);
+      const_cast<yl_act_t*>(p.x), 0, (int)((long)p.B * p.H * p.W * p.Cin * (long)sizeof(yl_act_t)), 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   unsigned goff[NSLOT];        // byte offsets of the lane's staging slots (channel block 0) for one tile
   auto tile_geom = [&](int tile) {
@@ -520,18 +520,20 @@ __global__ __launch_bounds__(256, 3) void yl_conv_dwh_kernel(YlConvMulti mp) {
       const int hr = hp / HP, hc = hp - hr * HP;
       const int iy = iy0 + hr, ix = ix0 + hc;
       const bool in = e < HF4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      goff[j] = in ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.Cin + (lane & 3) * 4) * 4) : OOB;
+      goff[j] = in ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.Cin + (lane & 3) * 4) * (int)sizeof(yl_act_t)) : OOB;
     }
   };
   auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
     const bool cok = kb * 16 + (lane & 3) * 4 < p.Cin;
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
-      const unsigned off = cok ? goff[j] + (unsigned)kb * 64u : OOB;
-#if YL_DWH_BUF
+      const unsigned off = cok ? goff[j] + (unsigned)kb * (16u * (unsigned)sizeof(yl_act_t)) : OOB;
+#if YL_DWH_BUF && !(defined(YL_F16S) && YL_F16S)
       r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+#elif YL_DWH_BUF
+      r[j] = __builtin_convertvector(__builtin_bit_cast(yl_h16x4, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)off, 0, 0)), f32x4);
 #else
-      r[j] = yl_ld4(off < OOB ? p.x + (off >> 2) : p.zeros);
+      r[j] = yl_ld4(off < OOB ? p.x + off / (unsigned)sizeof(yl_act_t) : p.zeros);
 #endif
     }
   };
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(256) void yl_uib_kernel(YlConvP p) {
     for (int m = 0; m < HM; ++m) {
       const int iy = iy0 + h_r[m], ix = ix0 + h_c[m];
       h_in[m] = h_ok[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const float* src = p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.C1 + 4 * kq;
+      const yl_act_t* src = p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.C1 + 4 * kq;
 #pragma unroll
       for (int kbi = 0; kbi < KBI; ++kbi) {
         const bool ok = h_in[m] && (kbi * 16 + 4 * kq) < p.C1;
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(256) void yl_stem_mfma_kernel(YlConvP p) {
       const int rem = (int)(lin - (size_t)b * ohw);
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
       const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
-      const float* xb = p.x + (size_t)b * 3 * plane;
+      const float* xb = reinterpret_cast<const float*>(p.x) + (size_t)b * 3 * plane;   // the fp32 NCHW network input
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int iy = y0 + tky[s], ix = x0 + tkx[s];
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(256) void yl_stem_mfma_kernel(YlConvP p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (!valid[mt]) continue;
-      float* orow = p.out + lins[mt] * p.N;
+      yl_act_t* orow = p.out + lins[mt] * p.N;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 16 + 4 * kq;
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(256) void yl_stem_mfma_kernel(YlConvP p) {
         if (YL_SMOOTH(p.act)) v = yl_act4(v, p.act);
         v.x = fminf(fmaxf(v.x, lo), hi); v.y = fminf(fmaxf(v.y, lo), hi);
         v.z = fminf(fmaxf(v.z, lo), hi); v.w = fminf(fmaxf(v.w, lo), hi);
-        *reinterpret_cast<f32x4*>(orow + n) = v;
+        yl_st4(orow + n, v);
       }
     }
   }
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(256) void yl_dw_kernel(YlConvP p) {
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) s = yl_ld4(p.bias + c);
   const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
-  const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin + c;
+  const yl_act_t* xb = p.x + (size_t)b * p.H * p.W * p.Cin + c;
   for (int dy = 0; dy < p.k; ++dy) {
     const int iy = y0 + dy;
     if (iy < 0 || iy >= p.H) continue;
@@ -923,7 +925,7 @@ __global__ __launch_bounds__(256) void yl_dw_kernel(YlConvP p) {
   s = yl_act4(s, p.act);
   const size_t o = lin * p.N + c;
   if (p.res) s += yl_ld4(p.res + o);
-  *reinterpret_cast<f32x4*>(p.out + o) = s;
+  yl_st4(p.out + o, s);
 }
 
 // Register-tiled stand-alone depthwise K x K (stride S): a lane owns 4 channels of a 4 x 2 block of output pixels and
@@ -984,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
     // addresses: wave-uniform 64-bit base per (row, column) (SALU) + the lane's 32-bit channel offset; a tap outside
     // the image selects the zero buffer with offset 0
     const char* xb = reinterpret_cast<const char*>(p.x + (size_t)b * H * W * C);
-    const unsigned coff = (unsigned)c * 4u;
+    const unsigned coff = (unsigned)c * (unsigned)sizeof(yl_act_t);
     const long zoff = reinterpret_cast<const char*>(p.zeros) - xb;
     // window rows double-buffered in registers: row r + 1 is requested before the FMAs of row r (the scheduling
     // barriers keep the compiler from hoisting all ROWS x COLS loads to the top: 192 VGPRs and spills at 5x5)
@@ -996,8 +998,8 @@ __global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
         const int ix = ix0 + q;
         const bool ok = yok && ix >= 0 && ix < W;
         const long m = -(long)ok;                                     // branch-free select (uniform: SALU and/or)
-        const long off = ((((long)iy * W + ix) * C * 4) & m) | (zoff & ~m);
-        row[q] = *reinterpret_cast<const f32x4*>(xb + off + (coff & (unsigned)m));
+        const long off = ((((long)iy * W + ix) * C * (long)sizeof(yl_act_t)) & m) | (zoff & ~m);
+        row[q] = yl_ld4(reinterpret_cast<const yl_act_t*>(xb + off + (coff & (unsigned)m)));
       }
     };
     // 5x5: the 25 tap weights must be re-read from LDS per block (an opaque zero in their address stops the compiler
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void yl_dw_tile_kernel(YlConvP p) {
         const size_t o = (((size_t)b * OH + oy) * OW + ox) * p.N + c;
         if (p.res) s4 += yl_ld4(p.res + o);
         if (POOL) psum += s4;
-        *reinterpret_cast<f32x4*>(p.out + o) = s4;
+        yl_st4(p.out + o, s4);
       }
     }
   }

@@ -57,6 +57,11 @@
 #include "yl_internal.h"
 #include "yl_dev.h"
 #include "yl_epi.h"
+#if defined(YL_F16S) && YL_F16S
+#define defined_YL_F16S 1
+#else
+#define defined_YL_F16S 0
+#endif
 
 // co-resident workgroups of `kernel` on the whole device (occupancy query cached per kernel and LDS size)
 template <typename K>
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwc_kernel(YlConvMulti mp) {
   // SGPRs -- inside the tap / copy loops that was most of their time
   const int Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N, NTtot = p.NTtot, dw_act = p.dw_act;
   const int pad_t = p.dw_pad_t, pad_l = p.dw_pad_l;
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const long zdelta = p.zeros - p.x;                            // float offset of the zero buffer from the input tensor
   const int tw = OW >> 2, th = OH >> 2;
   const int tiles_img = tw * th;
@@ -323,8 +328,8 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwc_kernel(YlConvMulti mp) {
     const int kq = lane >> 4, pl = lane & 15;
     const int nt0 = cw * NTW;
     const bool p2 = nt0 < NTtot;                                   // this wave owns output channels
-    const float* const resp = p.res;
-    float* const outp = p.out;
+    const yl_act_t* const resp = p.res;
+    yl_act_t* const outp = p.out;
     const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
     const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
     f32x4 wreg[KBMAX][NTW], breg[NTW];
@@ -383,12 +388,12 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwc_kernel(YlConvMulti mp) {
         if (it == 3) { asm volatile("" :: "v"(acc[0][0].x)); DWC_STAMP(21); }
         if (generic) yl_epi_generic<NTW, 1>(p, acc, px, nt0, kq);
         else {                                                      // == yl_epi_fast with the bias from registers
-          float* orow = outp + px[0].lin * N;
+          yl_act_t* orow = outp + px[0].lin * N;
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) {
             const int n = (nt0 + nt) * 16 + 4 * kq;
             const f32x4 v = yl_clamp4(acc[0][nt] + breg[nt], lo, hi);
-            if (n < N) *reinterpret_cast<f32x4*>(orow + n) = v;
+            if (n < N) yl_st4(orow + n, v);
           }
         }
       }
@@ -425,10 +430,10 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
   const int nt0 = nc * NTW;
   const int Cin = p.Cin, N = p.N, NTtot = p.NTtot, KB = p.KB, M = p.M;
   if ((long)mg * (MT * 16) >= M) return;
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wp);
   YlPix px[MT];
-  const float* xrow[MT];
+  const yl_act_t* xrow[MT];
   const float* srow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(256) void yl_conv_pwt_kernel(YlConvMulti mp, int nc
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         bq[u][mt] = yl_ld4(cok ? xrow[mt] + kb * 16 : p.zeros);
-        if (SC) bq[u][mt] *= yl_ld4(cok ? srow[mt] + kb * 16 : p.zeros);
+        if (SC) bq[u][mt] *= yl_ld4(cok ? srow[mt] + kb * 16 : reinterpret_cast<const float*>(p.zeros));
       }
     }
     (void)cin4;
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
   const int Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N, NTtot = p.NTtot, KB = p.KB;
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const long zdelta = p.zeros - p.x;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);                     // WL: [KB][NTtot][64] float4
   float* dwl = yl_clds + (WL ? (size_t)KB * NTtot * 256 : 0);        // [DK*DK][Cin] taps, [Cin] bias
@@ -962,7 +967,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_kxk_kernel(Y
   const int TK = p.TK, KB = p.KB, K = p.k, NTtot = p.NTtot;
   const int Cin = p.Cin, H = p.H, W = p.W, stride = p.stride, pad_t = p.pad_t, pad_l = p.pad_l, sh = p.in_shift;
   const int ohw = p.OH * p.OW, OW = p.OW, M = p.M;
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const long zdelta = p.zeros - p.x;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][3][NT][64] float4
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
@@ -1047,7 +1052,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_kxk_kernel(Y
     // puts KB = 21 k-steps of other channels between two touches of a line, more than L1 and the XCD's L2 hold, and
     // FETCH_SIZE showed every tap of every pixel coming from HBM / MALL again: 7.5 GB per launch for a 269 MB input.
     // Per lane: nine tap pointers (the zero buffer where a tap falls outside the image, marked in `inb`).
-    const float* tp[MT][9];
+    const yl_act_t* tp[MT][9];
     unsigned inb[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1065,7 +1070,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_kxk_kernel(Y
       const bool tail = kb * 16 + 4 * kq >= Cin;                  // channel tail of the last block: zeros
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const float* q = tp[mt][tap] + (((inb[mt] >> tap) & 1u) ? kb * 16 : 0);
+        const yl_act_t* q = tp[mt][tap] + (((inb[mt] >> tap) & 1u) ? kb * 16 : 0);
         dst[mt] = yl_ld4(tail ? xin + zdelta : q);
       }
     };
@@ -1169,7 +1174,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
   const int KB = p.KB, NTtot = p.NTtot, Cin = p.Cin, M = p.M;
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][CH][NT][64] float4
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);   // [KB][NTtot][64] float4
   const int NC = (KB + CH - 1) / CH;                         // chunks per item
@@ -1224,7 +1229,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
         px[0].ox = rem - px[0].oy * p.OW;
       }
     }
-    const float* xrow = xin + px[0].lin * Cin + 4 * kq;
+    const yl_act_t* xrow = xin + px[0].lin * Cin + 4 * kq;
     const float* srow = SC ? p.scale + (size_t)px[0].b * Cin + 4 * kq : nullptr;    // squeeze-excite gate of the pixel's image
     f32x4 acc[1][NT];
 #pragma unroll
@@ -1248,7 +1253,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
     auto fetch = [&](int kb) {
       const bool ok = kb * 16 + 4 * kq < Cin;                 // channel tail of the last block: zeros
       f32x4 v = yl_ld4(ok ? xrow + kb * 16 : p.zeros);
-      if (SC) v *= yl_ld4(ok ? srow + kb * 16 : p.zeros);     // x * gate (one rounding), then the GEMM
+      if (SC) v *= yl_ld4(ok ? srow + kb * 16 : reinterpret_cast<const float*>(p.zeros));     // x * gate (one rounding), then the GEMM
       return v;
     };
     f32x4 xq = fetch(0);
@@ -1403,8 +1408,8 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
   float* b2l = dwl + (((size_t)(DK * DK + 1) * Cmid + 3) & ~(size_t)3);   // [KB*16] expansion bias
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);          // projection [KB][NTtot][64]
   const f32x4* w2g = reinterpret_cast<const f32x4*>(p.w2p);        // expansion [KBI][KB][64]
-  const float* const xin = p.x;
-  const float* const up = p.up;                                     // FPN lateral + smooth pair: addend of the expansion
+  const yl_act_t* const xin = p.x;
+  const yl_act_t* const up = p.up;                                     // FPN lateral + smooth pair: addend of the expansion
   {
     const int nw = DK * DK * Cmid;
     yl_glds_floats(p.dw_w, dwl, nw, tid, NTH);
@@ -1479,7 +1484,7 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
       h_in[j] = h_ok[j] && iy >= 0 && iy < H && ix >= 0 && ix < W;
       uoff[j] = 0;
       if (up && h_in[j]) uoff[j] = ((((long)b * p.UH + (iy * p.UH) / H) * p.UW + (ix * p.UW) / W) * Cmid) + 4 * kq;
-      const float* src = xin + (((size_t)b * H + iy) * W + ix) * C1 + 4 * kq;
+      const yl_act_t* src = xin + (((size_t)b * H + iy) * W + ix) * C1 + 4 * kq;
 #pragma unroll
       for (int kbi = 0; kbi < KBI; ++kbi) {
         const bool ok = h_in[j] && (kbi * 16 + 4 * kq) < C1;
@@ -1671,7 +1676,7 @@ __global__ __launch_bounds__(NW * 64, GW == 1 ? 3 : 2) void yl_conv_dwk_kernel(Y
   const int KB = p.KB, NTtot = p.NTtot;
   const int Cin = p.Cin, H = p.H, W = p.W, DS = p.dw_stride, pad_t = p.dw_pad_t, pad_l = p.dw_pad_l;
   const int ohw = p.OH * p.OW, OW = p.OW, M = p.M;
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const long zdelta = p.zeros - p.x;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][S][GW][NT][64] float4
   float* dwl = yl_clds + (size_t)2 * PCS * 256;              // [9][Cin] taps, [Cin] bias
@@ -1751,7 +1756,7 @@ __global__ __launch_bounds__(NW * 64, GW == 1 ? 3 : 2) void yl_conv_dwk_kernel(Y
         }
     }
     // nine tap pointers of the lane's pixel (the zero buffer where a tap falls outside the image, marked in `inb`)
-    const float* tp[9];
+    const yl_act_t* tp[9];
     unsigned inb = 0;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -1764,7 +1769,7 @@ __global__ __launch_bounds__(NW * 64, GW == 1 ? 3 : 2) void yl_conv_dwk_kernel(Y
       const bool tail = kb * 16 + 4 * kq >= Cin;                  // channel tail of the last block: zeros
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const float* q = tp[tap] + (((inb >> tap) & 1u) ? kb * 16 : 0);
+        const yl_act_t* q = tp[tap] + (((inb >> tap) & 1u) ? kb * 16 : 0);
         dst[tap] = yl_ld4(tail ? xin + zdelta : q);
       }
     };
@@ -1843,7 +1848,8 @@ hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
   if (sel == 0) return hipErrorNotSupported;
   // window-in-LDS form (yl_conv_dwl_kernel): stride 1, pad 1, grids that fill the 8 x 8-pixel windows to >= 80 % (20 x 20: 69 %, slower than the tap-load kernel), >= 1.5 items
   // per CU (40 x 40 at B = 32: 0.116 -> 0.098 ms); "dev_select" bit 14 = off, bit 15 = on every grid (the bitwise test)
-  if (!(p.dev & YL_DEV_DWL_OFF) && p.dw_stride == 1 && p.dw_pad_t == 1 && p.dw_pad_l == 1 && !p.scale &&
+  // (the fp16-storage unit keeps the tap-load kernel: the windows are raw LDS-DMA copies of the tensor's bytes)
+  if (!(defined_YL_F16S) && !(p.dev & YL_DEV_DWL_OFF) && p.dw_stride == 1 && p.dw_pad_t == 1 && p.dw_pad_l == 1 && !p.scale &&
       (size_t)p.B * p.H * p.W * p.Cin < ((size_t)1 << 31)) {
     const long wins = (long)p.B * ((p.OW + 7) >> 3) * ((p.OH + 7) >> 3);
     if (((long)p.B * p.OH * p.OW * 10 >= wins * 64 * 8 && wins >= 3 * YL_NUM_CU) || (p.dev & YL_DEV_DWL_ALL)) {
@@ -1898,7 +1904,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
   const int WX = (OW + 7) >> 3, WY = (OH + 7) >> 3;
   const int wimg = WX * WY;
   const long WTOT = (long)p.B * wimg;                            // windows
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const long zdelta = p.zeros - p.x;
   const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wp);
   const long wgmax = (long)KB * NTtot - 1;                       // last weight piece
@@ -2153,7 +2159,7 @@ __global__ __launch_bounds__(NW * 64, 2) void yl_conv_dws_kernel(YlConvP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
   const int KB = p.KB, NTtot = p.NTtot, Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW;
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const long zdelta = p.zeros - p.x;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);                     // [2][S][NTW][64] float4
   f32x4* tl = wl + (size_t)2 * S * NTW * 64;                         // [2][S][TQP] float4: row t = tap t (t = TAPS: bias), 4 quads
@@ -2182,7 +2188,7 @@ __global__ __launch_bounds__(NW * 64, 2) void yl_conv_dws_kernel(YlConvP p) {
         const int kb = c * S + j;
         const int idx = r * 64 + lane, t = idx >> 2, ch = kb * 16 + (idx & 3) * 4;
         if (kb < KB && idx < TQ) {
-          const float* src = (ch < Cin) ? (t < TAPS ? p.dw_w + (size_t)t * Cin + ch : (p.dw_b ? p.dw_b + ch : p.zeros)) : p.zeros;
+          const float* src = (ch < Cin) ? (t < TAPS ? p.dw_w + (size_t)t * Cin + ch : (p.dw_b ? p.dw_b + ch : reinterpret_cast<const float*>(p.zeros))) : reinterpret_cast<const float*>(p.zeros);
           yl_glds16(src, tl + ((size_t)(buf * S + j) * TQP + r * 64));
         }
       }
@@ -2415,7 +2421,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
   const int TW = (OW + 1) >> 1, TH = (OH + 1) >> 1;
   const int timg = TW * TH;
   const long T = (long)p.B * timg;                            // Winograd tiles
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const long zdelta = p.zeros - p.x;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][16][NT][64] float4
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wino);
@@ -2571,7 +2577,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
               const size_t o = (((size_t)b * OH + oy) * OW + ox) * N + n;
               f32x4 v = yl_actc(y[a][c2] + bias, p.act, lo, hi);
               if (p.res) v += yl_ld4(p.res + o);                     // residual after the activation (yl_epi_generic's order)
-              *reinterpret_cast<f32x4*>(p.out + o) = v;
+              yl_st4(p.out + o, v);
             }
           }
       }
@@ -2651,7 +2657,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
   const int MX = (TW + 3) >> 2, MY = (TH + 3) >> 2;
   const int mimg = MX * MY;
   const long MTOT = (long)p.B * mimg;                           // m-tiles
-  const float* const xin = p.x;
+  const yl_act_t* const xin = p.x;
   const long zdelta = p.zeros - p.x;
   const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wino);
   const int NG2 = (p.NTtot + 1) >> 1;                           // n-tile pairs of the U image
@@ -2869,7 +2875,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
             const size_t o = (((size_t)eb * OH + oy) * OW + ox) * N + n;
             f32x4 v = yl_actc(yy[c2] + bias, p.act, lo, hi);
             if (p.res) v += yl_ld4(p.res + o);
-            *reinterpret_cast<f32x4*>(p.out + o) = v;
+            yl_st4(p.out + o, v);
           }
         }
       }

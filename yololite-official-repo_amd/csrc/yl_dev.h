@@ -20,6 +20,16 @@ __device__ __forceinline__ f32x4 yl_act4(f32x4 v, int act) {
   return r;
 }
 __device__ __forceinline__ f32x4 yl_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void yl_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// fp16 activation tensors (the fp16-storage unit, yl_internal.h: yl_act_t): four consecutive channels are ONE 8-byte access;
+// arithmetic stays fp32 (loads widen exactly, stores round to nearest even like torch's autocast casts)
+typedef _Float16 yl_h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 yl_ld4(const _Float16* p) {
+  return __builtin_convertvector(*reinterpret_cast<const yl_h16x4*>(p), f32x4);
+}
+__device__ __forceinline__ void yl_st4(_Float16* p, f32x4 v) {
+  *reinterpret_cast<yl_h16x4*>(p) = __builtin_convertvector(v, yl_h16x4);
+}
 
 
 // clamp to [lo,hi] in ONE VALU op per element (v_med3_f32).  fp32 MFMA and fp32 VALU share the SIMD's FMA

@@ -12,6 +12,21 @@ struct YlPix {
   size_t lin;        // linear output pixel index (clamped)
 };
 
+// store 4 consecutive channels / one channel at ELEMENT offset e of the layer's output tensor.  In the fp16-storage unit the
+// tensor is fp16 unless the layer says out_f32 (head outputs -> the fp32 detection levels, the mask prototypes)
+__device__ __forceinline__ void yl_out4(const YlConvP& p, size_t e, f32x4 v) {
+#if defined(YL_F16S) && YL_F16S
+  if (p.out_f32) { yl_st4(reinterpret_cast<float*>(p.out) + e, v); return; }
+#endif
+  yl_st4(p.out + e, v);
+}
+__device__ __forceinline__ void yl_out1(const YlConvP& p, size_t e, float v) {
+#if defined(YL_F16S) && YL_F16S
+  if (p.out_f32) { reinterpret_cast<float*>(p.out)[e] = v; return; }
+#endif
+  p.out[e] = (yl_act_t)v;
+}
+
 // ReLU-family activations as a clamp with wave-uniform bounds; SiLU behind a uniform branch
 __device__ __forceinline__ f32x4 yl_actc(f32x4 v, int act, float lo, float hi) {
   if (YL_SMOOTH(act)) return yl_act4(v, act);
@@ -33,7 +48,7 @@ __device__ __forceinline__ void yl_epi_fast(const YlConvP& p, f32x4 (&acc)[MT][N
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (!px[mt].valid) continue;
-    float* orow = p.out + px[mt].lin * (p.ldo ? p.ldo : p.N);
+    const size_t orow = px[mt].lin * (p.ldo ? p.ldo : p.N);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = (nt0 + nt) * 16 + 4 * kq;
@@ -41,8 +56,8 @@ __device__ __forceinline__ void yl_epi_fast(const YlConvP& p, f32x4 (&acc)[MT][N
       if (add_bias) v += yl_ld4(p.bias + n);
       v = yl_clamp4(v, lo, hi);
       if (n < p.N) {
-        if (p.ldo) { orow[n] = v.x; orow[n + 1] = v.y; orow[n + 2] = v.z; orow[n + 3] = v.w; }   // rows of ldo floats: unaligned
-        else *reinterpret_cast<f32x4*>(orow + n) = v;
+        if (p.ldo) { yl_out1(p, orow + n, v.x); yl_out1(p, orow + n + 1, v.y); yl_out1(p, orow + n + 2, v.z); yl_out1(p, orow + n + 3, v.w); }   // rows of ldo floats: unaligned
+        else yl_out4(p, orow + n, v);
       }
     }
   }
@@ -68,7 +83,7 @@ __device__ __forceinline__ void yl_epi_generic(const YlConvP& p, f32x4 (&acc)[MT
       v = yl_act4(v, p.act);
       if (p.res) v += yl_ld4(p.res + obase + n);
       if (p.up) v += yl_ld4(p.up + up_off + n);
-      *reinterpret_cast<f32x4*>(p.out + obase + n) = v;
+      yl_out4(p, obase + n, v);
     }
   }
 }

@@ -60,15 +60,25 @@ struct YlNmsP {
   int* done;             // [B][64 ints = 256 bytes]: class -> group table written by group 0 for the merge kernel
 };
 
+// ---- activation element type of a translation unit.  fp32 everywhere except the FOURTH compilation of the conv units
+// (-DYL_BF16=1 -DYL_F16=1 -DYL_F16S=1, option "store_f16", round 6): activation tensors live in HBM as fp16 -- the storage side
+// of the reference's fp16 autocast (scripts/helpers/evaluate.py:399,415).  The struct layout is the same in every unit (these
+// are pointers); the element type only decides pointer arithmetic and the load / store helpers (yl_dev.h: yl_ld4 / yl_st4).
+#if defined(YL_F16S) && YL_F16S
+typedef _Float16 yl_act_t;
+#else
+typedef float yl_act_t;
+#endif
+
 // ---- conv layer parameters (one struct for all conv kernels) -----------------------------------
 struct YlConvP {
-  const float* x;        // input: NHWC [B,H,W,Cin]  (STEM: NCHW [B,Cin,H,W])
+  const yl_act_t* x;     // input: NHWC [B,H,W,Cin]  (STEM: the fp32 NCHW network input [B,Cin,H,W], whatever yl_act_t is)
   const float* wp;       // packed weights (see yl_api.cpp pack_* for the layouts)
   const float* bias;     // [Npad16] (zero padded) or nullptr
-  const float* res;      // residual NHWC [B,OH,OW,N] or nullptr
-  const float* up;       // NHWC [B,UH,UW,N] nearest-upsampled and added, or nullptr
-  float* out;
-  const float* zeros;    // >= 64 zero bytes in HBM: out-of-range taps load from here (no select after the load)
+  const yl_act_t* res;   // residual NHWC [B,OH,OW,N] or nullptr
+  const yl_act_t* up;    // NHWC [B,UH,UW,N] nearest-upsampled and added, or nullptr
+  yl_act_t* out;         // (out_f32: an fp32 tensor -- detection levels, mask prototypes -- also in the fp16-storage unit)
+  const yl_act_t* zeros; // >= 1 KiB of zero bytes in HBM: out-of-range taps load from here (no select after the load)
   const float* dw_w;     // [dw_k*dw_k][Cin] tap-major
   const float* dw_b;     // [Cin] or nullptr
   int B, H, W, Cin;      // input tensor
@@ -125,6 +135,9 @@ struct YlConvP {
   // output row pitch in floats when it is not N (0 = N): the mask-coefficient part of a split head-output conv stores
   // its 32 columns into rows of 5+C+NM floats (yl_epi_fast only; scalar stores: the rows are not 16-byte aligned)
   int ldo;
+  // fp16-storage mode: this layer's output tensor is fp32 all the same (head outputs -> the detection level buffers the
+  // decode / NMS / mask kernels read, the mask prototypes); 0 in the fp32-storage units
+  int out_f32;
 };
 
 // YlConvP::dev -- developer kernel-selection switches (A/B runs, bitwise kernel-equivalence tests); per context, never
@@ -270,3 +283,13 @@ hipError_t yl_conv_init_f16();
 hipError_t yl_convc_init_f16();
 hipError_t yl_launch_stemblock_f16(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init_f16();
+// fp16-STORAGE builds (fourth compilation, -DYL_BF16=1 -DYL_F16=1 -DYL_F16S=1: option "store_f16"): fp16 operands and fp16
+// activation tensors in HBM; YlConvP's activation pointers are _Float16* in those units (same struct layout)
+hipError_t yl_launch_conv_f16s(const YlConvP& p, int tile_hint, hipStream_t st);
+hipError_t yl_launch_conv_multi_f16s(const YlConvP* ps, int n, int tile_hint, hipStream_t st);
+hipError_t yl_launch_stem_f16s(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_dw_f16s(const YlConvP& p, hipStream_t st);
+hipError_t yl_conv_init_f16s();
+hipError_t yl_convc_init_f16s();
+hipError_t yl_launch_stemblock_f16s(const YlConvP& p, hipStream_t st);
+hipError_t yl_stemblock_init_f16s();

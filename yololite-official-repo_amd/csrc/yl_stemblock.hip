@@ -194,13 +194,15 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
 
   // staging of the input block under the patch of tile (g_b, g_ty, g_tx): issued for tile t+1 during tile t's 3x3 phase
   // (one or two LDS-DMA rows per MFMA step), consumed by tile t+1's stem phase after an s_waitcnt vmcnt(0).
-  const float* g_xo = p.x;                            // interior staging in flight: uniform base of its input block
+  const float* const xnet = reinterpret_cast<const float*>(p.x);   // the network input: fp32 NCHW in every build
+  const float* const zf = reinterpret_cast<const float*>(p.zeros);
+  const float* g_xo = xnet;                           // interior staging in flight: uniform base of its input block
   bool g_int = false;
   auto gather_piece = [&](int k) { yl_glds16(g_xo + goff[k], stage + k * 256); };
   auto gather = [&]() {
     const int sy0 = 2 * g_ty * SB_TR - 1, sx0 = 2 * g_tx * SB_TC - 1;
     const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;
-    const float* xb = p.x + (size_t)g_b * 3 * plane;
+    const float* xb = xnet + (size_t)g_b * 3 * plane;
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + SB_PR <= p.SH && sx0 + SB_PC <= p.SW && iy0 >= 0 && ix0 >= 0 &&
                           iy0 + SB_SROWS <= p.H && ix0 + SB_SCOLS <= p.W &&
                           (ix0 + SB_SP <= p.W || iy0 + SB_SROWS < p.H || g_b + 1 < p.B);   // column 35: inside the tensor
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
         const int c = seg / SB_SROWS, r = seg - c * SB_SROWS;
         const int iy = iy0 + r, ix = ix0 + col;
         const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        yl_glds4(in ? xb + c * plane + (long)iy * p.W + ix : p.zeros, stage + k * 64);
+        yl_glds4(in ? xb + c * plane + (long)iy * p.W + ix : zf, stage + k * 64);
       }
     }
   };
@@ -236,13 +238,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
   // behind stores issued a moment earlier
   constexpr int NTO = NT3 > 0 ? NT3 : NT2;
   f32x4 ov[NTO];
-  float* o_row = p.out;
+  yl_act_t* o_row = p.out;
   bool o_valid = false;
   auto flush_out = [&]() {
 #pragma unroll
     for (int nt = 0; nt < NTO; ++nt) {
       const int n = nt * 16 + 4 * kq;
-      if (o_valid && n < Nout) *reinterpret_cast<f32x4*>(o_row + n) = ov[nt];
+      if (o_valid && n < Nout) yl_st4(o_row + n, ov[nt]);
     }
   };
 
