@@ -40,7 +40,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--json":
             for r in csv.DictReader(f):
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in acc.items():
-            if "yl_" not in k:
+            if "yl_" not in k or "yl_spin_kernel" in k:          # (the stream-overlap probe of context / pipeline creation)
                 continue
             for c, v in d.items():
                 if c not in tot:
