@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PEAK_16BIT_MFMA_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak (same guide); the reduced-precision modes' roof
 RIDGE = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)   # 19.7 FLOP/B
 
 
@@ -678,10 +679,16 @@ def measure_predict(args, model_name, B, seg, dev, rank, world, gather, min_seco
         if wino:                  # Winograd F(2x2,3x3) executes 16 multiplications where the direct conv has 36
             flops = flops * 16.0 / 36.0
         byts = float(L.bytes_in + L.bytes_out) * B
+        lowp = bool(args.bf16 or args.f16 or args.store_f16)
+        if args.store_f16:        # fp16 activation tensors: half the bytes, except the fp32 network input of an entry layer
+            entry = L.op in (0, 3, 9)                                      # OP_STEM, OP_STEMBLOCK, OP_NHWC4
+            byts = float((L.bytes_in if entry else 0.5 * L.bytes_in) + 0.5 * L.bytes_out) * B
+        # reduced-precision modes run on the 16-bit matrix pipe: dense peak 2.5 PFLOP/s (MI355X_MICROARCH.md), ridge 312 FLOP/B
+        peak_tf = PEAK_16BIT_MFMA_TFLOPS if lowp else PEAK_FP32_MFMA_TFLOPS
         ai = flops / byts
         dur = lay[k] * 1e-3
-        if ai >= RIDGE:
-            roof = {"bound": "mfma", "achieved": round(flops / dur / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s"}
+        if ai >= peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9):
+            roof = {"bound": "mfma", "achieved": round(flops / dur / 1e12, 3), "peak": peak_tf, "unit": "TFLOP/s"}
         else:
             roof = {"bound": "hbm", "achieved": round(byts / dur / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)

@@ -275,7 +275,16 @@ yl_status yl_read_slot(yl_ctx* ctx, int32_t slot, int32_t batch, float* dst_dev,
  * operands (weights and activations) to bf16 in registers and issues v_mfma_f32_16x16x16_bf16 with fp32 accumulation;
  * tensors stay fp32 in HBM; raw logits within 3e-2 of the level maximum),
  * "mfma_f16" (0/1, default 0: the same with fp16 operands on v_mfma_f32_16x16x16_f16 -- 11 mantissa bits instead of 8:
- * raw logits within 4e-3 of the level maximum; exclusive with "mfma_bf16"). */
+ * raw logits within 4e-3 of the level maximum; exclusive with "mfma_bf16"),
+ * "store_f16" (0/1, default 0, round 6: "mfma_f16" AND fp16 ACTIVATION TENSORS IN HBM -- the storage side of the reference's
+ * fp16 autocast, scripts/helpers/evaluate.py:399,415.  Every activation tensor between two launches is fp16 (arenas are
+ * planned at 2 bytes per element, loads widen, stores round to nearest even, arithmetic and accumulation fp32); the network
+ * input, the detection level tensors, the mask prototypes and the squeeze-excite gates stay fp32, and so do the packed
+ * weights (they are L2 / Infinity-Cache resident: 2.3 MB for edge_n).  MFMA tiles are the 16x16x16 fp16 ones of "mfma_f16".
+ * Kernels that stage activations by raw LDS-DMA copies (window-in-LDS depthwise, Winograd) give way to their tap-load
+ * predecessors in this mode; models with the hgnetv2 / convnextv2 element-wise ops are refused at the first forward
+ * (YL_ERR_UNSUPPORTED); yl_read_slot hands out fp32 and refuses fp16 slots.  Raw logits within 8e-3 of the level maximum
+ * (measured 3.7e-3 .. 5.9e-3 at 640x640); exclusive with the other two modes; never the parity path). */
 yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
 /* Current value of an option (the library's default if it was never written; values are stored clamped to the
  * option's range, e.g. "streams" 1..4).  YL_ERR_INVALID for an unknown name.  Also "dev_select" (default 0): a word of
@@ -288,7 +297,8 @@ yl_status yl_set_option(yl_ctx* ctx, const char* name, int32_t value);
  * grids of <= 20 x 20 pixels with one wave per tile instead of the split-K form, 11: Winograd layers through the first
  * kernel form (every transform position in one wave), 12-13: item shape of the position-split Winograd kernel (0 auto),
  * 14: depthwise 3x3 -> wide 1x1 layers with the taps from L1/L2 instead of the window-in-LDS kernel, 15: that kernel on
- * every grid it supports).                                                                                         */
+ * every grid it supports, 16: the fused head launch with the taps from L1/L2 (yl_conv_dpp_kernel) instead of the
+ * window-in-LDS form (yl_conv_dpw_kernel)).                                                                         */
 yl_status yl_get_option(const yl_ctx* ctx, const char* name, int32_t* value);
 /* Host-side query, no device needed: would yl_create accept a fused inverted-residual block (yl_layer with c2 > 0:
  * 1x1 expand c_in -> c_mid, depthwise dw_k x dw_k stride dw_stride, 1x1 project c_mid -> c_out) producing an
