@@ -340,7 +340,7 @@ def kernel_family(L, winograd=False, out_hw=None, batch=1):
     winograd: this layer runs as Winograd (see wino_layers); out_hw / batch: output grid and images per launch (the
     round-5 kernels with 8 x 8-pixel windows take a layer only where the grid fills them, yl_convc.hip)."""
     if L.op == 3:
-        return "yl_stemblock_kernel"
+        return "yl_stemdw_kernel" if L.dw_k == 3 else "yl_stemblock_kernel"
     if L.op == 4:
         return "yl_se_gate_kernel"
     if L.op != 1:

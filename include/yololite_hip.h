@@ -101,7 +101,9 @@ typedef struct {
   int32_t act;                /* YL_ACT_* applied after bias                                      */
   int32_t in_shift;           /* YL_OP_CONV, k>1, no prologue: the conv reads its input nearest-upsampled by
                                  2^in_shift (F.interpolate(scale_factor=2) folded into the tap addressing)   */
-  int32_t dw_k;               /* YL_OP_CONV only: 0 = none, else depthwise kxk prologue on input  */
+  int32_t dw_k;               /* YL_OP_CONV: 0 = none, else depthwise kxk prologue on input.  YL_OP_STEMBLOCK (round 6): 3 = the
+                               * second conv is DEPTHWISE 3x3 stride 1 pad 1 (w2 [c1][1][3][3], c2 == cout == 32) followed by
+                               * the 1x1 w3 -- timm's EfficientNet-Lite entry conv_stem -> blocks.0.0 as one launch            */
   int32_t dw_stride, dw_pad_t, dw_pad_l, dw_act;
   const float* w;             /* CONV/STEM: [cout][cin][k][k]; DW: [cout][1][k][k]                */
   const float* b;             /* [cout] or NULL                                                   */

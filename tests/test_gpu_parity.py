@@ -369,6 +369,33 @@ def test_fp16_storage_mode_refuses_the_fp32_only_ops():
     m(_x(2, 96, seed=1).to(DEV))
 
 
+@pytest.mark.parametrize("name,S,B", [("yololite_m", 224, 3), ("yololite_n", 352, 2), ("yololite_xl", 160, 2), ("yololite_m", 640, 5)])
+def test_fused_efficientnet_lite_entry_equals_the_two_launches(name, S, B):
+    """yl_stemdw_kernel (round 6): conv_stem (TF-SAME, 3 -> 32) -> blocks.0.0 (depthwise 3x3 + 1x1, 32 -> 16 / 24) of the
+    tf_efficientnet_lite backbones as ONE launch against the same model built with fuse_stem=False (plain stem kernel, then the
+    depthwise -> 1x1 kernel).  The stem GEMM sums its 27 products in another order (bias in the K pad slot), so the comparison
+    is a tolerance, not bitwise: every level within 2e-5 of its largest logit (and both within the oracle's bar, as the zoo sweep
+    checks).  224 / 352 / 160: grids of 14 / 22 / 10 tiles with every border case; lite4's 24-channel 1x1 (two n-tiles);
+    bitwise repeatable and batch-invariant."""
+    meta = zoo_meta(name, 80, S)
+    sd = synth_state_dict(meta, seed=7)
+    x = _x(B, S, seed=8)
+    fused = _hip_for(meta, sd)
+    from yololite_amd.model import YOLOLiteHIP
+    plain = YOLOLiteHIP(meta, fuse_stem=False)
+    plain.load_state_dict(sd); plain.to(DEV)
+    assert fused.program.layers[0].op == _lib.OP_STEMBLOCK and fused.program.layers[0].dw_k == 3
+    assert plain.program.layers[0].op == _lib.OP_STEM and len(plain.program.layers) == len(fused.program.layers) + 1
+    a = [t.clone() for t in fused(x.to(DEV))]
+    b = plain(x.to(DEV))
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-6
+    for u, v in zip(fused(x.to(DEV)), a):
+        assert torch.equal(u, v)
+    for u, v in zip(fused(x[1:2].to(DEV)), a):
+        assert torch.equal(u, v[1:2])
+
+
 def test_lanes_and_chunk_graphs_are_bitwise_the_plain_path():
     """side-stream lane for the coarse-level neck/head layers + one hipGraph per batch chunk: same bits as the
     single-stream eager path (scheduling must not change results)."""

@@ -848,6 +848,10 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
             : c->opt_bf16 == 3 ? yl_launch_conv_f16s(p, c->opt_tile_m, ls) : yl_launch_conv(p, c->opt_tile_m, ls);
         break;
       case YL_OP_STEMBLOCK:
+        if (d.dw_k == 3)
+          e = c->opt_bf16 == 1 ? yl_launch_stemdw_bf16(p, ls) : c->opt_bf16 == 2 ? yl_launch_stemdw_f16(p, ls)
+              : c->opt_bf16 == 3 ? yl_launch_stemdw_f16s(p, ls) : yl_launch_stemdw(p, ls);
+        else
         e = c->opt_bf16 == 1 ? yl_launch_stemblock_bf16(p, ls) : c->opt_bf16 == 2 ? yl_launch_stemblock_f16(p, ls)
             : c->opt_bf16 == 3 ? yl_launch_stemblock_f16s(p, ls) : yl_launch_stemblock(p, ls);
         break;
@@ -1490,7 +1494,12 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       if (!l.w2 || l.c2 < 1 || l.c3 < 0 || (l.c3 > 0 && !l.w3)) return bad("stem block needs w2 (and w3 when c3 > 0)");
       if (YL_SMOOTH(l.act) || YL_SMOOTH(l.act2) || YL_SMOOTH(l.act3))
         return fail(c, YL_ERR_UNSUPPORTED, "stem block: ReLU-family activations only");
-      if (!yl_stemblock_supported(l.cout, l.c2, l.c3))
+      if (l.dw_k == 3) {       // second conv DEPTHWISE 3x3 stride 1 pad 1, then the 1x1: the EfficientNet-Lite entry (yl_stemdw_kernel)
+        if (l.cout != 32 || l.c2 != 32 || l.c3 < 4 || l.c3 > 32 || (l.c3 & 3) || !l.w3 || l.dw_stride != 1 || l.dw_pad_t != 1 || l.dw_pad_l != 1)
+          return fail(c, YL_ERR_UNSUPPORTED, "stem block with a depthwise second conv: 3 -> 32 -> dw3x3 s1 pad 1 -> 1x1 (4..32 outputs)");
+      } else if (l.dw_k != 0) {
+        return fail(c, YL_ERR_UNSUPPORTED, "stem block: dw_k must be 0 (dense 3x3 s2 second conv) or 3 (depthwise 3x3 s1)");
+      } else if (!yl_stemblock_supported(l.cout, l.c2, l.c3))
         return fail(c, YL_ERR_UNSUPPORTED, "stem block: c1 in {16,32}, c2,c3 <= 32 and multiples of 4");
     } else if (l.op == YL_OP_STEM) {
       L.in_h = L.in_w = d->img_size;
@@ -1552,7 +1561,7 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
     }
     if (l.op == YL_OP_STEMBLOCK) {
       const int sh = (L.in_h + 2 * 0 + l.pad_t + (l.k - 1 - l.pad_t) - l.k) / l.stride + 1;   // symmetric / SAME stem
-      if (L.out_h != (sh + 2 - 3) / 2 + 1 || L.out_w != L.out_h) return bad("stem block output size mismatch");
+      if (L.out_h != (l.dw_k == 3 ? sh : (sh + 2 - 3) / 2 + 1) || L.out_w != L.out_h) return bad("stem block output size mismatch");
     } else {
       const bool pro = (l.op == YL_OP_CONV && l.dw_k > 0);
       const int st = pro ? l.dw_stride : l.stride, pt = pro ? l.dw_pad_t : l.pad_t, pl = pro ? l.dw_pad_l : l.pad_l;
@@ -1587,6 +1596,11 @@ yl_status yl_create(const yl_model_desc* d, int32_t device_id, yl_ctx** out) {
       if (l.b) memcpy(bias.data(), l.b, l.cout * sizeof(float));
       if (l.op == YL_OP_STEMBLOCK) {
         std::vector<float> w2, b2v((size_t)cdiv(l.c2, 16) * 16, 0.0f);
+        if (l.dw_k == 3) {                                           // depthwise taps [c][1][3][3] -> tap-major [9][c]
+          w2.assign((size_t)9 * l.c2, 0.0f);
+          for (int ch = 0; ch < l.c2; ++ch)
+            for (int t = 0; t < 9; ++t) w2[(size_t)t * l.c2 + ch] = l.w2[(size_t)ch * 9 + t];
+        } else
         pack_conv(l.w2, l.c2, l.cout, 3, w2);
         if (l.b2) memcpy(b2v.data(), l.b2, l.c2 * sizeof(float));
         if ((s = upload(c, w2, &L.w2p)) != YL_OK) return s;

@@ -222,6 +222,7 @@ hipError_t yl_launch_conv(const YlConvP& p, int tile_hint, hipStream_t st);
 hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStream_t st);   // n <= 4, same config
 hipError_t yl_launch_dw(const YlConvP& p, hipStream_t st);
 hipError_t yl_launch_stemblock(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_stemdw(const YlConvP& p, hipStream_t st);   // stem -> depthwise 3x3 s1 -> 1x1 (EfficientNet-Lite entry, round 6)
 hipError_t yl_stemblock_init();
 // depthwise 3x3 -> 1x1 -> 1x1 head output + decode as one launch (yl_dpp.hip)
 hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st);
@@ -275,6 +276,7 @@ hipError_t yl_launch_conv_bf16(const YlConvP& p, int tile_hint, hipStream_t st);
 hipError_t yl_launch_conv_multi_bf16(const YlConvP* ps, int n, int tile_hint, hipStream_t st);
 hipError_t yl_conv_init_bf16();
 hipError_t yl_launch_stemblock_bf16(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_stemdw_bf16(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init_bf16();
 // fp16-MFMA builds (third compilation, -DYL_BF16=1 -DYL_F16=1: option "mfma_f16")
 hipError_t yl_launch_conv_f16(const YlConvP& p, int tile_hint, hipStream_t st);
@@ -282,6 +284,7 @@ hipError_t yl_launch_conv_multi_f16(const YlConvP* ps, int n, int tile_hint, hip
 hipError_t yl_conv_init_f16();
 hipError_t yl_convc_init_f16();
 hipError_t yl_launch_stemblock_f16(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_stemdw_f16(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init_f16();
 // fp16-STORAGE builds (fourth compilation, -DYL_BF16=1 -DYL_F16=1 -DYL_F16S=1: option "store_f16"): fp16 operands and fp16
 // activation tensors in HBM; YlConvP's activation pointers are _Float16* in those units (same struct layout)
@@ -292,4 +295,5 @@ hipError_t yl_launch_dw_f16s(const YlConvP& p, hipStream_t st);
 hipError_t yl_conv_init_f16s();
 hipError_t yl_convc_init_f16s();
 hipError_t yl_launch_stemblock_f16s(const YlConvP& p, hipStream_t st);
+hipError_t yl_launch_stemdw_f16s(const YlConvP& p, hipStream_t st);
 hipError_t yl_stemblock_init_f16s();

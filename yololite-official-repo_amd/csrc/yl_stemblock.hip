@@ -23,6 +23,8 @@
 #define yl_launch_stemblock YL_LP_NAME(yl_launch_stemblock)
 #define yl_stemblock_init YL_LP_NAME(yl_stemblock_init)
 #define yl_stemblock_supported YL_LP_NAME(yl_stemblock_supported)
+#define yl_stemdw_kernel YL_LP_NAME(yl_stemdw_kernel)
+#define yl_launch_stemdw YL_LP_NAME(yl_launch_stemdw)
 #endif
 #include "yl_internal.h"
 #include "yl_dev.h"
@@ -408,6 +410,277 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemblock_kernel(YlConvP p) {
   flush_out();
 }
 
+// ------------------------------------------------------------------------------------------------
+// yl_stemdw_kernel (round 6): the EfficientNet-Lite entry as ONE launch -- stem 3x3 s2 (3 -> 32, TF-SAME or symmetric pads)
+// -> depthwise 3x3 s1 pad 1 (+BN+act) -> 1x1 (32 -> C3 <= 32, +BN): timm's conv_stem + bn1 and the DepthwiseSeparable block
+// blocks.0.0 of tf_efficientnet_lite0..4 behind model_v2.py:94-100 (yololite_m: lite2).  As two launches (plain stem kernel,
+// depthwise -> 1x1 kernel) the 32-channel stem output -- 13.1 MB per 640 x 640 image, the largest tensor of the network --
+// is written and read back: 0.237 + 0.178 ms and 840 MB of traffic at B = 32.
+// One WAVE owns an 8 x 8 output tile end to end (no workgroup barrier in the loop), like yl_stemblock_kernel:
+//   stage   the [3 channels x 21 rows] x 21 input columns under the tile's 10 x 10 stem patch land in the wave's LDS region
+//           by six LDS-DMA copies (interior tiles: uniform base + per-lane constant offsets; border tiles: dword-granular
+//           with per-lane bounds, out-of-image elements read the zero buffer), requested right after the previous tile's
+//           stem phase, so that they fly under its depthwise / 1x1 phases;
+//   stem    seven 16-pixel m-tiles (100 patch pixels): 7 ds_read_b32 per lane and m-tile, 7 x 2 MFMAs (the bias rides in the
+//           K = 27 -> 28 pad slot as in the stem block), clamp, zero outside the stem grid (the depthwise conv pads the STEM
+//           OUTPUT) -> wave-private patch [10][10][32 + 4];
+//   dw+pw   per output m-tile (two rows of eight pixels): the lane's 4 channels of both 16-channel blocks = bias + nine fma
+//           (tap weights resident in registers) from the patch, clamp = B fragments of the 1x1 GEMM (2 x NT3 x 4 MFMAs, A
+//           fragments resident in registers), + bias, clamp, one float4 NHWC store per lane.
+// 1.56x the stem's MFMAs for the patch halo (100 stem pixels per 64 outputs) -- the launch is bound by its 0.37 GB of
+// compulsory traffic and by VALU (288 fma per lane and tile), not by the matrix pipe.
+#define SD_T 8
+#define SD_P (SD_T + 2)
+#define SD_NP (SD_P * SD_P)
+#define SD_NM ((SD_NP + 15) / 16)
+#define SD_IR (2 * (SD_P - 1) + 3)
+#define SD_SP 24
+#define SD_NSEG (3 * SD_IR)
+#define SD_NCH (SD_NSEG * SD_SP / 4)
+#define SD_NSTG ((SD_NCH + 63) / 64)
+#define SD_NSTG1 ((SD_NSEG * SD_SP + 63) / 64)
+template <int NT3 /*ceil(C3/16)*/, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void yl_stemdw_kernel(YlConvP p) {
+  constexpr int NT1 = 2, C1 = 32, P1 = C1 + 4, KS = 7;
+  // the stage holds exactly the 63 x 24 staged floats (the last copy is masked to its 58 live lanes): 20448 B per wave, so that
+  // TWO 4-wave workgroups fit the 160 KiB of a CU (with whole 1 KiB copies: 2 x 82176 B = 512 B too many -- one wave per SIMD)
+  constexpr int PATCH_F = SD_NP * P1, WAVE_F = PATCH_F + SD_NSEG * SD_SP;
+  extern __shared__ __attribute__((aligned(16))) float sb_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  float* patch = sb_lds + wave * WAVE_F;
+  float* stage = patch + PATCH_F;
+  // ---- resident in registers: stem A fragments, depthwise taps + bias of the lane's channels, 1x1 A fragments + bias
+  float wa[KS][NT1];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) wa[s][nt] = p.wp[(s * NT1 + nt) * 64 + lane];
+#if YL_BF16
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) if (kq == 3) wa[6][nt] = 0.0f;
+  yl_s16x4 wab[2][NT1];
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) {
+    wab[0][nt] = yl_pk_bf16((f32x4){wa[0][nt], wa[1][nt], wa[2][nt], wa[3][nt]});
+    wab[1][nt] = yl_pk_bf16((f32x4){wa[4][nt], wa[5][nt], wa[6][nt], 0.0f});
+  }
+  f32x4 bias1[NT1];
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) bias1[nt] = yl_ld4(p.bias + nt * 16 + 4 * kq);
+  const bool slot6_lane = true;
+#else
+  const bool slot6_lane = kq != 3;                                   // lane group 3: the bias slot (input 1.0)
+#endif
+  f32x4 dww[9][NT1], dwb[NT1];
+#pragma unroll
+  for (int kb = 0; kb < NT1; ++kb) {
+    dwb[kb] = yl_ld4(p.b2 + kb * 16 + 4 * kq);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) dww[tap][kb] = yl_ld4(p.w2p + tap * C1 + kb * 16 + 4 * kq);
+  }
+  f32x4 w3r[NT1][NT3], bias3[NT3];
+#pragma unroll
+  for (int nt = 0; nt < NT3; ++nt) {
+    bias3[nt] = yl_ld4(p.b3 + nt * 16 + 4 * kq);
+#pragma unroll
+    for (int kb = 0; kb < NT1; ++kb) w3r[kb][nt] = reinterpret_cast<const f32x4*>(p.w3p)[(kb * NT3 + nt) * 64 + lane];
+  }
+  const int plane = p.H * p.W;
+  int tky[KS], tkx[KS], tc[KS], ks[KS];                               // tap decode of the lane's k slots: see yl_stemblock_kernel
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    int row, kx;
+    if (s < 3) { row = 2 * kq; kx = s; }
+    else if (s < 6) { row = 2 * kq + 1; kx = s - 3; }
+    else if (kq < 3) { row = 8; kx = kq; }
+    else { row = 7; kx = 2; }
+    tc[s] = row / 3; tky[s] = row - 3 * tc[s]; tkx[s] = kx;
+    ks[s] = (tc[s] * SD_IR + tky[s]) * SD_SP + tkx[s];
+  }
+  int goff[SD_NSTG];
+#pragma unroll
+  for (int k = 0; k < SD_NSTG; ++k) {
+    int e = k * 64 + lane;
+    e = e < SD_NCH ? e : SD_NCH - 1;
+    const int seg = e / (SD_SP / 4), ch = e - seg * (SD_SP / 4);
+    const int c = seg / SD_IR, r = seg - c * SD_IR;
+    goff[k] = c * plane + r * p.W + 4 * ch;
+  }
+  // the lane's patch pixel in each stem m-tile: stage base, patch write offset, patch coordinates
+  int mbase[SD_NM], mdst[SD_NM], mrc[SD_NM];
+#pragma unroll
+  for (int m = 0; m < SD_NM; ++m) {
+    const int q = 16 * m + pl, qq = q < SD_NP ? q : 0;
+    const int r = qq / SD_P, c = qq - r * SD_P;
+    mbase[m] = (2 * r) * SD_SP + 2 * c;
+    mdst[m] = qq * P1 + 4 * kq;
+    mrc[m] = (q < SD_NP ? 0 : (1 << 16)) | (r << 8) | c;
+  }
+  const float lo1 = (p.act == YL_ACT_NONE) ? -INFINITY : 0.0f, hi1 = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float lo2 = (p.act2 == YL_ACT_NONE) ? -INFINITY : 0.0f, hi2 = (p.act2 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const float lo3 = (p.act3 == YL_ACT_NONE) ? -INFINITY : 0.0f, hi3 = (p.act3 == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  const int ty = pl >> 3, tx = pl & 7;                               // lane's pixel inside an output m-tile (2 rows x 8 columns)
+  const int lr = (ty * SD_P + tx) * P1 + 4 * kq;                     // lane part of the patch read offset (+ (2 j + dy) rows, dx, kb)
+  const int C3 = p.C3;
+  const int tpr = (p.OW + SD_T - 1) / SD_T, tpc = (p.OH + SD_T - 1) / SD_T;
+  const int tiles_img = tpr * tpc, ntiles = p.B * tiles_img;
+  int r0, r1;                                                        // XCD bands (gridDim.x % 8 == 0), contiguous range per workgroup
+  {
+    const int gx = gridDim.x, bx = blockIdx.x;
+    if ((gx & 7) == 0) {
+      const int x = bx & 7, j = bx >> 3, nj = gx >> 3;
+      const long b0 = ((long)ntiles * x) >> 3, b1 = ((long)ntiles * (x + 1)) >> 3;
+      r0 = (int)(b0 + ((b1 - b0) * j) / nj); r1 = (int)(b0 + ((b1 - b0) * (j + 1)) / nj);
+    } else {
+      r0 = (int)(((long)ntiles * bx) / gx); r1 = (int)(((long)ntiles * (bx + 1)) / gx);
+    }
+  }
+  const float* const xnet = reinterpret_cast<const float*>(p.x);     // the network input: fp32 NCHW in every build
+  const float* const zf = reinterpret_cast<const float*>(p.zeros);
+  auto gather = [&](int tile) {                                      // stage the input block under `tile`'s stem patch
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tpr, txi = trem - tyi * tpr;
+    const int sy0 = tyi * SD_T - 1, sx0 = txi * SD_T - 1;
+    const int iy0 = sy0 * p.stride - p.pad_t, ix0 = sx0 * p.stride - p.pad_l;
+    const float* xb = xnet + (size_t)b * 3 * plane;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + SD_IR <= p.H && ix0 + SD_IR <= p.W &&
+                          (ix0 + SD_SP <= p.W || iy0 + SD_IR < p.H || b + 1 < p.B);   // columns 21..23: inside the tensor
+    if (interior) {
+      const float* xo = xb + (long)iy0 * p.W + ix0;
+#pragma unroll
+      for (int k = 0; k < SD_NSTG; ++k)
+        if (k + 1 < SD_NSTG || lane < SD_NCH - 64 * (SD_NSTG - 1)) yl_glds16(xo + goff[k], stage + k * 256);
+    } else {
+#pragma unroll
+      for (int k = 0; k < SD_NSTG1; ++k) {
+        int e = k * 64 + lane;
+        e = e < SD_NSEG * SD_SP ? e : SD_NSEG * SD_SP - 1;
+        const int seg = e / SD_SP, col = e - seg * SD_SP;
+        const int c = seg / SD_IR, r = seg - c * SD_IR;
+        const int iy = iy0 + r, ix = ix0 + col;
+        const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        if (k + 1 < SD_NSTG1 || lane < SD_NSEG * SD_SP - 64 * (SD_NSTG1 - 1)) yl_glds4(in ? xb + c * plane + (long)iy * p.W + ix : zf, stage + k * 64);
+      }
+    }
+  };
+  int tile = r0 + wave;
+  if (tile < r1) gather(tile);
+  while (tile < r1) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int tyi = trem / tpr, txi = trem - tyi * tpr;
+    const int sy0 = tyi * SD_T - 1, sx0 = txi * SD_T - 1;
+    const bool inner = sy0 >= 0 && sx0 >= 0 && sy0 + SD_P <= p.SH && sx0 + SD_P <= p.SW;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the staged input has landed (and the last tile's stores left)
+    // ---- stem on the 100 patch pixels -> wave-private patch
+#pragma unroll
+    for (int m = 0; m < SD_NM; ++m) {
+      float xs[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xs[s] = stage[mbase[m] + ks[s]];
+      f32x4 a1[NT1];
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) a1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if YL_BF16
+      {
+        const yl_s16x4 x0 = yl_pk_bf16((f32x4){xs[0], xs[1], xs[2], xs[3]});
+        const yl_s16x4 x1 = yl_pk_bf16((f32x4){xs[4], xs[5], xs[6], 0.0f});
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          a1[nt] = YL_MFMA16(wab[0][nt], x0, a1[nt]);
+          a1[nt] = YL_MFMA16(wab[1][nt], x1, a1[nt]);
+        }
+      }
+#else
+      const float x6 = slot6_lane ? xs[6] : 1.0f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], s == 6 ? x6 : xs[s], a1[nt], 0, 0, 0);
+#endif
+      const int r = (mrc[m] >> 8) & 255, c = mrc[m] & 255;
+      const bool live = (mrc[m] >> 16) == 0;
+      const int sy = sy0 + r, sx = sx0 + c;
+      const bool inside = inner || (sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW);   // else: the depthwise conv's zero padding
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) {
+#if YL_BF16
+        f32x4 v = yl_clamp4(a1[nt] + bias1[nt], lo1, hi1);
+#else
+        f32x4 v = yl_clamp4(a1[nt], lo1, hi1);
+#endif
+        if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (live) *reinterpret_cast<f32x4*>(patch + mdst[m] + nt * 16) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // patch writes of all lanes -> reads below; stage reads done
+    __builtin_amdgcn_wave_barrier();
+    const int next = tile + NWV;
+    if (next < r1) gather(next);                                     // in flight under the depthwise / 1x1 phases
+    // ---- depthwise 3x3 + 1x1 on the four output m-tiles
+    const int oy0 = tyi * SD_T, ox0 = txi * SD_T;
+#pragma unroll
+    for (int j = 0; j < SD_T / 2; ++j) {
+      f32x4 xq[NT1][1];
+#pragma unroll
+      for (int kb = 0; kb < NT1; ++kb) {
+        f32x4 q = dwb[kb];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(patch + lr + ((2 * j + tap / 3) * SD_P + tap % 3) * P1 + kb * 16);
+          q.x = fmaf(v.x, dww[tap][kb].x, q.x); q.y = fmaf(v.y, dww[tap][kb].y, q.y);
+          q.z = fmaf(v.z, dww[tap][kb].z, q.z); q.w = fmaf(v.w, dww[tap][kb].w, q.w);
+        }
+        xq[kb][0] = yl_clamp4(q, lo2, hi2);
+      }
+      f32x4 a3[1][NT3];
+#pragma unroll
+      for (int nt = 0; nt < NT3; ++nt) a3[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NT1; ++kb) yl_mma_step<NT3, 1>(w3r[kb], xq[kb], a3);
+      const int oy = oy0 + 2 * j + ty, ox = ox0 + tx;
+      if (oy < p.OH && ox < p.OW) {
+        yl_act_t* orow = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * C3;
+#pragma unroll
+        for (int nt = 0; nt < NT3; ++nt) {
+          const int n = nt * 16 + 4 * kq;
+          if (n < C3) yl_st4(orow + n, yl_clamp4(a3[0][nt] + bias3[nt], lo3, hi3));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // patch reads done before the next tile's writes
+    __builtin_amdgcn_wave_barrier();
+    tile = next;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no copy may land in LDS after the wave has ended
+}
+
+template <int NT3>
+static hipError_t sd_go(const YlConvP& p, hipStream_t st, bool attr_only) {
+  constexpr int NWV = 4;
+  const size_t lds = (size_t)NWV * (SD_NP * 36 + SD_NSEG * SD_SP) * 4;                 // 81792 B: two workgroups per CU
+  if (attr_only)
+    return hipFuncSetAttribute((const void*)yl_stemdw_kernel<NT3, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const long ntiles = (long)p.B * ((p.OW + SD_T - 1) / SD_T) * ((p.OH + SD_T - 1) / SD_T);
+  long gx = 2 * YL_NUM_CU;                                            // two 4-wave workgroups per CU (82 KB of LDS each)
+  if (gx > (ntiles + NWV - 1) / NWV) gx = (ntiles + NWV - 1) / NWV;
+  if (gx >= 8) gx &= ~7L;
+  hipLaunchKernelGGL((yl_stemdw_kernel<NT3, NWV>), dim3((unsigned)gx), dim3(NWV * 64), lds, st, p);
+  return hipGetLastError();
+}
+
+// stem 3x3 s2 (3 -> 32) -> depthwise 3x3 s1 pad 1 -> 1x1 (32 -> C3): p.w2p = depthwise taps [9][32], p.b2 [32], p.w3p / p.b3 the
+// packed 1x1 (two k-blocks), p.SH x p.SW the stem grid = the output grid
+hipError_t yl_launch_stemdw(const YlConvP& p, hipStream_t st) {
+  if (p.stride != 2 || p.k != 3 || p.C1 != 32 || p.C2 != 32 || p.C3 < 4 || p.C3 > 32 || (p.C3 & 3) || p.OH != p.SH || p.OW != p.SW)
+    return hipErrorInvalidValue;
+  return p.C3 <= 16 ? sd_go<1>(p, st, false) : sd_go<2>(p, st, false);
+}
+
 template <int NT1, int NT2, int NT3, int NWV>
 static hipError_t sb_launch(const YlConvP& p0, hipStream_t st, bool attr_only, size_t lds) {
   if (attr_only)
@@ -470,6 +743,8 @@ hipError_t yl_stemblock_init() {
   YlConvP p{};
   hipError_t e = sb_dispatch<1>(p, nullptr, true);
   if (e != hipSuccess) return e;
+  if ((e = sd_go<1>(p, nullptr, true)) != hipSuccess) return e;
+  if ((e = sd_go<2>(p, nullptr, true)) != hipSuccess) return e;
   return sb_dispatch<2>(p, nullptr, true);
 }
 

@@ -424,6 +424,23 @@ class _Builder:
                                    bytes_out=4 * oh * oh * cout))
         return o
 
+    def stemdw(self, prefix, eps, act, c1, c3, same):
+        """stem 3x3 s2 -> blocks.0.0 as a DepthwiseSeparable block (depthwise 3x3 s1 + 1x1, no residual) as ONE launch
+        (yl_stemdw_kernel, round 6): timm's EfficientNet-Lite entry, TF-SAME or symmetric stem padding."""
+        S = self.p.img_size
+        sh, pad = self.geom(S, 3, 2, same)
+        w1, b1 = self.fold(prefix + "conv_stem", prefix + "bn1", eps, False, (c1, 3, 3, 3))
+        w2, b2 = self.fold(prefix + "blocks.0.0.conv_dw", prefix + "blocks.0.0.bn1", eps, False, (c1, 1, 3, 3))
+        w3, b3 = self.fold(prefix + "blocks.0.0.conv_pw", prefix + "blocks.0.0.bn2", eps, False, (c3, c1, 1, 1))
+        o = self.slot(sh, sh, c3)
+        macs = sh * sh * c1 * 27 + sh * sh * (c1 * 9 + c1 * c3)
+        self.p.layers.append(Layer(_OP_STEMBLOCK, -1, o, 3, c1, 3, 2, pad, pad, _ACT[act], w1, b1,
+                                   c2=c1, act2=_ACT[act], c3=c3, act3=_ACT["none"], w2=w2, b2=b2, w3=w3, b3=b3,
+                                   dw_k=3, dw_stride=1, dw_pad_t=1, dw_pad_l=1,
+                                   name=prefix + "conv_stem+blocks.0.0", macs=macs, bytes_in=4 * 3 * S * S,
+                                   bytes_out=4 * sh * sh * c3))
+        return o
+
     def uib_fusable(self, x, cmid, cout, dk):
         """per-wave fused block (yl_uib_kernel; option fuse_uib): stride 1, grids multiples of 4"""
         h, w, c1 = self.dims(x)
@@ -764,8 +781,20 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
                    and s0[0]["type"] == "cn" and s0[0]["k"] == 3 and s0[0]["s"] == 2 and s0[0]["r"] == 1
                    and (len(s0) == 1 or (s0[1]["type"] == "cn" and s0[1]["k"] == 1 and s0[1]["s"] == 1 and s0[1]["r"] == 1))
                    and all(c <= 32 and c % 4 == 0 for c in c_s0))
+    # EfficientNet-Lite entry (round 6): stem -> DepthwiseSeparable blocks.0.0 (3x3 s1, no residual: the widths differ) as one
+    # launch; further repeats of stage 0 (depth multipliers > 1) follow as ordinary layers
+    s0_rep = s0[0]["r"] if (spec["dmult"] == 1.0 or (spec["fix_first_last"])) else int(math.ceil(s0[0]["r"] * spec["dmult"]))
+    fused_dw_entry = (b.fuse_stem and not fused_entry and act in ("relu", "relu6") and spec["stem"] == 32 and len(s0) == 1
+                      and s0[0]["type"] == "ds" and s0[0]["k"] == 3 and s0[0]["s"] == 1 and s0_rep == 1
+                      and 4 <= c_s0[0] <= 32 and c_s0[0] % 4 == 0 and c_s0[0] != spec["stem"]
+                      and b.p.img_size % 16 == 0)
     feats = []
-    if fused_entry:
+    if fused_dw_entry:
+        x = b.stemdw(prefix, eps, act, spec["stem"], c_s0[0], same)
+        cin, red = c_s0[0], 2
+        if _parse(arch[1][0])["s"] > 1:
+            feats.append((x, cin, red))
+    elif fused_entry:
         x = b.stemblock(prefix, eps, act, spec["stem"], c_s0[0], c_s0[1] if len(s0) == 2 else 0)
         cin, red = c_s0[-1], 4
         feats.append((-1, spec["stem"], 2))               # stem tap: never materialised, never consumed
@@ -777,7 +806,7 @@ def _backbone(b: _Builder, name: str, prefix: str = "backbone.") -> List[Tuple[i
         if s0[0]["s"] > 1:
             feats.append((x, cin, red))
     for si, stage in enumerate(arch):
-        if fused_entry and si == 0:
+        if (fused_entry or fused_dw_entry) and si == 0:
             continue
         bi = 0
         skip_next = False
