@@ -575,48 +575,62 @@ __global__ __launch_bounds__(NWV * 64, 2) void yl_stemdw_kernel(YlConvP p) {
     const int sy0 = tyi * SD_T - 1, sx0 = txi * SD_T - 1;
     const bool inner = sy0 >= 0 && sx0 >= 0 && sy0 + SD_P <= p.SH && sx0 + SD_P <= p.SW;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the staged input has landed (and the last tile's stores left)
-    // ---- stem on the 100 patch pixels -> wave-private patch
+    // ---- stem on the 100 patch pixels -> wave-private patch.  The seven stage reads of m-tile m + 1 are requested before the
+    // MFMAs of m-tile m (two register sets); two copies of the phase, selected by a wave-uniform branch: tiles whose patch lies
+    // inside the stem grid carry no padding logic
+    auto stem_phase = [&](auto inner_tag) {
+      constexpr bool INNER = decltype(inner_tag)::value;
+      float xs[2][KS];
 #pragma unroll
-    for (int m = 0; m < SD_NM; ++m) {
-      float xs[KS];
+      for (int s = 0; s < KS; ++s) xs[0][s] = stage[mbase[0] + ks[s]];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) xs[s] = stage[mbase[m] + ks[s]];
-      f32x4 a1[NT1];
+      for (int m = 0; m < SD_NM; ++m) {
+        if (m + 1 < SD_NM) {
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) a1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int s = 0; s < KS; ++s) xs[(m + 1) & 1][s] = stage[mbase[m + 1] + ks[s]];
+        }
+        const float (&x)[KS] = xs[m & 1];
+        f32x4 a1[NT1];
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) a1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #if YL_BF16
-      {
-        const yl_s16x4 x0 = yl_pk_bf16((f32x4){xs[0], xs[1], xs[2], xs[3]});
-        const yl_s16x4 x1 = yl_pk_bf16((f32x4){xs[4], xs[5], xs[6], 0.0f});
+        {
+          const yl_s16x4 x0 = yl_pk_bf16((f32x4){x[0], x[1], x[2], x[3]});
+          const yl_s16x4 x1 = yl_pk_bf16((f32x4){x[4], x[5], x[6], 0.0f});
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) {
+            a1[nt] = YL_MFMA16(wab[0][nt], x0, a1[nt]);
+            a1[nt] = YL_MFMA16(wab[1][nt], x1, a1[nt]);
+          }
+        }
+#else
+        const float x6 = slot6_lane ? x[6] : 1.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt)
+            a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], s == 6 ? x6 : x[s], a1[nt], 0, 0, 0);
+#endif
+        const bool live = (16 * m + 15 < SD_NP) || (mrc[m] >> 16) == 0;          // only the last m-tile has dead lanes
+        bool inside = true;
+        if (!INNER) {
+          const int sy = sy0 + ((mrc[m] >> 8) & 255), sx = sx0 + (mrc[m] & 255);
+          inside = sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW;                  // else: the depthwise conv's zero padding
+        }
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) {
-          a1[nt] = YL_MFMA16(wab[0][nt], x0, a1[nt]);
-          a1[nt] = YL_MFMA16(wab[1][nt], x1, a1[nt]);
+#if YL_BF16
+          f32x4 v = yl_clamp4(a1[nt] + bias1[nt], lo1, hi1);
+#else
+          f32x4 v = yl_clamp4(a1[nt], lo1, hi1);
+#endif
+          if (!INNER && !inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (live) *reinterpret_cast<f32x4*>(patch + mdst[m] + nt * 16) = v;
         }
       }
-#else
-      const float x6 = slot6_lane ? xs[6] : 1.0f;
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt)
-          a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][nt], s == 6 ? x6 : xs[s], a1[nt], 0, 0, 0);
-#endif
-      const int r = (mrc[m] >> 8) & 255, c = mrc[m] & 255;
-      const bool live = (mrc[m] >> 16) == 0;
-      const int sy = sy0 + r, sx = sx0 + c;
-      const bool inside = inner || (sy >= 0 && sy < p.SH && sx >= 0 && sx < p.SW);   // else: the depthwise conv's zero padding
-#pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) {
-#if YL_BF16
-        f32x4 v = yl_clamp4(a1[nt] + bias1[nt], lo1, hi1);
-#else
-        f32x4 v = yl_clamp4(a1[nt], lo1, hi1);
-#endif
-        if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (live) *reinterpret_cast<f32x4*>(patch + mdst[m] + nt * 16) = v;
-      }
-    }
+    };
+    if (inner) stem_phase(std::true_type{});
+    else stem_phase(std::false_type{});
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // patch writes of all lanes -> reads below; stage reads done
     __builtin_amdgcn_wave_barrier();
     const int next = tile + NWV;
