@@ -50,7 +50,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--json":
                 tot[c] += sum(full)
                 if c == "WRITE_SIZE":
                     ndisp += len(full)
-                    if "yl_stemblock_kernel" in k or "yl_stem_mfma_kernel" in k:
+                    if "yl_stemblock_kernel" in k or "yl_stem_mfma_kernel" in k or "yl_stemdw_kernel" in k:
                         steps = max(steps, len(full))
     if steps:
         per_step = {"fetch_kb": tot["FETCH_SIZE"] / steps, "write_kb": tot["WRITE_SIZE"] / steps, "steps": steps,
