@@ -438,12 +438,12 @@ yl_status ensure_act(yl_ctx* c, int B, int n) {
     c->plan_reuse = reuse;
     plan_slots(c, reuse);
     for (int i = 0; i < newn; ++i) {
-      if (c->arena_unit) HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)capi[i]));
+      if (c->arena_unit) HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)capi[i] + 256));   // (+256: yl_conv_wino2_kernel's unmasked channel tail)
       if (c->se_unit) HIPCHK(c, hipMalloc((void**)&c->se_scratch[i], c->se_unit * sizeof(float) * (size_t)capi[i]));
       c->arena_capi[i] = capi[i];
     }
     for (auto& s : c->slots)
-      if (s.pinned) HIPCHK(c, hipMalloc((void**)&s.pin, s.sz * (size_t)newB));
+      if (s.pinned) HIPCHK(c, hipMalloc((void**)&s.pin, s.sz * (size_t)newB + 256));
     for (int l = 0; l < c->L; ++l)
       HIPCHK(c, hipMalloc((void**)&c->level_buf[l],
                           (size_t)newB * c->level_A[l] * c->level_S[l] * c->level_S[l] * c->E * sizeof(float)));

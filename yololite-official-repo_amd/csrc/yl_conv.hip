@@ -1317,6 +1317,19 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
     const hipError_t es = yl_launch_conv_pws(p, st);
     if (es != hipErrorNotSupported) return es;
   }
+  if (n > 1 && p.dw_k == 0 && p.k == 1 && p.stride == 1 && tile_hint != 6 && p.dec_boxes && !p.dec_raw && p.NTtot == 6 && p.KB >= 5) {
+    // head outputs with many input channels (yololite_m: 328 -> 85): the levels with enough pixels each through
+    // yl_conv_pws_kernel's decode form (weights through LDS), the small ones together as before
+    YlConvP rest[4];
+    int nr = 0;
+    for (int k = 0; k < n; ++k) {
+      const hipError_t es = yl_launch_conv_pws(ps[k], st);
+      if (es == hipErrorNotSupported) rest[nr++] = ps[k];
+      else if (es != hipSuccess) return es;
+    }
+    if (nr == 0) return hipSuccess;
+    if (nr < n) return yl_launch_conv_multi(rest, nr, tile_hint, st);
+  }
   if (p.dw_k == 0 && p.k == 1 && p.stride == 1 && tile_hint != 6) {
     // (also the head-output layers of all levels in one launch when their decode runs in the epilogue)
     const hipError_t ep = yl_launch_conv_pwt_multi(ps, n, st);

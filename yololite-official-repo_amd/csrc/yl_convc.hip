@@ -1166,7 +1166,10 @@ hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
 // activation fragment of the next k-step requested before the MFMAs of this one; a wave reads its A fragments from
 // LDS in groups of <= 7 (28 VGPRs).  Per 16 pixels and k-step: one L1/L2 load + NT LDS reads for 4 NT MFMAs.  Same k
 // order (channel blocks ascending, four sub-steps each) and epilogues as yl_conv_pwt_kernel: bit-identical results.
-template <int NT, int NW, bool SC = false>
+// DEC (NT == 6, one n-group): the head output under yl_predict -- a wave holds whole rows of <= 96 logits and runs the decode
+// epilogue of yl_conv_pwt_kernel on them (yololite_m's 328 -> 85 outputs: 21 k-blocks of weights through LDS once per 64 / 128 pixels
+// instead of once per 32 through the vector-memory path).
+template <int NT, int NW, bool SC = false, bool DEC = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(YlConvP p) {
   constexpr int CH = 2;                                      // k-steps per weight chunk
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
@@ -1221,7 +1224,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
       if (!px[0].valid) lin = (size_t)M - 1;
       px[0].lin = lin;
       px[0].b = 0; px[0].oy = 0; px[0].ox = 0;
-      if (SC || p.up) {                                      // only the upsample-add epilogue / the gate need coordinates
+      if (SC || DEC || p.up) {                               // only the upsample-add / decode epilogues / the gate need coordinates
         const int b = (int)(lin / ohw);
         const int rem = (int)(lin - (size_t)b * ohw);
         px[0].b = b;
@@ -1256,8 +1259,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
       if (SC) v *= yl_ld4(ok ? srow + kb * 16 : reinterpret_cast<const float*>(p.zeros));     // x * gate (one rounding), then the GEMM
       return v;
     };
-    f32x4 xq = fetch(0);
-    for (int c = 0; c < NC; ++c, ++gchunk) {
+    // activation fragments PF k-steps ahead (a ring with compile-time slots: the chunk loop is unrolled by two).  One step ahead
+    // was 1 KB in flight per wave -- 16-32 KB per CU, which at the ~2 us of a loaded HBM / MALL round trip is ~2 TB/s over the
+    // chip: the 328 -> 85 head outputs and the 528 -> 88 projections sat on that, not on the matrix pipe.
+    constexpr int PF = 4;
+    f32x4 xr[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) xr[i] = fetch(i < KB ? i : KB - 1);
+    auto chunk = [&](auto par, int c) {
+      constexpr int P = decltype(par)::value;
       const int buf = (int)(gchunk & 1);
       // next chunk of the stream (this item's, or the first one of the workgroup's next item) into the other buffer
       if (gchunk + 1 < total_chunks) {
@@ -1267,12 +1277,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
       const f32x4* wb = wl + (size_t)buf * CH * NT * 64 + lane;
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
+        constexpr int dummy = 0; (void)dummy;
         const int kb = c * CH + j;
         if (kb < KB) {                                         // (workgroup-uniform) odd KB: the last chunk is half empty
-          const f32x4 xn = fetch(kb + 1 < KB ? kb + 1 : kb);
+          const int slot = (P * CH + j) % PF;
           constexpr int H0 = NT > 7 ? (NT + 1) / 2 : NT;       // A fragments in two groups: <= 28 VGPRs of them live
           constexpr int H1 = NT - H0;
-          f32x4 xs[1] = {xq};
+          f32x4 xs[1] = {xr[slot]};
+          xr[slot] = fetch(kb + PF < KB ? kb + PF : KB - 1);
           {
             f32x4 wq[H0], a0[1][H0];
 #pragma unroll
@@ -1290,11 +1302,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
 #pragma unroll
             for (int nt = 0; nt < H1; ++nt) acc[0][H0 + nt] = a1[0][nt];
           }
-          xq = xn;
         }
       }
       __syncthreads();             // every wave is done with `buf`; the copies into the other buffer have landed
+      ++gchunk;
+    };
+    for (int c = 0; c < NC; c += 2) {
+      chunk(std::integral_constant<int, 0>{}, c);
+      if (c + 1 < NC) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
+    if (DEC) { yl_epi_decode<NT, 1, false, true>(p, acc, px, 0, kq, lane); continue; }       // (one n-group: nt0 == 0)
     if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, 1>(p, acc, px, nt0, kq);
     else yl_epi_fast<NT, 1>(p, acc, px, nt0, kq, lo, hi, true);
   }
@@ -1303,8 +1320,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
 template <int NT, int NW>
 static hipError_t pws_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
   if (attr_only) {
-    const hipError_t e = hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return e;
+    if (NT == 6) {
+      e = hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT == 6 ? 6 : 6, NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      if (e != hipSuccess) return e;
+    }
     return hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   }
   YlConvP p = p0;
@@ -1313,7 +1334,10 @@ static hipError_t pws_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
   int gx = yl_resident_blocks_n(yl_conv_pws_kernel<NT, NW>, NW * 64, lds) & ~7;
   const int gy = (p.NTtot + NT - 1) / NT;
   while (gx > 8 && gx - 8 >= p.ntiles * gy) gx -= 8;
-  if (p.scale) hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW, true>), dim3(gx), dim3(NW * 64), lds, st, p);
+  if (p.dec_boxes) {
+    if (NT != 6 || p.scale) return hipErrorNotSupported;
+    hipLaunchKernelGGL((yl_conv_pws_kernel<6, NW, false, true>), dim3(gx), dim3(NW * 64), lds, st, p);
+  } else if (p.scale) hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW, true>), dim3(gx), dim3(NW * 64), lds, st, p);
   else hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
   return hipGetLastError();
 }
@@ -1330,7 +1354,9 @@ static hipError_t pws_nw(const YlConvP& p, hipStream_t st, bool eight, bool attr
 // plain 1x1 stride-1 layers (N % 4 == 0, no decode epilogue) with enough channels on both sides that the weight
 // stream pays: K >= 80 and >= 6 n-tiles.  hipErrorNotSupported otherwise (yl_conv_pwt_kernel runs the layer).
 hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
-  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || (p.N & 3) || p.dec_boxes) return hipErrorNotSupported;
+  const bool dec = p.dec_boxes && !p.dec_raw;                  // head output under yl_predict: rows of <= 96 logits, one n-group
+  if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || (p.dec_boxes && !dec)) return hipErrorNotSupported;
+  if (dec ? (p.NTtot != 6 || p.scale || p.res || p.up) : (p.N & 3) != 0) return hipErrorNotSupported;
   if ((p.dev & YL_DEV_PWS_OFF) || p.KB < 5 || p.NTtot < 6) return hipErrorNotSupported;     // (dev: A/B runs)
   // n-tiles per item, from {6..13}: the makespan of the launch in MFMA units -- (16-pixel x n-group) wave items dealt
   // to 1024 SIMDs, each NT x KB x 4 MFMAs long -- with a penalty when fewer than 1.5 waves per SIMD exist (one wave
@@ -1341,7 +1367,7 @@ hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
   double best = 1e30;
   long best_wi = 0;
   const long mt16 = ((long)p.M + 15) / 16;
-  for (int i = 0; i < 6; ++i) {
+  for (int i = dec ? 5 : 0; i < 6; ++i) {
     const long wi = mt16 * ((p.NTtot + cand[i] - 1) / cand[i]);
     const double sc = (double)((wi + 1023) / 1024) * cand[i] * (wi < 1536 ? 1.25 : 1.0);
     if (sc < best) { best = sc; NT = cand[i]; best_wi = wi; }
@@ -2658,8 +2684,6 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
   const int mimg = MX * MY;
   const long MTOT = (long)p.B * mimg;                           // m-tiles
   const yl_act_t* const xin = p.x;
-  const long zdelta = p.zeros - p.x;
-  const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wino);
   const int NG2 = (p.NTtot + 1) >> 1;                           // n-tile pairs of the U image
   const int G = (p.NTtot + NT - 1) / NT;
   const int bx = blockIdx.x, gx = gridDim.x;                    // gx % 8 == 0
@@ -2701,7 +2725,19 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
 
-  int soff[MT];                                                  // float offset of the lane's window slot (k-block 0), -1 = zeros
+  // Both operand streams go through raw buffer descriptors (round 6): the per-lane part of an address is ONE 32-bit byte
+  // offset fixed for the whole item, the k-block part is a scalar offset -- no vector instruction in the loop computes an
+  // address (the loop carried 14 64-bit adds and 8 selects for its ten requests).  Window lanes outside the image carry an
+  // offset beyond num_records: the hardware range check makes the copy write zeros.  The channel tail of the last k-block is
+  // not masked: those lanes copy the first channels of the next pixel (finite values; the context's arenas end in 256 spare
+  // bytes) and U is zero there (pack_wino pads with zeros), so the products are zeros as before.
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<yl_act_t*>(xin), 0, (int)((long)p.B * Hs * Ws * Cin * (long)sizeof(yl_act_t)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wino), 0, (int)((long)NG2 * KB * 16 * 2 * 1024), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const int lane16 = lane * 16;
+  unsigned voff[MT];                                             // byte offset of the lane's window slot (k-block 0), OOB = zeros
   auto setup = [&](int mblock) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -2711,37 +2747,42 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
       const int my = r / MX, mx = r - my * MX;
       const int gy = 8 * my - 1 + ry, gxx = 8 * mx - 1 + rx;
       const bool in = rpix && mi < MTOT && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
-      soff[mt] = in ? ((b * Hs + (gy >> SH)) * Ws + (gxx >> SH)) * Cin + 4 * rkq : -1;
+      voff[mt] = in ? (unsigned)((((b * Hs + (gy >> SH)) * Ws + (gxx >> SH)) * Cin + 4 * rkq) * (int)sizeof(yl_act_t)) : OOB;
     }
   };
   auto issue_raw = [&](int kb, int buf) {                        // branch-free: it is scheduled between MFMAs
 #if defined(YL_WINO_ABL) && (YL_WINO_ABL & 1)                    // ablation builds (tools/run_wino_abl.sh): results wrong
     if (kb > 0) return;
 #endif
-    const bool tail = kb * 16 + 4 * rkq >= Cin;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      yl_glds16((soff[mt] >= 0 && !tail) ? xin + soff[mt] + kb * 16 : xin + zdelta, Rl + (buf * MT + mt) * RM + wave * 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(Rl + (buf * MT + mt) * RM + wave * 64), 16,
+                                               (int)voff[mt], kb * 16 * (int)sizeof(yl_act_t), 0, 0);
   };
+  // Parity: the loop below is unrolled by two so that the window buffer and the U register set of a block are compile-time
+  // (LDS read offsets become immediates, no register renaming at the block's end).  Block kb uses buffer / set
+  // (kb + KB) & 1: the LAST block always sits in buffer 1, an odd KB starts with one single block out of buffer 1.
+  const int sh = KB & 1;
 
   int mb0 = 0, g = 0;
-  if (nmine > 0) { g = item_g(slot, mb0); setup(band0 + mb0); issue_raw(0, 0); }
+  if (nmine > 0) { g = item_g(slot, mb0); setup(band0 + mb0); issue_raw(0, sh); }
   for (int wi = 0; wi < nmine; ++wi) {
     const int mblock = band0 + mb0;
-    // U fragment of (n-tile g*NT + nt, k-block kb, position xi): pair-major image of pack_wino
-    size_t ub[NT];
+    // U fragment of (n-tile g*NT + nt, k-block kb, position xi): pair-major image of pack_wino; scalar byte offset
+    int ubs[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       int ntg = g * NT + nt;
       if (ntg >= 2 * NG2) ntg = 0;                                // beyond the image: any fragment (columns never stored)
-      ub[nt] = ((size_t)(ntg >> 1) * KB * 32 + (ntg & 1)) * 64 + lane;
+      ubs[nt] = (((ntg >> 1) * KB * 32 + (ntg & 1)) * 64 + 2 * wave * 128) * 16;
     }
-    auto load_u = [&](int kb, int xi, f32x4 (&dst)[NT]) {
+    auto load_u = [&](int kb, int ps, f32x4 (&dst)[NT]) {
 #if defined(YL_WINO_ABL) && (YL_WINO_ABL & 2)
       if (kb > 0) return;
 #endif
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) dst[nt] = wg[ub[nt] + (size_t)(kb * 16 + xi) * 128];
+      for (int nt = 0; nt < NT; ++nt)
+        dst[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, lane16, ubs[nt] + (kb * 16 + ps) * 2048, 0));
     };
     f32x4 acc[2][MT][NT];
 #pragma unroll
@@ -2757,9 +2798,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
       y[0] = wb[sY0]; y[1] = wb[sY1]; y[2] = wb[sY2];
     };
     auto make_b = [&](const f32x4 (&x)[3], const f32x4 (&y)[3], f32x4& b0, f32x4& b1) {
-      const f32x4 u0 = y[0] * sr4 + x[0], u1 = y[1] * sr4 + x[1], u2 = y[2] * sr4 + x[2];
-      b0 = u0 - u1;
-      b1 = u2 * sc4 + u1;
+      yl_wino_b(x, y, sr4, sc4, b0, b1);
     };
     auto mma_mt = [&](const f32x4 (&a)[NT], const f32x4& b, f32x4 (&c)[NT]) {    // one m-tile: the 4 steps x NT n-tiles
 #if YL_BF16
@@ -2777,9 +2816,6 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
         for (int nt = 0; nt < NT; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][st], b[st], c[nt], 0, 0, 0);
 #endif
     };
-    f32x4 a0[NT], a1[NT];
-    load_u(0, 2 * wave, a0);
-    load_u(0, 2 * wave + 1, a1);
     // One k-block: MT x (window reads of the next m-tile, B fragments, 2 x NT x 4 MFMAs).  The block's ONE barrier sits in
     // front of the LAST m-tile's MFMAs: by then the wave has read all it needs of window(kb) and its copies of
     // window(kb + 1) (requested a k-block ago) have landed, so behind the barrier window(kb + 1) is complete and window(kb)'s
@@ -2788,21 +2824,17 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
     // across k-blocks (with the barrier at the top of the block both waves of a SIMD met it with nothing to issue).
     // MODE 0: any block; 1: the second-to-last (nothing left to request); 2: the last (peeled like this so that the body
     // is branch-free: with conditional requests every merge waited for all outstanding loads).  The U fragments of block
-    // kb + 1 are requested into a second register set under the first two m-tiles and renamed at the end -- requested
-    // behind the last use of a0 / a1 they had no time to arrive.
+    // kb + 1 are requested into the OTHER register set under the first two m-tiles -- requested behind the last use of this
+    // block's set they had no time to arrive.  PAR = the block's window buffer and U set.
+    f32x4 ua[2][2][NT];                                           // [set][position][n-tile]
     f32x4 x[2][3], y[2][3];
-    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
-    __syncthreads();                                              // window(0) landed (requested under the previous epilogue)
-    issue_raw(1, 1);
-    load_win(0, 0, x[0], y[0]);
-    auto kblock = [&](int kb, auto mode) {
+    auto kblock = [&](int kb, auto par, auto mode) {
+      constexpr int PAR = decltype(par)::value;
       constexpr int MODE = decltype(mode)::value;
-      const int buf = kb & 1;
       WINO_STAMP(kb * 7 + 0);
-      f32x4 an0[NT], an1[NT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        if (mt + 1 < MT) load_win(buf, mt + 1, x[(mt + 1) & 1], y[(mt + 1) & 1]);
+        if (mt + 1 < MT) load_win(PAR, mt + 1, x[(mt + 1) & 1], y[(mt + 1) & 1]);
         f32x4 b0, b1;
         make_b(x[mt & 1], y[mt & 1], b0, b1);
         if (mt == MT - 1 && MODE < 2) {
@@ -2811,28 +2843,48 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
           __builtin_amdgcn_s_waitcnt(0x0070);                     // vmcnt(0) lgkmcnt(0): the wave's own window copies and reads (not left to the
           __syncthreads();                                        // compiler: LDS-DMA requests of the previous iteration are not carried over the back edge)
           WINO_STAMP(kb * 7 + 5);
-          if (MODE == 0) issue_raw(kb + 2, buf);
-          load_win(buf ^ 1, 0, x[0], y[0]);
+          if (MODE == 0) issue_raw(kb + 2, PAR);
+          load_win(PAR ^ 1, 0, x[0], y[0]);
           __builtin_amdgcn_sched_barrier(0);
           WINO_STAMP(kb * 7 + 6);
         }
-        mma_mt(a0, b0, acc[0][mt]);
-        if (MODE < 2 && mt == 0) load_u(kb + 1, 2 * wave, an0);
-        mma_mt(a1, b1, acc[1][mt]);
-        if (MODE < 2 && mt == (MT > 2 ? 1 : 0)) load_u(kb + 1, 2 * wave + 1, an1);
+        mma_mt(ua[PAR][0], b0, acc[0][mt]);
+        if (MODE < 2 && mt == 0) load_u(kb + 1, 0, ua[PAR ^ 1][0]);
+        mma_mt(ua[PAR][1], b1, acc[1][mt]);
+        if (MODE < 2 && mt == (MT > 2 ? 1 : 0)) load_u(kb + 1, 1, ua[PAR ^ 1][1]);
         // m-tile by m-tile: left alone the scheduler gathered all window reads at the top (spills) and pushed the U
         // requests behind the last MFMA
         __builtin_amdgcn_sched_barrier(0);
         if (mt < 3) WINO_STAMP(kb * 7 + 1 + mt);
       }
-      if (MODE < 2) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { a0[nt] = an0[nt]; a1[nt] = an1[nt]; }
-      }
     };
-    for (int kb = 0; kb + 2 < KB; ++kb) kblock(kb, std::integral_constant<int, 0>{});
-    kblock(KB - 2, std::integral_constant<int, 1>{});
-    kblock(KB - 1, std::integral_constant<int, 2>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    int kb = 0;
+    if (sh) {                                                     // odd KB: block 0 on its own, out of buffer / set 1
+      load_u(0, 0, ua[1][0]);
+      load_u(0, 1, ua[1][1]);
+      __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+      __syncthreads();                                            // window(0) landed (requested under the previous epilogue)
+      issue_raw(1, 0);
+      load_win(1, 0, x[0], y[0]);
+      kblock(0, I1{}, I0{});
+      kb = 1;
+    } else {
+      load_u(0, 0, ua[0][0]);
+      load_u(0, 1, ua[0][1]);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      issue_raw(1, 1);
+      load_win(0, 0, x[0], y[0]);
+    }
+    for (; kb + 3 < KB; kb += 2) {
+      kblock(kb, I0{}, I0{});
+      kblock(kb + 1, I1{}, I0{});
+    }
+    kblock(KB - 2, I0{}, I1{});
+    kblock(KB - 1, I1{}, I2{});
     // the item's coordinates for the epilogue, then the next item's window(0) request flies under the epilogue
     const int eg = g;
     const int emt = wave & (MT - 1), epart = wave / MT;            // output role: m-tile, row a (and column c2 when MT = 2)
@@ -2845,7 +2897,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
     const int oa = epart & 1;
     const int oy = 2 * (4 * emy + ty4) + oa, ox0 = 2 * (4 * emx + tx4);
     __syncthreads();                                              // every wave is done with the windows
-    if (wi + 1 < nmine) issue_raw(0, 0);
+    if (wi + 1 < nmine) issue_raw(0, sh);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if (nt > 0) __syncthreads();                                // the previous n-tile's exchange is read
@@ -2913,7 +2965,10 @@ hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st) {
     return hipErrorNotSupported;
   // second form (positions across the waves): K loops long enough to amortise the accumulator exchange, grids that fill
   // the 4 x 4-tile m-tiles; "dev_select" bit 11 keeps the first form (bitwise A/B), bits 12-13 pick a shape (A/B runs)
-  if (!(p.dev & YL_DEV_WINO_V1) && p.KB >= 4 && p.NTtot >= 3) {
+  // (second form: 32-bit byte offsets into the input tensor and the U image)
+  const bool small = (size_t)p.B * (p.H >> p.in_shift) * (p.W >> p.in_shift) * p.Cin * sizeof(yl_act_t) < ((size_t)1 << 31) &&
+                     (size_t)((p.NTtot + 1) / 2) * p.KB * 32768 < ((size_t)1 << 31);
+  if (!(p.dev & YL_DEV_WINO_V1) && p.KB >= 4 && p.NTtot >= 3 && small) {
     const int TW = (p.OW + 1) >> 1, TH = (p.OH + 1) >> 1;
     const int MX = (TW + 3) >> 2, MY = (TH + 3) >> 2;
     const long MTOT = (long)p.B * MX * MY;

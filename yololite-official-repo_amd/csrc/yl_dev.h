@@ -46,6 +46,34 @@ __device__ __forceinline__ f32x4 yl_fma4(f32x4 a, f32x4 b, f32x4 acc) {
   return (f32x4){lo.x, lo.y, hi.x, hi.y};
 }
 
+// B fragments of two Winograd positions from the six window reads of an m-tile (yl_conv_wino2_kernel): u_c = y_c * sr + x_c,
+// b0 = u0 - u1, b1 = u2 * sc + u1 as TEN packed instructions by name.  Inline asm because the instruction selector splits the
+// builtin form into scalar v_fma_f32 / v_sub_f32 pairs in register-tight loops (61 instead of 40 VALU instructions per k-block),
+// and on gfx950 a VALU instruction of one wave is matrix-pipe time of the SIMD's other wave.  The trailing s_nop 1: b0 / b1 are
+// MFMA operands, a VALU result needs two wait states before a matrix instruction reads it, and the hazard recognizer does not
+// look into asm statements (without it: wrong results).  fma(u1, -1, u0) would be the same bits as u0 - u1; v_pk_add_f32 with
+// the negate modifier needs no constant register.
+__device__ __forceinline__ void yl_wino_b(const f32x4 (&x)[3], const f32x4 (&y)[3], f32x4 sr4, f32x4 sc4, f32x4& b0, f32x4& b1) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  f32x2_ u[3][2];
+  const f32x2_ sr = (f32x2_){sr4.x, sr4.y}, sc = (f32x2_){sc4.x, sc4.y};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(u[c][0]) : "v"((f32x2_){y[c].x, y[c].y}), "v"(sr), "v"((f32x2_){x[c].x, x[c].y}));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(u[c][1]) : "v"((f32x2_){y[c].z, y[c].w}), "v"(sr), "v"((f32x2_){x[c].z, x[c].w}));
+  }
+  f32x2_ r0, r1, r2, r3;
+  asm("v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %1, %5, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %2, %8, %10, %6\n\t"
+      "v_pk_fma_f32 %3, %9, %10, %7\n\t"
+      "s_nop 1"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(u[0][0]), "v"(u[0][1]), "v"(u[1][0]), "v"(u[1][1]), "v"(u[2][0]), "v"(u[2][1]), "v"(sc));
+  b0 = (f32x4){r0.x, r0.y, r1.x, r1.y};
+  b1 = (f32x4){r2.x, r2.y, r3.x, r3.y};
+}
+
 __device__ __forceinline__ f32x4 yl_clamp4(f32x4 v, float lo, float hi) {
   f32x4 r;
   r.x = __builtin_amdgcn_fmed3f(v.x, lo, hi); r.y = __builtin_amdgcn_fmed3f(v.y, lo, hi);
