@@ -1922,7 +1922,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
   f32x4* const Wl = reinterpret_cast<f32x4*>(yl_clds);           // [3][NTP][64]
   f32x4* const Rl = Wl + 3 * NTP * 64;                           // [2 buffers][2 windows][RM]
-  float* const dwl = reinterpret_cast<float*>(Rl + 2 * 2 * RM);  // [9][Cin] taps, [Cin] bias
+  float* const dwl = reinterpret_cast<float*>(Rl + 2 * 2 * RM);  // [KB][10][16]: taps 0..8 + bias of a k-block's channels (zeros beyond Cin)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
@@ -1931,9 +1931,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
   const int wimg = WX * WY;
   const long WTOT = (long)p.B * wimg;                            // windows
   const yl_act_t* const xin = p.x;
-  const long zdelta = p.zeros - p.x;
-  const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wp);
-  const long wgmax = (long)KB * NTtot - 1;                       // last weight piece
+  const int wgmax = KB * NTtot - 1;                              // last weight piece
   const int bx = blockIdx.x, gx = gridDim.x;                     // gx % 8 == 0
   const int per = gx >> 3, slot = bx >> 3;
   const int tpx = (p.ntiles + 7) >> 3;                           // items per XCD band
@@ -1953,12 +1951,22 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
     const int P = (4 * qy + sy + tap / 3) * RP + 4 * qx + sx + tap % 3;
     ts[tap] = wsel * RM + 4 * P + (kq ^ (((P >> 2) & 1) << 1));
   }
-  {
-    const int nw = 9 * Cin;
-    yl_glds_floats(p.dw_w, dwl, nw, tid, 512);
-    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cin, tid, 512);
-    else for (int i = tid; i < Cin; i += 512) dwl[nw + i] = 0.0f;
+  // the tap image k-block-major, so that a lane's ten tap / bias reads of a block are ONE address + immediates
+  for (int i = tid; i < KB * 160; i += 512) {
+    const int kb = i / 160, r = i - kb * 160, t = r >> 4, ch = kb * 16 + (r & 15);
+    dwl[i] = ch < Cin ? (t < 9 ? p.dw_w[(size_t)t * Cin + ch] : (p.dw_b ? p.dw_b[ch] : 0.0f)) : 0.0f;
   }
+  // Operand streams through raw buffer descriptors (as yl_conv_wino2_kernel, round 6): the lane's part of an address is a 32-bit
+  // byte offset fixed for the item (window) or the launch (weights), the k-block part is scalar; lanes outside the image carry an
+  // out-of-range offset and the copy writes zeros.  The channel tail of the last k-block is not masked: those lanes copy the next
+  // pixel's first channels (the arenas end in 256 spare bytes), their tap weights here and their 1x1 weights are zeros.
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<yl_act_t*>(xin), 0, (int)((long)p.B * H * W * Cin * (long)sizeof(yl_act_t)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wp), 0, (int)((long)KB * NTtot * 1024), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const int lane16 = lane * 16;
+  const int sh = KB & 1;                                         // window(kb) lives in buffer (kb + KB) & 1: see yl_conv_wino2_kernel
   const bool pre_add = (p.res || p.up) && p.act == YL_ACT_NONE;
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
@@ -1966,32 +1974,31 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
   const float dhi = (p.dw_act == YL_ACT_RELU6) ? 6.0f : INFINITY;
   const int dw_act = p.dw_act;
 
-  int soff[2];
+  unsigned voff[2];
   auto issue_win = [&](int kb, int buf) {
-    const bool tail = kb * 16 + 4 * rkq >= Cin;
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2)
-      yl_glds16((soff[w2] >= 0 && !tail) ? xin + soff[w2] + kb * 16 : xin + zdelta, Rl + (buf * 2 + w2) * RM + wave * 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(Rl + (buf * 2 + w2) * RM + wave * 64), 16,
+                                               (int)voff[w2], kb * 16 * (int)sizeof(yl_act_t), 0, 0);
   };
   auto issue_wts = [&](int kb, int wb) {
 #pragma unroll
     for (int j = 0; j < NTP / 8; ++j) {
       const int i = wave + 8 * j;                                // (pieces NTT..NTP-1: pad, any valid source)
-      long src = (long)kb * NTtot + (i < NTT ? i : 0);
+      int src = kb * NTtot + (i < NTT ? i : 0);
       src = src < wgmax ? src : wgmax;
-      yl_glds16(wg + src * 64 + lane, Wl + ((size_t)wb * NTP + i) * 64);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(Wl + ((size_t)wb * NTP + i) * 64), 16,
+                                               lane16, src * 1024, 0, 0);
     }
   };
   auto make_b = [&](int kb, int buf) {
-    const int cc = kb * 16 + 4 * kq;
-    const int cs = cc < Cin ? cc : Cin - 4;
-    const float* tapw = dwl + cs;
+    const float* tapw = dwl + kb * 160 + 4 * kq;
     const f32x4* const wb = Rl + buf * 2 * RM;
-    f32x4 xq = yl_ld4(tapw + 9 * Cin);
+    f32x4 xq = yl_ld4(tapw + 9 * 16);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const f32x4 x = wb[ts[tap]];
-      const f32x4 w = yl_ld4(tapw + tap * Cin);
+      const f32x4 w = yl_ld4(tapw + tap * 16);
       xq.x = fmaf(x.x, w.x, xq.x); xq.y = fmaf(x.y, w.y, xq.y);
       xq.z = fmaf(x.z, w.z, xq.z); xq.w = fmaf(x.w, w.w, xq.w);
     }
@@ -2023,7 +2030,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
       const int wy = r / WX, wx = r - wy * WX;
       const int gy = 8 * wy - 1 + ry, gxx = 8 * wx - 1 + rx;
       const bool in = rpix && wi < WTOT && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
-      soff[w2] = in ? ((b * H + gy) * W + gxx) * Cin + 4 * rkq : -1;
+      voff[w2] = in ? (unsigned)((((b * H + gy) * W + gxx) * Cin + 4 * rkq) * (int)sizeof(yl_act_t)) : OOB;
     }
     f32x4 acc[1][NTT];
 #pragma unroll
@@ -2045,12 +2052,12 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
       }
     }
     __syncthreads();                                              // the previous item's last weight reads are done
-    issue_win(0, 0); issue_wts(0, 0);
-    issue_win(1, 1); issue_wts(1, 1);                             // (KB >= 12: the launcher)
+    issue_win(0, sh); issue_wts(0, 0);
+    issue_win(1, sh ^ 1); issue_wts(1, 1);                        // (KB >= 12: the launcher)
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
     __syncthreads();
     f32x4 xq[1];
-    xq[0] = make_b(0, 0);
+    xq[0] = make_b(0, sh);
     int wb = 0;
     f32x4 wq[2][4];                                               // A fragments of the current / the next MFMA group
     auto read_a = [&](int wbuf, int c, f32x4 (&dst)[4]) {
@@ -2068,7 +2075,8 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
     // between MFMA groups (a first version built B(kb + 1) in one piece between two halves of the block's MFMAs: both waves
     // of a SIMD waited there for 19 LDS reads with nothing to issue).  MODE 0 any block, 1 the second-to-last (no
     // requests), 2 the last (no next B): branch-free bodies.
-    auto kblock = [&](int kb, auto mode) {
+    auto kblock = [&](int kb, auto par, auto mode) {
+      constexpr int PAR = decltype(par)::value;                   // buffer of window(kb) (compile-time: LDS offsets are immediates)
       constexpr int MODE = decltype(mode)::value;
       const int wb1 = wb == 2 ? 0 : wb + 1;
       // the wave's own copies first: the compiler's wait-count pass does not carry the LDS-DMA requests of the previous
@@ -2079,14 +2087,12 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
       __syncthreads();
       WINO_STAMP(kb * 7 + 1);
       if (MODE == 0) {
-        issue_win(kb + 2, kb & 1);
+        issue_win(kb + 2, PAR);
         issue_wts(kb + 2, wb >= 1 ? wb - 1 : 2);                  // (wb + 2) % 3
       }
       WINO_STAMP(kb * 7 + 2);
-      const int cc = (kb + 1) * 16 + 4 * kq;
-      const int cs = cc < Cin ? cc : Cin - 4;
-      const float* const tapw = dwl + cs;
-      const f32x4* const win = Rl + ((kb + 1) & 1) * 2 * RM;
+      const float* const tapw = dwl + (kb + 1) * 160 + 4 * kq;
+      const f32x4* const win = Rl + (PAR ^ 1) * 2 * RM;
       f32x4 xn = xq[0];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -2094,9 +2100,9 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
         if (c + 1 < NCH) read_a(wb, c + 1, wq[(c + 1) & 1]);
         else if (MODE < 2) read_a(wb1, 0, wq[0]);
         if (MODE < 2 && c < 3) {
-          if (c == 0) xn = yl_ld4(tapw + 9 * Cin);
+          if (c == 0) xn = yl_ld4(tapw + 9 * 16);
 #pragma unroll
-          for (int t = 0; t < 3; ++t) { tx[t] = win[ts[3 * c + t]]; tw[t] = yl_ld4(tapw + (3 * c + t) * Cin); }
+          for (int t = 0; t < 3; ++t) { tx[t] = win[ts[3 * c + t]]; tw[t] = yl_ld4(tapw + (3 * c + t) * 16); }
         }
         __builtin_amdgcn_sched_barrier(0);
 #if YL_BF16
@@ -2117,7 +2123,7 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
         __builtin_amdgcn_sched_barrier(0);                        // (else the fma chain moves up to the group's first MFMA and waits there
         if (MODE < 2 && c < 3) {                                  //  for the reads issued a moment before)
 #pragma unroll
-          for (int t = 0; t < 3; ++t) xn = __builtin_elementwise_fma(tx[t], tw[t], xn);   // (two v_pk_fma_f32: the same fma per component)
+          for (int t = 0; t < 3; ++t) xn = yl_pk_fma4(tx[t], tw[t], xn);     // two v_pk_fma_f32 by name: the same fma per component
           if (c == 2) xn = yl_actc(xn, dw_act, dlo, dhi);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2126,9 +2132,19 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
       xq[0] = xn;
       wb = wb1;
     };
-    for (int kb = 0; kb + 2 < KB; ++kb) kblock(kb, std::integral_constant<int, 0>{});
-    kblock(KB - 2, std::integral_constant<int, 1>{});
-    kblock(KB - 1, std::integral_constant<int, 2>{});
+    {
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      int kb = 0;
+      if (sh) { kblock(0, I1{}, I0{}); kb = 1; }                  // odd KB: block 0 on its own, out of buffer 1
+      for (; kb + 3 < KB; kb += 2) {
+        kblock(kb, I0{}, I0{});
+        kblock(kb + 1, I1{}, I0{});
+      }
+      kblock(KB - 2, I0{}, I1{});
+      kblock(KB - 1, I1{}, I2{});
+    }
     if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NTT, 1>(p, acc, px, 0, kq);
     else yl_epi_fast<NTT, 1>(p, acc, px, 0, kq, lo, hi, true);
   }
@@ -2142,8 +2158,9 @@ static hipError_t dwl_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
   YlConvP p = p0;
   const long WTOT = (long)p.B * ((p.OW + 7) >> 3) * ((p.OH + 7) >> 3);
   p.ntiles = (int)((WTOT + 1) / 2);
-  const size_t lds = ((size_t)3 * NTP * 64 + 4 * 512) * 16 + (((size_t)10 * p.Cin + 3) & ~(size_t)3) * 4;
+  const size_t lds = ((size_t)3 * NTP * 64 + 4 * 512) * 16 + (size_t)p.KB * 160 * 4;
   if (lds > 128 * 1024) return hipErrorNotSupported;
+  if ((size_t)p.B * p.H * p.W * p.Cin * sizeof(yl_act_t) >= ((size_t)1 << 31)) return hipErrorNotSupported;   // 32-bit byte offsets
   const int res = yl_resident_blocks_n(yl_conv_dwl_kernel<NTT>, 512, lds);
   int gx = res & ~7;
   if (gx < 8) gx = 8;

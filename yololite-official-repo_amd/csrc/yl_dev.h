@@ -74,6 +74,17 @@ __device__ __forceinline__ void yl_wino_b(const f32x4 (&x)[3], const f32x4 (&y)[
   b1 = (f32x4){r2.x, r2.y, r3.x, r3.y};
 }
 
+// acc + a * b per component as two v_pk_fma_f32 BY NAME (the builtin form above is split into scalar instructions when the
+// selector likes).  Inline asm: the hazard recognizer does not see a VALU write in it -- the result must not be an operand of a
+// matrix instruction within two wait states (yl_conv_dwl_kernel: it is the next k-block's B fragment).
+__device__ __forceinline__ f32x4 yl_pk_fma4(f32x4 a, f32x4 b, f32x4 acc) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  f32x2_ lo, hi;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"((f32x2_){a.x, a.y}), "v"((f32x2_){b.x, b.y}), "v"((f32x2_){acc.x, acc.y}));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"((f32x2_){a.z, a.w}), "v"((f32x2_){b.z, b.w}), "v"((f32x2_){acc.z, acc.w}));
+  return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
+
 __device__ __forceinline__ f32x4 yl_clamp4(f32x4 v, float lo, float hi) {
   f32x4 r;
   r.x = __builtin_amdgcn_fmed3f(v.x, lo, hi); r.y = __builtin_amdgcn_fmed3f(v.y, lo, hi);
