@@ -2123,7 +2123,11 @@ __global__ __launch_bounds__(512, 2) void yl_conv_dwl_kernel(YlConvP p) {
         __builtin_amdgcn_sched_barrier(0);                        // (else the fma chain moves up to the group's first MFMA and waits there
         if (MODE < 2 && c < 3) {                                  //  for the reads issued a moment before)
 #pragma unroll
+#if defined(YL_DWL_PK) && !YL_DWL_PK                                 // (A/B builds)
+          for (int t = 0; t < 3; ++t) xn = __builtin_elementwise_fma(tx[t], tw[t], xn);
+#else
           for (int t = 0; t < 3; ++t) xn = yl_pk_fma4(tx[t], tw[t], xn);     // two v_pk_fma_f32 by name: the same fma per component
+#endif
           if (c == 2) xn = yl_actc(xn, dw_act, dlo, dhi);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2815,7 +2819,13 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino2_kernel(YlConvP p) {
       y[0] = wb[sY0]; y[1] = wb[sY1]; y[2] = wb[sY2];
     };
     auto make_b = [&](const f32x4 (&x)[3], const f32x4 (&y)[3], f32x4& b0, f32x4& b1) {
+#if defined(YL_WINO_PK) && !YL_WINO_PK                               // (A/B builds)
+      const f32x4 u0 = y[0] * sr4 + x[0], u1 = y[1] * sr4 + x[1], u2 = y[2] * sr4 + x[2];
+      b0 = u0 - u1;
+      b1 = u2 * sc4 + u1;
+#else
       yl_wino_b(x, y, sr4, sc4, b0, b1);
+#endif
     };
     auto mma_mt = [&](const f32x4 (&a)[NT], const f32x4& b, f32x4 (&c)[NT]) {    // one m-tile: the 4 steps x NT n-tiles
 #if YL_BF16
