@@ -2207,7 +2207,13 @@ __global__ __launch_bounds__(NW * 64, 2) void yl_conv_dws_kernel(YlConvP p) {
   const int kq = lane >> 4, pl = lane & 15;
   const int KB = p.KB, NTtot = p.NTtot, Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW;
   const yl_act_t* const xin = p.x;
-  const long zdelta = p.zeros - p.x;
+  // staging loads through a raw buffer descriptor (round 6, as yl_conv_wino2_kernel): a 32-bit byte offset per slot fixed for the
+  // item + a scalar k-block offset -- the loop carried 8 64-bit adds and 16 selects per k-block for its four loads; slots outside
+  // the image carry an out-of-range offset (the load returns zeros); the channel tail is not masked (tap weights and 1x1 weights
+  // of those channels are zeros, the arenas end in 256 spare bytes)
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<yl_act_t*>(xin), 0, (int)((long)p.B * H * W * Cin * (long)sizeof(yl_act_t)), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);                     // [2][S][NTW][64] float4
   f32x4* tl = wl + (size_t)2 * S * NTW * 64;                         // [2][S][TQP] float4: row t = tap t (t = TAPS: bias), 4 quads
   float* halo = reinterpret_cast<float*>(tl + (size_t)2 * S * TQP) + wave * (HP * PITCHF);
@@ -2297,7 +2303,7 @@ __global__ __launch_bounds__(NW * 64, 2) void yl_conv_dws_kernel(YlConvP p) {
           }
         }
     }
-    long goff[NSLOT];
+    unsigned goff[NSLOT];
     {
       const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * txi * DS - p.dw_pad_l;
 #pragma unroll
@@ -2307,13 +2313,18 @@ __global__ __launch_bounds__(NW * 64, 2) void yl_conv_dws_kernel(YlConvP p) {
         const int hr = hp / HP, hc = hp - hr * HP;
         const int iy = iy0 + hr, ix = ix0 + hc;
         const bool in = e < HF4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        goff[j] = in ? (((long)b * H + iy) * W + ix) * Cin + (lane & 3) * 4 : -1;
+        goff[j] = in ? (unsigned)((((b * H + iy) * W + ix) * Cin + (lane & 3) * 4) * (int)sizeof(yl_act_t)) : OOB;
       }
     }
     auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
-      const bool cok = kb * 16 + (lane & 3) * 4 < Cin;
 #pragma unroll
-      for (int j = 0; j < NSLOT; ++j) r[j] = yl_ld4(xin + ((cok && goff[j] >= 0) ? goff[j] + kb * 16 : zdelta));
+      for (int j = 0; j < NSLOT; ++j) {
+#if defined_YL_F16S
+        r[j] = __builtin_convertvector(__builtin_bit_cast(yl_h16x4, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)goff[j], kb * 32, 0)), f32x4);
+#else
+        r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[j], kb * 64, 0));
+#endif
+      }
     };
     auto stage_store = [&](const f32x4 (&r)[NSLOT]) {
 #pragma unroll
@@ -2419,6 +2430,7 @@ bool yl_dws_supported(int cin, int n, int dk, int ds, int oh, int ow) {
 #endif
 
 hipError_t yl_launch_conv_dws(const YlConvP& p, hipStream_t st) {
+  if ((size_t)p.B * p.H * p.W * p.Cin * sizeof(yl_act_t) >= ((size_t)1 << 31)) return hipErrorNotSupported;   // 32-bit byte offsets
   if (p.dw_k == 0 || p.k != 1 || p.stride != 1 || p.dec_boxes || p.C1 > 0 || p.scale || p.in_shift || p.w3p ||
       !yl_dws_supported(p.Cin, p.N, p.dw_k, p.dw_stride, p.OH, p.OW) ||
       (size_t)p.B * p.H * p.W * p.Cin >= ((size_t)1 << 40))
