@@ -614,7 +614,12 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   const int kq = lane >> 4, pl = lane & 15;
   const int Cin = p.Cin, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N, NTtot = p.NTtot, KB = p.KB;
   const yl_act_t* const xin = p.x;
-  const long zdelta = p.zeros - p.x;
+  // staging loads through a raw buffer descriptor (round 6, see yl_conv_dws_kernel): 32-bit byte offset per slot + scalar k-block
+  // offset, zeros outside the image from the hardware range check; the channel tail is not masked (the 1x1 weights of those k
+  // slots are zeros, the tap weights are clamped to the last channels, the arenas end in 256 spare bytes)
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<yl_act_t*>(p.x), 0, (int)((long)p.B * H * W * Cin * (long)sizeof(yl_act_t)), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);                     // WL: [KB][NTtot][64] float4
   float* dwl = yl_clds + (WL ? (size_t)KB * NTtot * 256 : 0);        // [DK*DK][Cin] taps, [Cin] bias
   float* halo = dwl + (((size_t)(DK * DK + 1) * Cin + 3) & ~(size_t)3) + wave * (HPY * PITCHF);
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
   }
   const int sdb = wstride / tiles_img, sdrem = wstride - sdb * tiles_img;
   const int sdy = sdrem / twn, sdx = sdrem - sdy * twn;
-  long goff[NSLOT];
+  unsigned goff[NSLOT];
   auto tile_geom = [&]() {
     const int b = tb;
     const int iy0 = 4 * tyi * DS - p.dw_pad_t, ix0 = 4 * MT * txi * DS - p.dw_pad_l;
@@ -670,13 +675,18 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void yl_conv_dwt_kernel(YlCon
       const int hr = hp / HPX, hc = hp - hr * HPX;
       const int iy = iy0 + hr, ix = ix0 + hc;
       const bool in = e < HF4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      goff[j] = in ? (((long)b * H + iy) * W + ix) * Cin + (lane & 3) * 4 : -1;
+      goff[j] = in ? (unsigned)((((b * H + iy) * W + ix) * Cin + (lane & 3) * 4) * (int)sizeof(yl_act_t)) : OOB;
     }
   };
   auto stage_load = [&](int kb, f32x4 (&r)[NSLOT]) {
-    const bool cok = kb * 16 + (lane & 3) * 4 < Cin;
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) r[j] = yl_ld4(xin + ((cok && goff[j] >= 0) ? goff[j] + kb * 16 : zdelta));
+    for (int j = 0; j < NSLOT; ++j) {
+#if defined_YL_F16S
+      r[j] = __builtin_convertvector(__builtin_bit_cast(yl_h16x4, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)goff[j], kb * 32, 0)), f32x4);
+#else
+      r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[j], kb * 64, 0));
+#endif
+    }
   };
   auto stage_store = [&](const f32x4 (&r)[NSLOT]) {
 #pragma unroll
@@ -935,6 +945,7 @@ hipError_t yl_launch_conv_dwt(YlConvMulti& m, hipStream_t st) {
   bool two = false, wl = p.KB * p.NTtot <= 36;
   for (int k = 0; k < m.n; ++k) {
     if ((m.p[k].OH & 3) || (m.p[k].OW & 3)) return hipErrorNotSupported;
+    if ((size_t)m.p[k].B * m.p[k].H * m.p[k].W * m.p[k].Cin * sizeof(yl_act_t) >= ((size_t)1 << 31)) return hipErrorNotSupported;   // 32-bit byte offsets
     if (m.p[k].OW & 7) two = false;
   }
   const int nts[5] = {1, 2, 3, 4, 6};
