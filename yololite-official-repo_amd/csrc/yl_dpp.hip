@@ -278,7 +278,12 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     return b[buf * WSL + 24 * (tap / 3) + 4 * (tap % 3)];
   };
 
-  struct Src { const float* s[3]; };
+  // window copies through a raw buffer descriptor (round 6): 32-bit byte offset per copy fixed for the tile + scalar k-block
+  // offset (with global_load_lds the instruction offset also moves the LDS address, so every request paid a 64-bit add);
+  // lanes outside the image carry an out-of-range offset: the copy writes zeros
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xin), 0, (int)((long)p.B * H * W * Cin * 4), 0x00020000);
+  struct Src { unsigned s[3]; };
   auto setup = [&](int tile, Src& src, YlPix& px) {
     const bool tv = tile < r1;
     const int tc = tv ? tile : r1 - 1;
@@ -291,14 +296,15 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     for (int j = 0; j < 3; ++j) {
       const int gy = 4 * tyi - 1 + cy[j], gxx = 4 * txi - 1 + cx[j];
       const bool in = tv && cq[j] >= 0 && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
-      src.s[j] = in ? xin + (((long)b * H + gy) * W + gxx) * Cin + 4 * cq[j] : p.zeros;
+      src.s[j] = in ? (unsigned)((((b * H + gy) * W + gxx) * Cin + 4 * cq[j]) * 4) : 0x80000000u;
     }
   };
   auto request = [&](const Src& src, int kb, int buf) {
     if (DPW_ABL & 8) return;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      if (j < 2 || WSL == 192 || lane < 16) yl_glds16(src.s[j] + kb * 16, winl + buf * WSL + j * 64);
+      if (j < 2 || WSL == 192 || lane < 16)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(winl + buf * WSL + j * 64), 16, (int)src.s[j], kb * 64, 0, 0);
   };
 
   Src cs, ns;
@@ -856,7 +862,8 @@ hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st) {
     return hipErrorNotSupported;
   for (int k = 0; k < n; ++k)
     if (!yl_dpp_supported(ps[k].Cin, ps[k].N, ps[k].C3, ps[k].OH, ps[k].OW) || ps[k].Cin != q.Cin || ps[k].N != q.N ||
-        ps[k].C3 != q.C3 || ps[k].H != ps[k].OH || ps[k].W != ps[k].OW)
+        ps[k].C3 != q.C3 || ps[k].H != ps[k].OH || ps[k].W != ps[k].OW ||
+        (size_t)ps[k].B * ps[k].H * ps[k].W * ps[k].Cin * 4 >= ((size_t)1 << 31))        // (32-bit byte offsets of the window copies)
       return hipErrorNotSupported;
   const int kb = q.Cin / 16, nt1 = q.N / 16, nt3 = (q.C3 + 15) / 16;
 #define YL_DPP_RUN(A, B, C) if (kb == A && nt1 == B && nt3 == C) return dpp_go<A, B, C>(ps, n, st, false);
