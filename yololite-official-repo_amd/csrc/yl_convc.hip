@@ -1441,17 +1441,19 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
   const int Cmid = p.Cin, KB = p.KB, NTtot = p.NTtot, C1 = p.C1, H = p.H, W = p.W, OH = p.OH, OW = p.OW, N = p.N;
   float* slab = yl_clds;                                           // [2][SLAB]
   f32x4* wpl = reinterpret_cast<f32x4*>(yl_clds + 2 * SLAB);       // [2][NT][64] float4: projection weights of a slab
-  float* dwl = yl_clds + 2 * SLAB + 2 * NT * 256;                  // [DK*DK][Cmid] taps, [Cmid] dw bias
-  float* b2l = dwl + (((size_t)(DK * DK + 1) * Cmid + 3) & ~(size_t)3);   // [KB*16] expansion bias
+  float* dwl = yl_clds + 2 * SLAB + 2 * NT * 256;                  // [KB][DK*DK + 1][16]: taps + dw bias of a slab's channels (zeros beyond Cmid):
+                                                                   // k-block-major, so that a lane's tap reads of a slab are ONE address + immediates
+  float* b2l = dwl + (size_t)KB * (DK * DK + 1) * 16;              // [KB*16] expansion bias
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);          // projection [KB][NTtot][64]
   const f32x4* w2g = reinterpret_cast<const f32x4*>(p.w2p);        // expansion [KBI][KB][64]
   const yl_act_t* const xin = p.x;
   const yl_act_t* const up = p.up;                                     // FPN lateral + smooth pair: addend of the expansion
   {
-    const int nw = DK * DK * Cmid;
-    yl_glds_floats(p.dw_w, dwl, nw, tid, NTH);
-    if (p.dw_b) yl_glds_floats(p.dw_b, dwl + nw, Cmid, tid, NTH);
-    else for (int i = tid; i < Cmid; i += NTH) dwl[nw + i] = 0.0f;
+    constexpr int T1 = DK * DK + 1;
+    for (int i = tid; i < KB * T1 * 16; i += NTH) {
+      const int kb = i / (T1 * 16), r = i - kb * (T1 * 16), t = r >> 4, ch = kb * 16 + (r & 15);
+      dwl[i] = ch < Cmid ? (t < DK * DK ? p.dw_w[(size_t)t * Cmid + ch] : (p.dw_b ? p.dw_b[ch] : 0.0f)) : 0.0f;
+    }
     for (int i = tid; i < KB * 16; i += NTH) b2l[i] = p.b2[i];
   }
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
@@ -1585,16 +1587,14 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
       if (kb + 1 < KB) load_proj(kb + 1, buf ^ 1);
       else if (tile + tstride < tend) load_proj(0, buf ^ 1);        // first slab of the workgroup's next tile
       // ---- D: depthwise on the slab -> B fragments
-      const int c = kb * 16 + 4 * kq;
-      const int cs = c < Cmid ? c : Cmid - 4;
-      const float* tapw = dwl + cs;
+      const float* tapw = dwl + kb * ((DK * DK + 1) * 16) + 4 * kq;
       f32x4 xq[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_ld4(tapw + DK * DK * Cmid);
+      for (int mt = 0; mt < MT; ++mt) xq[mt] = yl_ld4(tapw + DK * DK * 16);
       auto tap_row = [&](int dy) {
 #pragma unroll
         for (int dx = 0; dx < DK; ++dx) {
-          const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * Cmid);
+          const f32x4 w = yl_ld4(tapw + (dy * DK + dx) * 16);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(sb + rbase + dy * PITCHF + (dx + 4 * mt * DS) * 16);
@@ -1629,7 +1629,7 @@ __global__ __launch_bounds__(RBN * CBN * 64, (DK == 3 && DS * MT <= 2 && KBI <= 
 static size_t yl_ir_lds(int dk, int ds, int mt, int rbn, int cbn, int nt, int cmid) {
   const int hh = (4 * rbn - 1) * ds + dk, hw = (4 * mt * cbn - 1) * ds + dk;
   const int pitch = ((hw * 16 + 7) / 64) * 64 + 56;
-  return ((size_t)2 * hh * pitch + (size_t)2 * nt * 256 + ((((size_t)(dk * dk + 1) * cmid) + 3) & ~(size_t)3) + (size_t)((cmid + 15) / 16) * 16) * 4;
+  return ((size_t)2 * hh * pitch + (size_t)2 * nt * 256 + (size_t)((cmid + 15) / 16) * 16 * (dk * dk + 1) + (size_t)((cmid + 15) / 16) * 16) * 4;
 }
 
 template <int KBI, int NT, int DK, int DS, int MT, int RBN, int CBN>
