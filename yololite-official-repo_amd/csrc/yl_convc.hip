@@ -1714,7 +1714,11 @@ __global__ __launch_bounds__(NW * 64, GW == 1 ? 3 : 2) void yl_conv_dwk_kernel(Y
   const int Cin = p.Cin, H = p.H, W = p.W, DS = p.dw_stride, pad_t = p.dw_pad_t, pad_l = p.dw_pad_l;
   const int ohw = p.OH * p.OW, OW = p.OW, M = p.M;
   const yl_act_t* const xin = p.x;
-  const long zdelta = p.zeros - p.x;
+  // tap loads through a raw buffer descriptor (round 6, see yl_conv_dws_kernel): a 32-bit byte offset per tap fixed for the item +
+  // a scalar k-block offset (the loop carried a select, a conditional add and a 64-bit add per tap); taps outside the image carry
+  // an out-of-range offset (zeros from the range check); the channel tail is not masked (its 1x1 weights are zeros)
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<yl_act_t*>(xin), 0, (int)((long)p.B * H * W * Cin * (long)sizeof(yl_act_t)), 0x00020000);
   f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][S][GW][NT][64] float4
   float* dwl = yl_clds + (size_t)2 * PCS * 256;              // [9][Cin] taps, [Cin] bias
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);
@@ -1793,21 +1797,21 @@ __global__ __launch_bounds__(NW * 64, GW == 1 ? 3 : 2) void yl_conv_dwk_kernel(Y
         }
     }
     // nine tap pointers of the lane's pixel (the zero buffer where a tap falls outside the image, marked in `inb`)
-    const yl_act_t* tp[9];
-    unsigned inb = 0;
+    unsigned tp[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int iy = px[0].oy * DS - pad_t + tap / 3, ix = px[0].ox * DS - pad_l + tap % 3;
       const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
-      tp[tap] = xin + (in ? ((((long)px[0].b * H + iy) * W + ix) * Cin + 4 * kq) : zdelta);
-      inb |= in ? (1u << tap) : 0u;
+      tp[tap] = in ? (unsigned)((((px[0].b * H + iy) * W + ix) * Cin + 4 * kq) * (int)sizeof(yl_act_t)) : 0x80000000u;
     }
     auto fetch = [&](f32x4 (&dst)[9], int kb) {
-      const bool tail = kb * 16 + 4 * kq >= Cin;                  // channel tail of the last block: zeros
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const yl_act_t* q = tp[tap] + (((inb >> tap) & 1u) ? kb * 16 : 0);
-        dst[tap] = yl_ld4(tail ? xin + zdelta : q);
+#if defined_YL_F16S
+        dst[tap] = __builtin_convertvector(__builtin_bit_cast(yl_h16x4, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)tp[tap], kb * 32, 0)), f32x4);
+#else
+        dst[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)tp[tap], kb * 64, 0));
+#endif
       }
     };
     f32x4 xt[9];
@@ -1879,6 +1883,7 @@ static hipError_t dwl_go(const YlConvP& p0, hipStream_t st, bool attr_only);
 // single problem.  hipErrorNotSupported otherwise (yl_conv_mfma_kernel's streamed mode then runs the layer).
 hipError_t yl_launch_conv_dwk(const YlConvP& p, hipStream_t st) {
   if (p.dw_k != 3 || (p.N & 3) || p.dec_boxes || p.C1 > 0 || p.KB < 12 || p.NTtot <= 8) return hipErrorNotSupported;
+  if ((size_t)p.B * p.H * p.W * p.Cin * sizeof(yl_act_t) >= ((size_t)1 << 31)) return hipErrorNotSupported;   // 32-bit byte offsets
   // developer A/B ("dev_select" bits 5-6): 2 = off, 1 = one n-group per item (depthwise recomputed per group),
   // 0 = default: a wave holds every n-group
   const int sel = YL_DEV_DWK(p.dev) == 2 ? 0 : (YL_DEV_DWK(p.dev) == 1 ? 1 : 2);
