@@ -733,21 +733,20 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
       bool all = true;
       for (size_t q = i; q < gend; ++q) all = all && c->layers[q].wp_det != nullptr;
       if (all) {
-        YlConvP pd[4], pm[4];
+        YlConvP pd[4];
         const int nd = 5 + c->C;
         for (size_t q = i; q < gend; ++q) {
           YlConvP o;
           params(q, o);
-          YlConvP& a = pd[q - i]; YlConvP& m2 = pm[q - i];
+          YlConvP& a = pd[q - i];
           a = o; a.wp = c->layers[q].wp_det; a.bias = c->layers[q].b_det; a.N = nd; a.NTtot = cdiv(nd, 16); a.dec_raw = 0;
-          m2 = o; m2.wp = c->layers[q].wp_mc; m2.bias = c->layers[q].b_mc; m2.N = c->NM; m2.NTtot = cdiv(c->NM, 16);
-          m2.dec_boxes = nullptr; m2.dec_scores = nullptr; m2.dec_cls = nullptr; m2.dec_raw = 0;
-          m2.out = o.out + nd; m2.ldo = c->E;
+          // the coefficient part rides along as the second weight image (yl_launch_conv_multi: one pass where it pays, else a
+          // second plain 1x1 launch): its columns go into the level rows behind the detection columns
+          a.w3p = c->layers[q].wp_mc; a.b3 = c->layers[q].b_mc; a.C3 = c->NM;
+          a.out = o.out + nd; a.ldo = c->E;
         }
         const int n = (int)(gend - i);
-        hipError_t e = conv_multi(c, pd, n, st);
-        if (e == hipSuccess)
-          e = conv_multi(c, pm, n, st);
+        const hipError_t e = conv_multi(c, pd, n, st);
         if (e != hipSuccess) {
           char b[256];
           snprintf(b, sizeof(b), "layers %zu..%zu split head launch failed: %s", i, gend - 1, hipGetErrorString(e));

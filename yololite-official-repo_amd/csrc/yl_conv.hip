@@ -1270,6 +1270,26 @@ hipError_t yl_launch_conv_multi(const YlConvP* ps, int n, int tile_hint, hipStre
     if (e != hipErrorNotSupported) return e;
   }
 #endif
+  if (ps[0].k == 1 && ps[0].dw_k == 0 && ps[0].dec_boxes && !ps[0].dec_raw && ps[0].w3p) {
+    // head output of a segmentation model under yl_predict (yl_api.hip): 5 + C detection columns through the decode epilogue AND
+    // the NM mask-coefficient columns (second weight image w3p / b3 / C3, stored plain into the level rows out / ldo).  Levels with
+    // enough pixels: ONE pass over the input (yl_conv_pws_kernel's two-image form); the others as the two launches of round 4.
+    YlConvP det[4], mc[4];
+    int nr = 0;
+    for (int k = 0; k < n; ++k) {
+      const hipError_t e = tile_hint != 6 ? yl_launch_conv_pws(ps[k], st) : hipErrorNotSupported;
+      if (e == hipSuccess) continue;
+      if (e != hipErrorNotSupported) return e;
+      det[nr] = ps[k]; det[nr].w3p = nullptr; det[nr].b3 = nullptr; det[nr].C3 = 0; det[nr].ldo = 0;
+      mc[nr] = ps[k]; mc[nr].wp = ps[k].w3p; mc[nr].bias = ps[k].b3; mc[nr].N = ps[k].C3; mc[nr].NTtot = (ps[k].C3 + 15) / 16;
+      mc[nr].w3p = nullptr; mc[nr].b3 = nullptr; mc[nr].C3 = 0;
+      mc[nr].dec_boxes = nullptr; mc[nr].dec_scores = nullptr; mc[nr].dec_cls = nullptr; mc[nr].dec_raw = 0;
+      ++nr;
+    }
+    if (nr == 0) return hipSuccess;
+    const hipError_t e = yl_launch_conv_multi(det, nr, tile_hint, st);
+    return e != hipSuccess ? e : yl_launch_conv_multi(mc, nr, tile_hint, st);
+  }
   YlConvMulti m = {};
   m.n = n;
   int big = 0;

@@ -1180,16 +1180,20 @@ hipError_t yl_launch_conv_kxk(const YlConvP& p, hipStream_t st) {
 // DEC (NT == 6, one n-group): the head output under yl_predict -- a wave holds whole rows of <= 96 logits and runs the decode
 // epilogue of yl_conv_pwt_kernel on them (yololite_m's 328 -> 85 outputs: 21 k-blocks of weights through LDS once per 64 / 128 pixels
 // instead of once per 32 through the vector-memory path).
-template <int NT, int NW, bool SC = false, bool DEC = false>
+// NT2 > 0 (with DEC): NT2 more n-tiles from a SECOND weight image (YlConvP::w3p / b3 / C3: the mask coefficients of a segmentation
+// head, model_v2.py head output split into 5 + C detection columns and NM coefficient columns) ride in the same launch -- the wave's
+// rows are read once instead of once per part; the extra columns are stored plain into the level rows (p.out, p.ldo).
+template <int NT, int NW, bool SC = false, bool DEC = false, int NT2 = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(YlConvP p) {
   constexpr int CH = 2;                                      // k-steps per weight chunk
+  constexpr int NTA = NT + NT2;                              // n-tiles a wave accumulates
   extern __shared__ __attribute__((aligned(16))) float yl_clds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, pl = lane & 15;
   const int KB = p.KB, NTtot = p.NTtot, Cin = p.Cin, M = p.M;
   const yl_act_t* const xin = p.x;
-  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][CH][NT][64] float4
+  f32x4* wl = reinterpret_cast<f32x4*>(yl_clds);            // [2][CH][NTA][64] float4
   const f32x4* wg = reinterpret_cast<const f32x4*>(p.wp);   // [KB][NTtot][64] float4
   const int NC = (KB + CH - 1) / CH;                         // chunks per item
   const int G = (NTtot + NT - 1) / NT;                       // n-groups (the last one may be partial: clamped reads, no stores)
@@ -1206,13 +1210,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
   const long total_chunks = (long)nmine * NC;
   // asynchronous copy of chunk `c` (k-steps c*CH .. c*CH+CH-1, clamped) of n-group g into buffer `buf`
   auto load_chunk = [&](int g, int c, int buf) {
-    for (int i = wave; i < CH * NT; i += NW) {
-      const int j = i / NT, nt = i - j * NT;
+    for (int i = wave; i < CH * NTA; i += NW) {
+      const int j = i / NTA, nt = i - j * NTA;
       int kb = c * CH + j;
       kb = kb < KB ? kb : KB - 1;
+      if (NT2 > 0 && nt >= NT) {                              // (wave-uniform) second image: [KB][NT2][64]
+        yl_glds16(reinterpret_cast<const f32x4*>(p.w3p) + ((size_t)kb * NT2 + (nt - NT)) * 64 + lane, wl + ((size_t)buf * CH * NTA + i) * 64);
+        continue;
+      }
       int ntg = g * NT + nt;
       ntg = ntg < NTtot ? ntg : NTtot - 1;
-      yl_glds16(wg + ((size_t)kb * NTtot + ntg) * 64 + lane, wl + ((size_t)buf * CH * NT + i) * 64);
+      yl_glds16(wg + ((size_t)kb * NTtot + ntg) * 64 + lane, wl + ((size_t)buf * CH * NTA + i) * 64);
     }
   };
   if (total_chunks > 0) load_chunk(slot / bt, 0, 0);
@@ -1245,9 +1253,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
     }
     const yl_act_t* xrow = xin + px[0].lin * Cin + 4 * kq;
     const float* srow = SC ? p.scale + (size_t)px[0].b * Cin + 4 * kq : nullptr;    // squeeze-excite gate of the pixel's image
-    f32x4 acc[1][NT];
+    f32x4 acc[1][NTA];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NTA; ++nt) acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (pre_add) {
       const size_t obase = px[0].lin * p.N;
       size_t up_off = 0;
@@ -1285,21 +1293,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
         if (c + 1 < NC) load_chunk(g, c + 1, buf ^ 1);
         else load_chunk((item + per) / bt, 0, buf ^ 1);
       }
-      const f32x4* wb = wl + (size_t)buf * CH * NT * 64 + lane;
+      const f32x4* wb = wl + (size_t)buf * CH * NTA * 64 + lane;
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         constexpr int dummy = 0; (void)dummy;
         const int kb = c * CH + j;
         if (kb < KB) {                                         // (workgroup-uniform) odd KB: the last chunk is half empty
           const int slot = (P * CH + j) % PF;
-          constexpr int H0 = NT > 7 ? (NT + 1) / 2 : NT;       // A fragments in two groups: <= 28 VGPRs of them live
-          constexpr int H1 = NT - H0;
+          constexpr int H0 = NTA > 7 ? (NTA + 1) / 2 : NTA;    // A fragments in two groups: <= 28 VGPRs of them live
+          constexpr int H1 = NTA - H0;
           f32x4 xs[1] = {xr[slot]};
           xr[slot] = fetch(kb + PF < KB ? kb + PF : KB - 1);
           {
             f32x4 wq[H0], a0[1][H0];
 #pragma unroll
-            for (int nt = 0; nt < H0; ++nt) { wq[nt] = wb[(j * NT + nt) * 64]; a0[0][nt] = acc[0][nt]; }
+            for (int nt = 0; nt < H0; ++nt) { wq[nt] = wb[(j * NTA + nt) * 64]; a0[0][nt] = acc[0][nt]; }
             yl_mma_step<H0, 1>(wq, xs, a0);
 #pragma unroll
             for (int nt = 0; nt < H0; ++nt) acc[0][nt] = a0[0][nt];
@@ -1308,7 +1316,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
             constexpr int H1s = H1 > 0 ? H1 : 1;
             f32x4 wq[H1s], a1[1][H1s];
 #pragma unroll
-            for (int nt = 0; nt < H1; ++nt) { wq[nt] = wb[(j * NT + H0 + nt) * 64]; a1[0][nt] = acc[0][H0 + nt]; }
+            for (int nt = 0; nt < H1; ++nt) { wq[nt] = wb[(j * NTA + H0 + nt) * 64]; a1[0][nt] = acc[0][H0 + nt]; }
             yl_mma_step<H1s, 1>(wq, xs, a1);
 #pragma unroll
             for (int nt = 0; nt < H1; ++nt) acc[0][H0 + nt] = a1[0][nt];
@@ -1322,9 +1330,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void yl_conv_pws_kernel(Y
       chunk(std::integral_constant<int, 0>{}, c);
       if (c + 1 < NC) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
-    if (DEC) { yl_epi_decode<NT, 1, false, true>(p, acc, px, 0, kq, lane); continue; }       // (one n-group: nt0 == 0)
-    if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NT, 1>(p, acc, px, nt0, kq);
-    else yl_epi_fast<NT, 1>(p, acc, px, nt0, kq, lo, hi, true);
+    if (DEC) {                                                // (one n-group: nt0 == 0)
+      if (NT2 > 0) {
+        constexpr int N2 = NT2 > 0 ? NT2 : 1;
+        f32x4 ad[1][NT], am[1][N2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ad[0][nt] = acc[0][nt];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) am[0][nt] = acc[0][NT + nt];
+        YlConvP pm = p;                                       // the second part: plain columns into the level rows
+        pm.bias = p.b3; pm.N = p.C3;
+        yl_epi_fast<N2, 1>(pm, am, px, 0, kq, lo, hi, true);
+        yl_epi_decode<NT, 1, false, true>(p, ad, px, 0, kq, lane);
+      } else {
+        yl_epi_decode<NT, 1, false, true>(p, *reinterpret_cast<f32x4 (*)[1][NT]>(&acc), px, 0, kq, lane);
+      }
+      continue;
+    }
+    if (!pre_add && (p.res || p.up || YL_SMOOTH(p.act))) yl_epi_generic<NTA, 1>(p, acc, px, nt0, kq);
+    else yl_epi_fast<NTA, 1>(p, acc, px, nt0, kq, lo, hi, true);
   }
 }
 
@@ -1335,6 +1359,8 @@ static hipError_t pws_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
     if (e != hipSuccess) return e;
     if (NT == 6) {
       e = hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT == 6 ? 6 : 6, NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT == 6 ? 6 : 6, NW, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       if (e != hipSuccess) return e;
     }
     return hipFuncSetAttribute((const void*)yl_conv_pws_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1347,7 +1373,13 @@ static hipError_t pws_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
   while (gx > 8 && gx - 8 >= p.ntiles * gy) gx -= 8;
   if (p.dec_boxes) {
     if (NT != 6 || p.scale) return hipErrorNotSupported;
-    hipLaunchKernelGGL((yl_conv_pws_kernel<6, NW, false, true>), dim3(gx), dim3(NW * 64), lds, st, p);
+    if (p.w3p) {                                              // + the mask coefficients (32 columns) from the second weight image
+      const size_t lds2 = (size_t)2 * 2 * 8 * 1024;
+      int gx2 = yl_resident_blocks_n(yl_conv_pws_kernel<6, NW, false, true, 2>, NW * 64, lds2) & ~7;
+      while (gx2 > 8 && gx2 - 8 >= p.ntiles * gy) gx2 -= 8;
+      hipLaunchKernelGGL((yl_conv_pws_kernel<6, NW, false, true, 2>), dim3(gx2), dim3(NW * 64), lds2, st, p);
+    } else
+      hipLaunchKernelGGL((yl_conv_pws_kernel<6, NW, false, true>), dim3(gx), dim3(NW * 64), lds, st, p);
   } else if (p.scale) hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW, true>), dim3(gx), dim3(NW * 64), lds, st, p);
   else hipLaunchKernelGGL((yl_conv_pws_kernel<NT, NW>), dim3(gx), dim3(NW * 64), lds, st, p);
   return hipGetLastError();
@@ -1367,7 +1399,7 @@ static hipError_t pws_nw(const YlConvP& p, hipStream_t st, bool eight, bool attr
 hipError_t yl_launch_conv_pws(const YlConvP& p, hipStream_t st) {
   const bool dec = p.dec_boxes && !p.dec_raw;                  // head output under yl_predict: rows of <= 96 logits, one n-group
   if (p.k != 1 || p.stride != 1 || p.dw_k > 0 || p.C1 > 0 || p.in_shift || (p.dec_boxes && !dec)) return hipErrorNotSupported;
-  if (dec ? (p.NTtot != 6 || p.scale || p.res || p.up) : (p.N & 3) != 0) return hipErrorNotSupported;
+  if (dec ? (p.NTtot != 6 || p.scale || p.res || p.up || (p.w3p && (p.C3 != 32 || YL_SMOOTH(p.act)))) : ((p.N & 3) != 0 || p.w3p)) return hipErrorNotSupported;
   if ((p.dev & YL_DEV_PWS_OFF) || p.KB < 5 || p.NTtot < 6) return hipErrorNotSupported;     // (dev: A/B runs)
   // n-tiles per item, from {6..13}: the makespan of the launch in MFMA units -- (16-pixel x n-group) wave items dealt
   // to 1024 SIMDs, each NT x KB x 4 MFMAs long -- with a penalty when fewer than 1.5 waves per SIMD exist (one wave
