@@ -1134,9 +1134,11 @@ def test_split_head_output_of_a_seg_model_is_bitwise_the_combined_launch():
     the mask coefficients -> the generic kernel's scalar epilogue at 40 TFLOP/s) runs as TWO launches of the same 1x1 conv --
     rows [0, 85) with the decode in the epilogue and no raw rows (the detector's fast path), rows [85, 117) as a plain 1x1
     storing into the level rows' coefficient columns.  Same k order per output: detections AND masks are bit-identical to
-    the combined launch ("fuse_head" 0)."""
+    the combined launch ("fuse_head" 0).  Round 6: on levels with enough pixels the two parts are ONE launch again
+    (yl_conv_pws_kernel's decode form with the coefficient columns from a second weight image: the rows are read once) --
+    edge_m at 640 x 640, B = 8 takes it on the 80 x 80 level and the two-launch form on the others."""
     from yololite_amd.program import MODEL_ZOO
-    for name, S, B in (("edge_m", 320, 2), ("edge_n", 320, 2)):
+    for name, S, B in (("edge_m", 320, 2), ("edge_n", 320, 2), ("edge_m", 640, 8)):
         meta = make_meta(num_classes=80, img_size=S, seg=True, **MODEL_ZOO[name])
         sd = synth_state_dict(meta, seed=3, head_noise=2.0)
         for k, v in sd.items():
