@@ -2571,6 +2571,14 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
   // out of phase 2.06 ms.  (Grouping by w & 1 or (w >> 1) & 1 puts both waves of a SIMD in one group: 3.27 ms.)
   const int grp = wave >> 2;
   if (grp == 1) __syncthreads();
+  // SH == 0 (round 6): the patch loads go through a raw buffer descriptor whose base sits (W + 1) pixels IN FRONT of the tensor, so
+  // that the lane's part of every address -- the patch origin, which may lie one row and one column outside the image -- is ONE
+  // non-negative 32-bit byte offset for the tile and the element / k-block part is a scalar offset; elements outside the image
+  // take an out-of-range offset (one select each; the loop carried a select pair, a compare and a 64-bit add per element: 85
+  // vector instructions per k-block for 16 loads).  The channel tail is not masked (U is zero there, pack_wino).
+  const int borg = (W + 1) * Cin * (int)sizeof(yl_act_t);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(xin) - borg), 0, (int)((long)p.B * H * W * Cin * (long)sizeof(yl_act_t)) + borg, 0x00020000);
   const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
   const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
 
@@ -2605,7 +2613,17 @@ __global__ __launch_bounds__(512, 2) void yl_conv_wino_kernel(YlConvP p) {
         const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
         inb |= (iy >= 0 && iy < H && ix >= 0 && ix < W) ? (1u << (r * 4 + q)) : 0u;
       }
+    const int vbase = pbase * (int)sizeof(yl_act_t) + borg;       // >= 0: the patch origin seen from the descriptor's base
     auto load_row = [&](int kb, int r, f32x4 (&dst)[16]) {
+      if (!SH && !defined_YL_F16S) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = r * 4 + q;
+          dst[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((inb >> e) & 1u) ? vbase : (int)0x80000000u,
+                                                                                 ((r * W + q) * Cin + kb * 16) * (int)sizeof(yl_act_t), 0));
+        }
+        return;
+      }
       const bool tail = kb * 16 + 4 * kq >= Cin;                  // channel tail of the last block: zeros
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
