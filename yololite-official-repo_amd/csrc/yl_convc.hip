@@ -3073,7 +3073,7 @@ hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st) {
   // (second form: 32-bit byte offsets into the input tensor and the U image)
   const bool small = (size_t)p.B * (p.H >> p.in_shift) * (p.W >> p.in_shift) * p.Cin * sizeof(yl_act_t) < ((size_t)1 << 31) &&
                      (size_t)((p.NTtot + 1) / 2) * p.KB * 32768 < ((size_t)1 << 31);
-  if (!(p.dev & YL_DEV_WINO_V1) && p.KB >= 4 && p.NTtot >= 3 && small) {
+  if (!(p.dev & YL_DEV_WINO_V1) && p.KB >= 2 && p.NTtot >= 3 && small) {   // (KB >= 2: the peeled last two blocks)
     const int TW = (p.OW + 1) >> 1, TH = (p.OH + 1) >> 1;
     const int MX = (TW + 3) >> 2, MY = (TH + 3) >> 2;
     const long MTOT = (long)p.B * MX * MY;
