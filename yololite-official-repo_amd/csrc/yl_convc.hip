@@ -2400,10 +2400,23 @@ __global__ __launch_bounds__(NW * 64, 2) void yl_conv_dws_kernel(YlConvP p) {
           for (int dy = 0; dy < DK; ++dy) {                          // one tap row at a time bounds the register footprint
 #pragma unroll
             for (int dx = 0; dx < DK; ++dx) {
+              // (ablation builds, results wrong: -DYL_DWS_ABL=1 one tap-weight read per row, =2 one tap read per row, =3 both, =4 no fma chain)
+#if defined(YL_DWS_ABL) && (YL_DWS_ABL & 1)
+              const f32x4 w = tw[(dy * DK) * 4];
+#else
               const f32x4 w = tw[(dy * DK + dx) * 4];
+#endif
+#if defined(YL_DWS_ABL) && (YL_DWS_ABL & 2)
+              const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF);
+#else
               const f32x4 v = *reinterpret_cast<const f32x4*>(halo + rbase + dy * PITCHF + dx * 16);
+#endif
+#if defined(YL_DWS_ABL) && (YL_DWS_ABL & 4)
+              if (dx == 0) { xq[0] += v * w; }
+#else
               xq[0].x = fmaf(v.x, w.x, xq[0].x); xq[0].y = fmaf(v.y, w.y, xq[0].y);
               xq[0].z = fmaf(v.z, w.z, xq[0].z); xq[0].w = fmaf(v.w, w.w, xq[0].w);
+#endif
             }
           }
           xq[0] = yl_actc(xq[0], dw_act, dlo, dhi);
