@@ -3079,8 +3079,8 @@ static hipError_t wino2_go(const YlConvP& p0, hipStream_t st, bool attr_only) {
 // ReLU-family epilogue; layer_params hands it over only under option "winograd").
 hipError_t yl_launch_conv_wino(const YlConvP& p, hipStream_t st) {
   if (!p.wino || p.k != 3 || p.stride != 1 || p.dw_k > 0 || p.up || p.dec_boxes || p.C1 > 0 || (p.N & 3) || p.w3p || p.scale ||
-      p.in_shift > 1 || (size_t)p.B * (p.H >> p.in_shift) * (p.W >> p.in_shift) * p.Cin >= ((size_t)1 << 31))
-    return hipErrorNotSupported;
+      p.in_shift > 1 || ((size_t)p.B * (p.H >> p.in_shift) * (p.W >> p.in_shift) * p.Cin + (size_t)(p.W + 1) * p.Cin) * sizeof(yl_act_t) >= ((size_t)1 << 31))
+    return hipErrorNotSupported;                            // (32-bit byte offsets: both forms read through buffer descriptors)
   // second form (positions across the waves): K loops long enough to amortise the accumulator exchange, grids that fill
   // the 4 x 4-tile m-tiles; "dev_select" bit 11 keeps the first form (bitwise A/B), bits 12-13 pick a shape (A/B runs)
   // (second form: 32-bit byte offsets into the input tensor and the U image)
