@@ -78,6 +78,8 @@ def build_workload(model_name="edge_n", S=640, B=64, seed=1, seg=False, dev="cud
     model = ya.build_model_from_meta(meta, **kw)
     model.load_state_dict(sd)
     model.to(dev)
+    if os.environ.get("YL_DEV_SELECT"):                     # developer A/B runs of whole test / bench commands (0 in production)
+        model._ctx_for(S).set_option("dev_select", int(os.environ["YL_DEV_SELECT"], 0))
     return dict(meta=meta, sd=sd, model=model, ctx=model._ctx_for(S), prog=model.program, seed=seed,
                 x=synth_images(B, S, seed=1234 + rank).to(dev))
 

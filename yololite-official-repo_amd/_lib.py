@@ -56,6 +56,7 @@ DEV_WINO_V1 = 1 << 11            # Winograd: yl_conv_wino_kernel (every position
 DEV_DWL_OFF = 1 << 14             # depthwise 3x3 -> wide 1x1: yl_conv_dwk_kernel instead of yl_conv_dwl_kernel (window in LDS)
 DEV_DWL_ALL = 1 << 15             # ... yl_conv_dwl_kernel on every grid (partial windows, few items: the bitwise test)
 DEV_DPW_OFF = 1 << 16             # fused head launch: yl_conv_dpp_kernel (taps from L1/L2) instead of yl_conv_dpw_kernel (window in LDS)
+DEV_K3W_OFF = 1 << 17             # small-channel dense 3x3: Winograd / direct kernels instead of yl_conv_k3w_kernel
 DEV_WINO_SHAPE_SHIFT = 12         # yl_conv_wino2_kernel item shape (2 bits): 0 auto, 1 (4,4), 2 (2,7), 3 two m-tiles
 
 _fp = C.POINTER(C.c_float)

@@ -438,12 +438,21 @@ yl_status ensure_act(yl_ctx* c, int B, int n) {
     c->plan_reuse = reuse;
     plan_slots(c, reuse);
     for (int i = 0; i < newn; ++i) {
-      if (c->arena_unit) HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)capi[i] + 256));   // (+256: yl_conv_wino2_kernel's unmasked channel tail)
+      // + 256 spare bytes, and the arena starts out as zeros: the kernels that read through buffer descriptors do not mask the
+      // channel tail of a tensor's last k-block -- those lanes read up to 48 bytes behind the pixel (the next pixel, the next slot,
+      // at the very end the spare bytes) and meet zero weights; 0 x garbage must not be 0 x NaN on the first run after an allocation
+      if (c->arena_unit) {
+        HIPCHK(c, hipMalloc((void**)&c->arena[i], c->arena_unit * (size_t)capi[i] + 256));
+        HIPCHK(c, hipMemset(c->arena[i], 0, c->arena_unit * (size_t)capi[i] + 256));
+      }
       if (c->se_unit) HIPCHK(c, hipMalloc((void**)&c->se_scratch[i], c->se_unit * sizeof(float) * (size_t)capi[i]));
       c->arena_capi[i] = capi[i];
     }
     for (auto& s : c->slots)
-      if (s.pinned) HIPCHK(c, hipMalloc((void**)&s.pin, s.sz * (size_t)newB + 256));
+      if (s.pinned) {
+        HIPCHK(c, hipMalloc((void**)&s.pin, s.sz * (size_t)newB + 256));
+        HIPCHK(c, hipMemset(s.pin, 0, s.sz * (size_t)newB + 256));
+      }
     for (int l = 0; l < c->L; ++l)
       HIPCHK(c, hipMalloc((void**)&c->level_buf[l],
                           (size_t)newB * c->level_A[l] * c->level_S[l] * c->level_S[l] * c->E * sizeof(float)));
@@ -842,6 +851,9 @@ yl_status run_layers(yl_ctx* c, const float* x, int b0, int B, float* const* lev
       }
       case YL_OP_STEM: e = c->opt_bf16 == 3 ? yl_launch_stem_f16s(p, ls) : yl_launch_stem(p, ls); break;
       case YL_OP_CONV:
+        // small-channel dense 3x3 on large grids: window-in-LDS kernel (fp32 units only; "tile_m" 6 keeps the generic kernel)
+        e = (!c->opt_bf16 && c->opt_tile_m != 6) ? yl_launch_conv_k3w(p, ls) : hipErrorNotSupported;
+        if (e != hipErrorNotSupported) break;
         e = c->opt_bf16 == 1 ? yl_launch_conv_bf16(p, c->opt_tile_m, ls)
             : c->opt_bf16 == 2 ? yl_launch_conv_f16(p, c->opt_tile_m, ls)
             : c->opt_bf16 == 3 ? yl_launch_conv_f16s(p, c->opt_tile_m, ls) : yl_launch_conv(p, c->opt_tile_m, ls);
@@ -1712,7 +1724,7 @@ yl_status yl_set_option(yl_ctx* c, const char* name, int32_t value) {
   if (!strcmp(name, "tile_m")) { c->opt_tile_m = value; drop_graph(c); return YL_OK; }
   if (!strcmp(name, "streams")) { c->opt_streams = value < 1 ? 1 : (value > 4 ? 4 : value); drop_graph(c); return YL_OK; }
   if (!strcmp(name, "split_k")) { c->opt_split_k = value ? 1 : 0; drop_graph(c); return YL_OK; }
-  if (!strcmp(name, "dev_select")) { c->opt_dev = value & 0xffffff; drop_graph(c); return YL_OK; }
+  if (!strcmp(name, "dev_select")) { c->opt_dev = value & 0x3ffffff; drop_graph(c); return YL_OK; }
   return fail(c, YL_ERR_INVALID, std::string("unknown option ") + name);
 }
 

@@ -278,12 +278,12 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     return b[buf * WSL + 24 * (tap / 3) + 4 * (tap % 3)];
   };
 
-  // window copies through a raw buffer descriptor (round 6): 32-bit byte offset per copy fixed for the tile + scalar k-block
-  // offset (with global_load_lds the instruction offset also moves the LDS address, so every request paid a 64-bit add);
-  // lanes outside the image carry an out-of-range offset: the copy writes zeros
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(xin), 0, (int)((long)p.B * H * W * Cin * 4), 0x00020000);
-  struct Src { unsigned s[3]; };
+  // (Round 6 tried these copies through a raw buffer descriptor -- `buffer_load_dwordx4 ... offen lds`, scalar k-block offset, no
+  // 64-bit add per request: +1.1 % on the headline -- and took it back: the ring below waits with PARTIAL counts (vmcnt(3 (NBUF - 1)):
+  // "everything but the two youngest windows has landed"), which needs the copies to complete in issue order; with the buffer form
+  // the FIRST launch on freshly allocated arenas lost a detection in 5 of 100 fresh processes (tools/flake_dbg.py; 0 of 100 with
+  // global_load_lds, bisected to that commit).  The kernels that use the buffer form wait for vmcnt(0).)
+  struct Src { const float* s[3]; };
   auto setup = [&](int tile, Src& src, YlPix& px) {
     const bool tv = tile < r1;
     const int tc = tv ? tile : r1 - 1;
@@ -296,15 +296,14 @@ __global__ __launch_bounds__(DPW_NW * 64, DPW_NW / 4) void yl_conv_dpw_kernel(Yl
     for (int j = 0; j < 3; ++j) {
       const int gy = 4 * tyi - 1 + cy[j], gxx = 4 * txi - 1 + cx[j];
       const bool in = tv && cq[j] >= 0 && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
-      src.s[j] = in ? (unsigned)((((b * H + gy) * W + gxx) * Cin + 4 * cq[j]) * 4) : 0x80000000u;
+      src.s[j] = in ? xin + (((long)b * H + gy) * W + gxx) * Cin + 4 * cq[j] : p.zeros;
     }
   };
   auto request = [&](const Src& src, int kb, int buf) {
     if (DPW_ABL & 8) return;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      if (j < 2 || WSL == 192 || lane < 16)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(winl + buf * WSL + j * 64), 16, (int)src.s[j], kb * 64, 0, 0);
+      if (j < 2 || WSL == 192 || lane < 16) yl_glds16(src.s[j] + kb * 16, winl + buf * WSL + j * 64);
   };
 
   Src cs, ns;
@@ -870,6 +869,164 @@ hipError_t yl_launch_conv_dpp(const YlConvP* ps, int n, hipStream_t st) {
   YL_DPP_SHAPES(YL_DPP_RUN)
 #undef YL_DPP_RUN
   return hipErrorNotSupported;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense 3x3 (stride 1, pad 1) with FEW channels on both sides -- 16 or 32 in, <= 16 out -- on large grids (round 6): the first
+// fused-MBConv blocks of efficientnetv2 (timm `er` / `cn` blocks behind model_v2.py:94-100: 32 -> 16 and 16 -> 16 at 320 x 320).
+// They ran through yl_conv_wino_kernel with one of its two n-tiles empty (0.48 / 0.34 ms at B = 32: 206 vector instructions per
+// 128 MFMAs of which 64 are useful) or, without Winograd, through yl_conv_mfma_kernel's nine fragment-shaped tap loads per
+// k-block.  Here, with the machinery of yl_conv_dpw_kernel: one WAVE = one 4 x 4-pixel m-tile; its 6 x 6-pixel input window of
+// every 16-channel block lands in a wave-private LDS region by buffer-descriptor LDS-DMA copies (quads on the 64 contiguous bytes
+// of one pixel; pixels outside the image: out-of-range offset = zeros), the 9 KB taps are conflict-free ds_read_b128 in fragment
+// order, ALL weight fragments (9 taps x KB blocks, one n-tile) live in registers for the whole launch, and the next tile's
+// windows are requested as soon as this tile's taps are in registers -- they fly under its 36 KB MFMAs.  No workgroup barrier, no
+// vector instruction computes an address.  Same k order (tap-major, k-blocks inside), pre-add rule and epilogues as
+// yl_conv_mfma_kernel: BIT-IDENTICAL to the direct path ("dev_select" bit 17 switches the kernel off; tests/test_gpu_parity.py).
+#define K3W_NW 8
+template <int KB /*Cin/16*/>
+__global__ __launch_bounds__(K3W_NW * 64, 2) void yl_conv_k3w_kernel(YlConvP p) {
+  constexpr int Cin = KB * 16, WSL = 192;
+  extern __shared__ __attribute__((aligned(16))) float dpp_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, pl = lane & 15;
+  f32x4* const winl = reinterpret_cast<f32x4*>(dpp_lds) + wave * (KB * WSL);      // the wave's windows: [KB][WSL] float4
+  f32x4 wr[9][KB];                                                   // A fragments of (tap, k-block): pack_conv [tap][kb][1 n-tile][64]
+  {
+    const f32x4* const wg = reinterpret_cast<const f32x4*>(p.wp);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) wr[tap][kb] = wg[(tap * KB + kb) * 64 + lane];
+  }
+  const int H = p.H, W = p.W, OW = p.OW, OH = p.OH, N = p.N;
+  const int tw = OW >> 2, th = OH >> 2;
+  const int tiles_img = tw * th;
+  const int ntiles = p.B * tiles_img;
+  const int bx = blockIdx.x, gx = gridDim.x;
+  int r0, r1;                                                        // XCD bands, see yl_conv_dpp_kernel
+  if ((gx & 7) == 0) {
+    const int x = bx & 7, j = bx >> 3, nj = gx >> 3;
+    const long b0 = ((long)ntiles * x) >> 3, b1 = ((long)ntiles * (x + 1)) >> 3;
+    r0 = (int)(b0 + ((b1 - b0) * j) / nj);
+    r1 = (int)(b0 + ((b1 - b0) * (j + 1)) / nj);
+  } else {
+    r0 = (int)(((long)ntiles * bx) / gx); r1 = (int)(((long)ntiles * (bx + 1)) / gx);
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)((long)p.B * H * W * Cin * 4), 0x00020000);
+  const bool pre_add = p.res != nullptr && p.act == YL_ACT_NONE;     // (as yl_conv_mfma_kernel: the addend initialises the accumulator)
+  const float lo = (p.act == YL_ACT_RELU || p.act == YL_ACT_RELU6) ? 0.0f : -INFINITY;
+  const float hi = (p.act == YL_ACT_RELU6) ? 6.0f : INFINITY;
+  // copy role of the lane in copy j: slot 64 j + lane = (pixel P = y * 6 + x of the window, stored quad) -- yl_conv_dpw_kernel's layout
+  int cy[3], cx[3], cq[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int s = 64 * j + lane, P = s >> 2;
+    cy[j] = P / 6; cx[j] = P - 6 * cy[j];
+    cq[j] = s < 144 ? ((s & 3) ^ ((cy[j] & 1) << 1)) : -1;
+  }
+  const int sy = pl >> 2, sx = pl & 3;
+  const f32x4* const tb0 = winl + 4 * (6 * sy + sx) + (kq ^ ((sy & 1) << 1));          // rows sy, sy + 2
+  const f32x4* const tb1 = winl + 4 * (6 * sy + sx) + (kq ^ (((sy + 1) & 1) << 1));    // row sy + 1
+  auto tap_at = [&](int kb, int tap) -> f32x4 {
+    const f32x4* const b = (tap / 3) == 1 ? tb1 : tb0;
+    return b[kb * WSL + 24 * (tap / 3) + 4 * (tap % 3)];
+  };
+  struct Src { unsigned s[3]; };
+  auto setup = [&](int tile, Src& src, YlPix& px) {
+    const bool tv = tile < r1;
+    const int tc = tv ? tile : r1 - 1;
+    const int b = tc / tiles_img;
+    const int trem = tc - b * tiles_img;
+    const int tyi = trem / tw, txi = trem - tyi * tw;
+    px.b = b; px.oy = 4 * tyi + sy; px.ox = 4 * txi + sx; px.valid = tv;
+    px.lin = ((size_t)b * OH + px.oy) * OW + px.ox;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int gy = 4 * tyi - 1 + cy[j], gxx = 4 * txi - 1 + cx[j];
+      const bool in = tv && cq[j] >= 0 && gy >= 0 && gy < H && gxx >= 0 && gxx < W;
+      src.s[j] = in ? (unsigned)((((b * H + gy) * W + gxx) * Cin + 4 * cq[j]) * 4) : 0x80000000u;
+    }
+  };
+  auto request = [&](const Src& src) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        // (all 64 lanes, also in the third copy whose lanes >= 16 carry the out-of-range offset and write zeros into unused slots:
+        //  an exec-masked LDS-DMA copy issued at the start of the kernel left the first window of every wave wrong)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(winl + kb * WSL + j * 64), 16, (int)src.s[j], kb * 64, 0, 0);
+  };
+  Src cs, ns;
+  YlPix pxc, pxn;
+  int tile = r0 + wave;
+  setup(tile, cs, pxc);
+  if (tile < r1) request(cs);
+  while (tile < r1) {
+    const int next = tile + K3W_NW;
+    setup(next, ns, pxn);
+    f32x4 acc[1][1];
+    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pre_add) {
+      const int n = 4 * kq;
+      if (n < N) acc[0][0] = yl_ld4(p.res + pxc.lin * N + n);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): this tile's windows (and the residual row) have landed;
+    asm volatile("" ::: "memory");                                   // the builtin keeps the compiler's counter model right, the asm keeps
+    f32x4 xt[KB][9];                                                 // the tap reads below it
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) xt[kb][tap] = tap_at(kb, tap);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the taps are in registers: the windows are free
+    if (next < r1) request(ns);                                      // the next tile's windows fly under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[tap][kb][st], xt[kb][tap][st], acc[0][0], 0, 0, 0);
+    const YlPix pxd[1] = {pxc};
+    if (!pre_add && (p.res || YL_SMOOTH(p.act))) yl_epi_generic<1, 1>(p, acc, pxd, 0, kq);
+    else yl_epi_fast<1, 1>(p, acc, pxd, 0, kq, lo, hi, true);
+    tile = next;
+    cs = ns; pxc = pxn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no copy may land in LDS after the wave has ended
+}
+
+template <int KB>
+static hipError_t k3w_go(const YlConvP& p, hipStream_t st) {
+  const size_t lds = (size_t)K3W_NW * KB * 192 * 16;
+  const long t = (long)p.B * (p.OH >> 2) * (p.OW >> 2);
+  static int res = 0;
+  if (!res) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)yl_conv_k3w_kernel<KB>, K3W_NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
+    if (nb > 2) nb = 2;
+    res = nb * YL_NUM_CU;
+  }
+  long nb = res;
+  if (nb > (t + K3W_NW - 1) / K3W_NW) nb = (t + K3W_NW - 1) / K3W_NW;
+  if (nb >= 8) nb &= ~7L;
+  hipLaunchKernelGGL((yl_conv_k3w_kernel<KB>), dim3((unsigned)nb), dim3(K3W_NW * 64), lds, st, p);
+  return hipGetLastError();
+}
+
+// dense 3x3 stride-1 pad-1 layers with 16 / 32 input and <= 16 output channels (one n-tile), 4x4-tileable grids with enough tiles
+// to fill the chip; fp32 storage and arithmetic only (the caller keeps the reduced-precision units on their own kernels)
+hipError_t yl_launch_conv_k3w(const YlConvP& p, hipStream_t st) {
+  if (p.k != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.dw_k > 0 || p.C1 > 0 || p.w3p || p.up || p.dec_boxes || p.scale ||
+      p.in_shift || p.ldo || (p.N & 3) || p.NTtot != 1 || (p.Cin != 16 && p.Cin != 32) || (p.OH & 3) || (p.OW & 3) || p.H != p.OH || p.W != p.OW ||
+      (p.dev & YL_DEV_K3W_OFF))
+    return hipErrorNotSupported;
+  if ((long)p.B * (p.OH >> 2) * (p.OW >> 2) < 4L * K3W_NW * YL_NUM_CU) return hipErrorNotSupported;    // (small grids: the other kernels)
+  if ((size_t)p.B * p.H * p.W * p.Cin * 4 >= ((size_t)1 << 31)) return hipErrorNotSupported;            // 32-bit byte offsets
+  return p.Cin == 16 ? k3w_go<1>(p, st) : k3w_go<2>(p, st);
 }
 
 hipError_t yl_dpp_init() {

@@ -156,6 +156,7 @@ struct YlConvP {
 #define YL_DEV_DWL_OFF (1u << 14)      // depthwise 3x3 -> wide 1x1: yl_conv_dwk_kernel (taps from L1/L2) instead of yl_conv_dwl_kernel
 #define YL_DEV_DWL_ALL (1u << 15)      // ... yl_conv_dwl_kernel on every grid it supports (partial windows, few items: the bitwise test)
 #define YL_DEV_DPW_OFF (1u << 16)      // fused head launch: yl_conv_dpp_kernel (taps from L1/L2) instead of yl_conv_dpw_kernel (window in LDS)
+#define YL_DEV_K3W_OFF (1u << 17)     // small-channel dense 3x3: the Winograd / direct kernels instead of yl_conv_k3w_kernel (bitwise A/B)
 
 // squeeze-excite gate (yl_se.hip): fixed-order two-pass spatial mean + the two FCs + sigmoid
 struct YlSeP {
@@ -232,6 +233,8 @@ hipError_t yl_dpp_init();
 hipError_t yl_launch_conv_s2c(const YlConvP& p, hipStream_t st);
 // depthwise 3x3 -> 1x1 expand -> 1x1 project (+residual) as one launch (yl_dpp.hip)
 hipError_t yl_launch_conv_dpq(const YlConvP& p, hipStream_t st);
+// dense 3x3 with 16 / 32 -> <= 16 channels on large grids, window in LDS (yl_dpp.hip, round 6; fp32 only)
+hipError_t yl_launch_conv_k3w(const YlConvP& p, hipStream_t st);
 bool yl_dpq_supported(int cin, int cmid, int cout, int oh, int ow);
 bool yl_stemblock_supported(int c1, int c2, int c3);
 hipError_t yl_conv_init();
