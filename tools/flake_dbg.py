@@ -1,9 +1,14 @@
-"""The edge_n B=64 parity test's sequence in a fresh process; on a mismatch between the eager and the bench schedule say which one moved."""
+"""The full-size parity test's sequence in a fresh process (python tools/flake_dbg.py [model B seg]); on a mismatch between the eager and the
+bench schedule (graph replay, two chunk streams: its FIRST launch runs on freshly allocated arenas) say which one moved.  Round 6: caught a
+rare first-launch error of the buffer-descriptor LDS-DMA form of yl_conv_dpw_kernel (5 of 100 processes)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from yololite_amd import _lib
-wl = bench.build_workload("edge_n", 640, 64, seed=1, dev="cuda:0", rank=0)
+NAME = sys.argv[1] if len(sys.argv) > 1 else "edge_n"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+SEG = len(sys.argv) > 3 and sys.argv[3] == "1"
+wl = bench.build_workload(NAME, 640, B, seed=1, dev="cuda:0", rank=0, seg=SEG)
 ctx, x = wl["ctx"], wl["x"]
 mo = bench.MAX_OUT
 def pred():
