@@ -526,33 +526,37 @@ def test_winograd_position_split_kernel_is_bitwise_the_first_form(name, B, S, se
 
 
 def test_small_channel_3x3_window_kernel_is_bitwise_the_direct_kernel():
-    """yl_conv_k3w_kernel (round 6: dense 3x3, 16 / 32 -> <= 16 channels on large grids -- efficientnetv2's first fused-MBConv blocks at
-    320 x 320 -- one wave per 4 x 4-pixel tile, 6 x 6 window of every 16-channel block in wave-private LDS, all weight fragments in
-    registers) keeps the k order (tap-major, k-blocks inside), the pre-add rule and the epilogues of yl_conv_mfma_kernel -> identical
-    bits to the direct path ("winograd" 0) with the kernel switched off ("dev_select" bit 17); under the default options it replaces
-    the first-form Winograd kernel on those layers: within 1e-4 of it and inside the oracle bound.  640 x 640, B = 3: 19 200 tiles
-    (the launcher wants >= 8192)."""
+    """yl_conv_k3w_kernel (round 6: dense 3x3, 16 / 32 -> <= 16 channels on grids of >= 160 x 160 pixels -- efficientnetv2's first
+    fused-MBConv blocks at 320 x 320 -- one wave per 4 x 4-pixel tile, 6 x 6 window of every 16-channel block in wave-private LDS, all
+    weight fragments in registers) keeps the k order (tap-major, k-blocks inside), the pre-add rule and the epilogues of
+    yl_conv_mfma_kernel -> identical bits to the direct path ("winograd" 0) with the kernel switched off ("dev_select" bit 17).  It runs
+    only where the direct kernel would (under the default options those layers stay with Winograd: same results as before), selected
+    by shape and not by batch (B = 1 and B = 3 take it alike)."""
     meta = zoo_meta("yololite_m_v2", 80, 640)
     sd = synth_state_dict(meta, seed=9)
     m = _hip_for(meta, sd)
     ctx = m._ctx_for(640)
     x = _x(3, 640, seed=21)
     xd = x.to(DEV)
-    def run(wino, dev):
+    def run(wino, dev, xin=None):
         ctx.set_option("winograd", wino)
         ctx.set_option("dev_select", dev)
-        return [t.clone() for t in m(xd)]
+        return [t.clone() for t in m(xd if xin is None else xin)]
     direct_off, direct_on = run(0, _lib.DEV_K3W_OFF), run(0, 0)
     for u, v in zip(direct_off, direct_on):
         assert torch.equal(u, v)
+    one = run(0, 0, xd[1:2])                                                 # batch invariance with the kernel on
+    for u, v in zip(direct_on, one):
+        assert torch.equal(u[1:2], v)
     wino_off, wino_on = run(1, _lib.DEV_K3W_OFF), run(1, 0)
-    assert any(not torch.equal(u, v) for u, v in zip(wino_off, wino_on))     # the kernel really takes layers away from Winograd
     for u, v in zip(wino_off, wino_on):
-        assert float((u - v).abs().max()) <= 1e-4
+        assert torch.equal(u, v)                                             # the default options do not see the kernel
+    assert any(not torch.equal(u, v) for u, v in zip(direct_on, wino_on))
     ctx.set_option("dev_select", 0)
     with torch.no_grad():
         ref = _oracle_for(meta, sd)(x)
-    _cmp_levels(wino_on, ref, C=80)
+    _cmp_levels(direct_on, ref, C=80)
+    ctx.set_option("winograd", 1)
 
 
 @pytest.mark.parametrize("name,B,S", [("edge_m", 2, 320), ("edge_m", 3, 224), ("yololite_m", 2, 256), ("edge_l", 1, 320),
